@@ -1,0 +1,211 @@
+"""CPU oracle for the CamRaDepth forward pass. TEST INFRASTRUCTURE ONLY.
+
+This is a plain-PyTorch (CPU, fp32) restatement of the reference model written as pure
+functions over a `state_dict` with the reference's key names. Only tests/, bench.py's
+`cpu_baseline` leg and `__graft_entry__.smoke()` may import it; the product path
+(camradepth_amd/) never does.
+
+Parity status: PINNED. `tests/golden/make_golden.py` imports the real reference
+(/root/reference, CPU) and stores its outputs; `tests/test_oracle_golden.py` checks this file
+against those fixtures.  Third-party arithmetic (torch conv/group_norm/gelu/upsample_bicubic2d,
+timm DropPath) is unpinned by the reference itself (it has no tests) and is pinned here only
+through those fixtures (torch 2.10 CPU).
+
+`quant="bf16"` rounds tensors to bf16 at the points where CUDA autocast does in the reference's
+training loop (conv / matmul inputs, weights and outputs; src/main/runner.py:191) while
+accumulating in fp32. That mode exists to compare against the bf16 HIP path at a tight tolerance.
+"""
+import math
+import torch
+import torch.nn.functional as F
+
+GN_DIV = 16  # reference: src/utils/args.py:38 (groupnorm_divisor)
+
+
+def _q(t, quant):
+    if quant == "bf16" and t is not None:
+        return t.to(torch.bfloat16).to(torch.float32)
+    return t
+
+
+def _conv2d(x, w, b, quant, **kw):
+    """Conv2d under autocast: low-precision operands and result, fp32 accumulation."""
+    return _q(F.conv2d(_q(x, quant), _q(w, quant), _q(b, quant), **kw), quant)
+
+
+def _conv1d(x, w, b, quant):
+    return _q(F.conv1d(_q(x, quant), _q(w, quant), _q(b, quant)), quant)
+
+
+def _gn(x, sd, name, groups):
+    return F.group_norm(x, groups, sd[name + ".weight"], sd[name + ".bias"], 1e-5)
+
+
+def patch_embed(sd, name, x, k, stride, quant=None):
+    """OverlapPatchEmbed.forward (reference: src/models/simplified_attention.py:183-188)."""
+    y = _conv2d(x, sd[name + ".proj.weight"], sd[name + ".proj.bias"], quant, stride=stride, padding=k // 2)
+    H, W = y.shape[2], y.shape[3]
+    y = _gn(y, sd, name + ".norm", y.shape[1] // GN_DIV)
+    return y.flatten(2), H, W
+
+
+def attention_maxpool(sd, name, x, H, W, heads, sr, quant=None, taps=None):
+    """Attention_MaxPool.forward (reference: src/models/simplified_attention.py:90-109)."""
+    B, C, N = x.shape
+    d = C // heads
+    scale = d ** -0.5
+    q = _conv1d(x, sd[name + ".q.weight"], sd[name + ".q.bias"], quant)
+    q = q.reshape(B, heads, d, N).permute(0, 1, 3, 2)
+    if sr > 1:
+        x_ = x.reshape(B, C, H, W)
+        x_ = _conv2d(x_, sd[name + ".sr.weight"], sd[name + ".sr.bias"], quant, stride=sr).reshape(B, C, -1)
+        x_ = _gn(x_, sd, name + ".norm", C // GN_DIV)
+        k = _conv1d(x_, sd[name + ".k.weight"], sd[name + ".k.bias"], quant).reshape(B, heads, d, -1)
+    else:
+        k = _conv1d(x, sd[name + ".k.weight"], sd[name + ".k.bias"], quant).reshape(B, heads, d, -1)
+    v = torch.mean(x, 2, True).repeat(1, 1, heads).transpose(-2, -1)      # [B, heads, C]
+    attn = _q(_q(q @ k, quant) * scale, quant)                            # [B, heads, N, M]
+    attn, idx = torch.max(attn, -1)                                       # [B, heads, N]
+    if taps is not None:
+        taps[name + ".rowmax"] = attn
+    out = _q(_q(attn.transpose(-2, -1), quant) @ _q(v, quant), quant)     # [B, N, C]
+    out = out.transpose(-2, -1)
+    return _conv1d(out, sd[name + ".proj.weight"], sd[name + ".proj.bias"], quant)
+
+
+def mlp(sd, name, x, H, W, dim, quant=None):
+    """Mlp.forward + DWConv.forward (reference: simplified_attention.py:34-43, 318-323)."""
+    B = x.shape[0]
+    h = _conv1d(x, sd[name + ".fc1.weight"], sd[name + ".fc1.bias"], quant)
+    hid = h.shape[1]
+    h = _gn(h, sd, name + ".norm1", hid // GN_DIV)
+    h = _conv2d(h.reshape(B, hid, H, W), sd[name + ".dwconv.dwconv.weight"], sd[name + ".dwconv.dwconv.bias"],
+                quant, padding=1, groups=hid).flatten(2)
+    h = _gn(h, sd, name + ".norm2", dim // GN_DIV)        # groups from out_features (:24)
+    h = F.gelu(h)
+    return _conv1d(h, sd[name + ".fc2.weight"], sd[name + ".fc2.bias"], quant)
+
+
+def block(sd, name, x, H, W, heads, sr, quant=None, drop_path=None, taps=None):
+    """Block.forward (reference: simplified_attention.py:141-145). drop_path: [B] scaled mask or None."""
+    C = x.shape[1]
+    dp = (lambda t: t) if drop_path is None else (lambda t: t * drop_path.view(-1, 1, 1))
+    xn = _gn(x, sd, name + ".norm1", C // GN_DIV)
+    x = x + dp(attention_maxpool(sd, name + ".attn", xn, H, W, heads, sr, quant, taps))
+    x = x + dp(mlp(sd, name + ".mlp1", _gn(x, sd, name + ".norm2", C // GN_DIV), H, W, C, quant))
+    return x
+
+
+def encoder(sd, x, cfg, quant=None, masks=None, taps=None):
+    """SimplifiedTransformer.forward_features (reference: simplified_attention.py:265-306)."""
+    B = x.shape[0]
+    outs, bi = [], 0
+    for s in range(4):
+        k, stride = (7, 4) if s == 0 else (3, 2)
+        x, H, W = patch_embed(sd, f"dest_encoder.patch_embed{s + 1}", x, k, stride, quant)
+        for i in range(cfg.depths[s]):
+            dp = None if masks is None else masks["drop_path"][bi]
+            x = block(sd, f"dest_encoder.block{s + 1}.{i}", x, H, W, cfg.heads[s], cfg.reduction_ratio[s],
+                      quant, dp, taps)
+            bi += 1
+        x = x.reshape(B, -1, H, W).contiguous()
+        outs.append(x)
+    return outs
+
+
+def conv_layer(sd, name, x, k, quant=None):
+    """ConvLayer.forward: conv(no bias) -> GroupNorm(Cout/16) -> GELU (reference: src/utils/utils.py:210-228)."""
+    w = sd[name + ".model.0.weight"]
+    y = _conv2d(x, w, None, quant, padding=k // 2)
+    return F.gelu(_gn(y, sd, name + ".model.1", w.shape[0] // GN_DIV))
+
+
+def short_res_block(sd, name, x, quant=None):
+    """ShortResBlock.forward (reference: src/utils/utils.py:127-135)."""
+    for li in range(2):
+        out = conv_layer(sd, f"{name}.layers.{li}", x, 3, quant)
+        x = torch.cat((x, out), dim=1)
+    return conv_layer(sd, f"{name}.layers.2", x, 3, quant)
+
+
+def bicubic2x(x):
+    """nn.Upsample(scale_factor=2, mode='bicubic') (reference: src/utils/utils.py:241)."""
+    return F.interpolate(x, scale_factor=2, mode="bicubic")
+
+
+def decoder_stage(sd, name, x, skip=None, quant=None):
+    """Decoder.forward (reference: src/utils/utils.py:249-257)."""
+    x = bicubic2x(x)
+    if skip is not None:
+        x = torch.cat((x, skip), dim=1)
+    return short_res_block(sd, name + ".conv", x, quant)
+
+
+def depth_activation(sd, name, x, quant=None):
+    """Depth_Activation.forward (reference: src/utils/utils.py:285-289)."""
+    z = _conv2d(x, sd[name + ".conv_1.weight"], sd[name + ".conv_1.bias"], quant, padding=1)
+    a = torch.sigmoid(z)
+    return _conv2d(a, sd[name + ".conv_2.weight"], sd[name + ".conv_2.bias"], quant, padding=1)
+
+
+def seg_block(logits, num_classes):
+    """Seg_Block.forward: argmax / num_classes, no gradient (reference: src/utils/utils.py:95-100)."""
+    return torch.argmax(logits, dim=1, keepdim=True) / num_classes
+
+
+def forward(sd, x, cfg, quant=None, masks=None, taps=None):
+    """CamRaDepth.forward (reference: src/models/CamRaDepth.py:99-176).
+
+    masks: None (eval) or the dict of synth.make_masks (train mode with injected Dropout2d /
+    DropPath masks). Returns the reference's nested output dict.
+    """
+    d2 = iter(masks["dropout2d"]) if masks is not None else None
+    drop = (lambda t: t) if masks is None else (lambda t: t * next(d2).view(t.shape[0], t.shape[1], 1, 1))
+    outs = encoder(sd, x, cfg, quant, masks, taps)
+    if taps is not None:
+        for i, o in enumerate(outs):
+            taps[f"enc{i + 1}"] = o
+    e1 = conv_layer(sd, "from_encoder_1", outs[3], 1, quant)
+    e2 = conv_layer(sd, "from_encoder_2", outs[2], 1, quant)
+    e3 = conv_layer(sd, "from_encoder_3", outs[1], 1, quant)
+    e4 = conv_layer(sd, "from_encoder_4", outs[0], 1, quant)
+    s1 = drop(decoder_stage(sd, "depth_upsample.0", e1, e2, quant))
+    s2 = drop(decoder_stage(sd, "depth_upsample.1", s1, e3, quant))
+    s3 = drop(decoder_stage(sd, "depth_upsample.2", s2, e4, quant))
+    d3 = depth_activation(sd, "depth_activation_3", s3, quant)
+    s3 = torch.cat([s3, d3], 1)
+    s4 = drop(decoder_stage(sd, "depth_upsample.3", s3, None, quant))
+    sup_map = unsup_map = seg_map = seg_feat = seg_final = None
+    if cfg.supervised_seg or cfg.unsupervised_seg:
+        seg_feat = drop(decoder_stage(sd, "seg_upsample.0", s3, None, quant))
+    if cfg.supervised_seg:
+        sup_map = seg_block(_conv2d(seg_feat, sd["seg_conv_stage_4.weight"], sd["seg_conv_stage_4.bias"], quant,
+                                    padding=1), cfg.num_classes)
+        seg_map = sup_map
+    if cfg.unsupervised_seg:
+        unsup_map = seg_block(_conv2d(seg_feat, sd["unsup_stage_4.weight"], sd["unsup_stage_4.bias"], quant,
+                                      padding=1), 19)
+        seg_map = unsup_map if sup_map is None else torch.cat([sup_map, unsup_map], 1)
+    if cfg.supervised_seg:
+        seg_feat = torch.cat((seg_feat, sup_map), dim=1)
+    elif cfg.unsupervised_seg:
+        seg_feat = torch.cat((seg_feat, unsup_map), dim=1)
+    tmp = torch.cat((s4, seg_map), dim=1) if seg_map is not None else s4
+    d4 = depth_activation(sd, "depth_activation_4", tmp, quant)
+    s4 = torch.cat([s4, d4], 1)
+    s5 = drop(decoder_stage(sd, "depth_upsample.4", s4, x, quant))
+    if cfg.supervised_seg or cfg.unsupervised_seg:
+        seg_feat = drop(decoder_stage(sd, "seg_upsample.1", seg_feat, x, quant))
+    if cfg.supervised_seg:
+        seg_final = _conv2d(seg_feat, sd["seg_conv_final.weight"], sd["seg_conv_final.bias"], quant, padding=1)
+        sup_map = seg_block(seg_final, cfg.num_classes)
+        seg_map = sup_map
+    if cfg.unsupervised_seg:
+        unsup_map = seg_block(_conv2d(seg_feat, sd["unsup_final.weight"], sd["unsup_final.bias"], quant, padding=1), 19)
+        seg_map = unsup_map if sup_map is None else torch.cat([sup_map, unsup_map], 1)
+    tmp = torch.cat((s5, seg_map), dim=1) if seg_map is not None else s5
+    final = depth_activation(sd, "depth_activation_5", tmp, quant)
+    if taps is not None:
+        taps.update({"s1": s1, "s2": s2, "s3": s3, "s4": s4, "s5": s5})
+    return {"depth": {"intermediate_depths": (None, None, d3, d4), "final_depth": final},
+            "seg": {"final_seg": seg_final, "intermediate_seg": None, "unsup_map": unsup_map}}

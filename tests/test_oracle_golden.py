@@ -1,0 +1,189 @@
+"""Pins the CPU oracle (oracle/) against fixtures produced by the imported reference
+(tests/golden/make_golden.py). CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from camradepth_amd import synth
+from camradepth_amd.config import ModelConfig
+from camradepth_amd.params import param_specs
+from oracle import losses as olosses
+from oracle import model as omodel
+from oracle import optim as ooptim
+from tests.util import golden_state_dict, load_npz, max_err, param_order, rel_err, subsample
+
+VARIANTS = ["base", "supervised_seg", "unsupervised_seg", "sup_unsup_seg"]
+TOL = 2e-5  # fp32 CPU vs fp32 CPU, different op grouping only
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_param_inventory_matches_reference(variant):
+    cfg = ModelConfig.variant(variant)
+    ref = param_order(variant)
+    mine = [[n, list(s)] for n, s in param_specs(cfg)]
+    assert mine == ref["params"]
+    assert [n for n, _ in mine] == ref["state_dict_keys"]
+    assert sum(int(np.prod(s)) for _, s in mine) == ref["num_params"]
+    if variant == "base":
+        assert ref["num_params"] == 21966595 and len(mine) == 881
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_forward_eval_64x96(variant):
+    cfg = ModelConfig.variant(variant)
+    sd = golden_state_dict(cfg)
+    g = load_npz(f"forward64x96_{variant}.npz")
+    batch = synth.make_batch(1, 64, 96, seed=1234)
+    taps = {}
+    with torch.no_grad():
+        out = omodel.forward(sd, batch["image"], cfg, taps=taps)
+    for i in range(4):
+        assert max_err(taps[f"enc{i + 1}"].numpy(), g[f"eval_enc{i + 1}"]) < 1e-4
+    assert max_err(out["depth"]["final_depth"].numpy(), g["eval_final_depth"]) < TOL
+    assert max_err(out["depth"]["intermediate_depths"][3].numpy(), g["eval_depth_half"]) < TOL
+    assert max_err(out["depth"]["intermediate_depths"][2].numpy(), g["eval_depth_quarter"]) < TOL
+    if cfg.supervised_seg:
+        assert max_err(subsample(out["seg"]["final_seg"], 32768), g["eval_final_seg"]) < 1e-4
+    if cfg.unsupervised_seg:
+        assert np.array_equal(out["seg"]["unsup_map"].numpy(), g["eval_unsup_map"])
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("mode", ["evalgrad", "train"])
+def test_loss_and_grads_64x96(variant, mode):
+    cfg = ModelConfig.variant(variant)
+    sd = {k: v.clone().requires_grad_(True) for k, v in golden_state_dict(cfg).items()}
+    g = load_npz(f"forward64x96_{variant}.npz")
+    batch = synth.make_batch(2, 64, 96, seed=77)
+    masks = synth.make_masks(cfg, 2, seed=4321) if mode == "train" else None
+    x = batch["image"].clone().requires_grad_(True)
+    out = omodel.forward(sd, x, cfg, masks=masks)
+    loss, parts = olosses.total_loss(out, batch, cfg.supervised_seg)
+    loss.backward()
+    ref = g[mode + "_loss"]
+    got = [float(loss.detach()), float(parts["full"]), float(parts["half"]), float(parts["quarter"]), float(parts["seg"]),
+           float(parts["rmse"])]
+    np.testing.assert_allclose(got, ref, rtol=2e-5, atol=1e-6)
+    assert max_err(out["depth"]["final_depth"].detach().numpy(), g[mode + "_final_depth"]) < TOL
+    assert rel_err(subsample(x.grad, 32768), g[mode + "_grad_input"]) < 1e-3
+    for key in g:
+        if key.startswith(mode + "_grad:"):
+            name = key.split(":", 1)[1]
+            if g[key].size == 0:  # the reference produces no gradient (argmax-only consumers, Q8)
+                assert sd[name].grad is None, name
+                continue
+            assert rel_err(subsample(sd[name].grad), g[key]) < 1e-3, name
+    norms = np.array([float(sd[n].grad.norm()) if sd[n].grad is not None else -1.0 for n, _ in param_specs(cfg)])
+    np.testing.assert_allclose(norms, g[mode + "_gradnorms"], rtol=2e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("variant", ["base", "supervised_seg"])
+def test_forward_eval_256x416(variant):
+    cfg = ModelConfig.variant(variant)
+    sd = golden_state_dict(cfg)
+    g = load_npz(f"forward256x416_{variant}.npz")
+    batch = synth.make_batch(1, 256, 416, seed=1234)
+    taps = {}
+    with torch.no_grad():
+        out = omodel.forward(sd, batch["image"], cfg, taps=taps)
+        loss, parts = olosses.total_loss(out, batch, cfg.supervised_seg)
+    assert max_err(out["depth"]["final_depth"].numpy(), g["final_depth"]) < 5e-5
+    assert max_err(out["depth"]["intermediate_depths"][2].numpy(), g["depth_quarter"]) < 5e-5
+    assert max_err(out["depth"]["intermediate_depths"][3].numpy(), g["depth_half"].astype(np.float32)) < 2e-3
+    for i in range(4):
+        e = taps[f"enc{i + 1}"]
+        np.testing.assert_allclose([float(e.mean()), float(e.norm())], g[f"enc{i + 1}_stats"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(parts["rmse"]), g["loss"][5], rtol=1e-4)
+    if cfg.supervised_seg:
+        am = out["seg"]["final_seg"].argmax(1).numpy().astype(np.uint8)
+        assert (am != g["seg_argmax"]).mean() < 1e-4
+
+
+def test_leaf_modules():
+    g = load_npz("leaf_modules.npz")
+
+    def sd_for(shapes, seed, prefix="m."):
+        return {prefix + k: v for k, v in synth.fill_state_dict(shapes, seed).items()}
+
+    def blk_shapes(dim, ratio, sr):
+        hid = dim * ratio
+        s = {"norm1.weight": (dim,), "norm1.bias": (dim,), "norm2.weight": (dim,), "norm2.bias": (dim,),
+             "attn.q.weight": (dim, dim, 1), "attn.q.bias": (dim,), "attn.k.weight": (dim, dim, 1), "attn.k.bias": (dim,),
+             "attn.proj.weight": (dim, dim, 1), "attn.proj.bias": (dim,),
+             "mlp1.fc1.weight": (hid, dim, 1), "mlp1.fc1.bias": (hid,), "mlp1.dwconv.dwconv.weight": (hid, 1, 3, 3),
+             "mlp1.dwconv.dwconv.bias": (hid,), "mlp1.fc2.weight": (dim, hid, 1), "mlp1.fc2.bias": (dim,),
+             "mlp1.norm1.weight": (hid,), "mlp1.norm1.bias": (hid,), "mlp1.norm2.weight": (hid,), "mlp1.norm2.bias": (hid,)}
+        if sr > 1:
+            s.update({"attn.sr.weight": (dim, dim, sr, sr), "attn.sr.bias": (dim,), "attn.norm.weight": (dim,),
+                      "attn.norm.bias": (dim,)})
+        return s
+
+    with torch.no_grad():
+        for tag, (dim, heads, ratio, sr, H, W) in {"blk_sr2": (32, 2, 4, 2, 8, 12), "blk_sr1": (48, 3, 2, 1, 4, 6),
+                                                    "blk_sr4": (32, 1, 8, 4, 8, 8)}.items():
+            sd = sd_for(blk_shapes(dim, ratio, sr), 11)
+            x = torch.from_numpy(g[f"{tag}_x"])
+            assert max_err(omodel.block(sd, "m", x, H, W, heads, sr).numpy(), g[f"{tag}_y"]) < TOL
+            xn = torch.nn.functional.group_norm(x, dim // 16, sd["m.norm1.weight"], sd["m.norm1.bias"])
+            assert max_err(omodel.attention_maxpool(sd, "m.attn", xn, H, W, heads, sr).numpy(), g[f"{tag}_attn_y"]) < TOL
+            assert max_err(omodel.mlp(sd, "m.mlp1", xn, H, W, dim).numpy(), g[f"{tag}_mlp_y"]) < TOL
+        sd = sd_for({"proj.weight": (32, 7, 7, 7), "proj.bias": (32,), "norm.weight": (32,), "norm.bias": (32,)}, 12)
+        assert max_err(omodel.patch_embed(sd, "m", torch.from_numpy(g["pe7_x"]), 7, 4)[0].numpy(), g["pe7_y"]) < TOL
+        sd = sd_for({"proj.weight": (32, 16, 3, 3), "proj.bias": (32,), "norm.weight": (32,), "norm.bias": (32,)}, 13)
+        assert max_err(omodel.patch_embed(sd, "m", torch.from_numpy(g["pe3_x"]), 3, 2)[0].numpy(), g["pe3_y"]) < TOL
+        x = torch.from_numpy(g["convlayer_x"])
+        sd = sd_for({"model.0.weight": (32, 24, 3, 3), "model.1.weight": (32,), "model.1.bias": (32,)}, 14)
+        assert max_err(omodel.conv_layer(sd, "m", x, 3).numpy(), g["convlayer_y"]) < TOL
+
+        def srb_shapes(cin, pre=""):
+            s = {}
+            for li, (ci, co) in enumerate([(cin, 96), (cin + 96, 64), (cin + 160, 128)]):
+                s[f"{pre}layers.{li}.model.0.weight"] = (co, ci, 3, 3)
+                s[f"{pre}layers.{li}.model.1.weight"] = (co,)
+                s[f"{pre}layers.{li}.model.1.bias"] = (co,)
+            return s
+        sd = sd_for(srb_shapes(24), 15)
+        assert max_err(omodel.short_res_block(sd, "m", x).numpy(), g["srb_y"]) < TOL
+        sd = sd_for(srb_shapes(24, "conv."), 16)
+        xd, skip = torch.from_numpy(g["dec_x"]), torch.from_numpy(g["dec_skip"])
+        assert max_err(omodel.decoder_stage(sd, "m", xd, skip).numpy(), g["dec_y"]) < TOL
+        assert max_err(omodel.bicubic2x(xd).numpy(), g["bicubic_y"]) == 0.0
+        sd = sd_for({"conv_1.weight": (32, 24, 3, 3), "conv_1.bias": (32,), "conv_2.weight": (1, 32, 3, 3),
+                     "conv_2.bias": (1,)}, 17)
+        x = torch.from_numpy(g["da_x"])
+        assert max_err(omodel.depth_activation(sd, "m", x).numpy(), g["da_y"]) < TOL
+        assert np.array_equal(omodel.seg_block(x[:, :21], 21).numpy(), g["segblock_y"])
+
+
+def test_diffgradnorm_40_steps():
+    g = load_npz("diffgradnorm_40steps.npz")
+    ps = [torch.from_numpy(g[f"p{j}_init"]).clone() for j in range(3)]
+    sts = [ooptim.new_state(p) for p in ps]
+    branch_taken = 0
+    for it in range(40):
+        lr, b1, b2 = g["hp"][it]
+        for j in range(3):
+            grad = torch.from_numpy(g[f"p{j}_grads"][it])
+            e_prev = float(sts[j]["exp_grad_norm"])
+            branch_taken += int(0.95 * e_prev + 0.05 * float(grad.norm()) > float(grad.norm()))
+            ooptim.step_tensor(ps[j], grad, sts[j], lr, b1, b2)
+            np.testing.assert_allclose(ps[j].numpy(), g[f"p{j}_traj"][it], rtol=1e-6, atol=1e-7)
+            np.testing.assert_allclose(float(sts[j]["exp_grad_norm"]), g["exp_grad_norm"][it][j], rtol=1e-6)
+    assert branch_taken >= 6  # the norm-correction branch (diffGradNorm.py:84) is exercised
+    for j in range(3):
+        np.testing.assert_allclose(sts[j]["exp_avg"].numpy(), g[f"p{j}_exp_avg"], rtol=1e-5, atol=1e-8)
+        np.testing.assert_allclose(sts[j]["exp_avg_sq"].numpy(), g[f"p{j}_exp_avg_sq"], rtol=1e-5, atol=1e-10)
+    sched = ooptim.one_cycle_schedule(41, 6e-5)
+    np.testing.assert_allclose([s[0] for s in sched[:40]], g["hp"][:, 0], rtol=1e-9)
+    np.testing.assert_allclose([s[1] for s in sched[:40]], g["hp"][:, 1], rtol=1e-9)
+
+
+def test_losses_and_metrics():
+    g = load_npz("losses_metrics.npz")
+    b = synth.make_batch(2, 24, 40, seed=3)
+    pred, logits = torch.from_numpy(g["pred"]), torch.from_numpy(g["logits"])
+    np.testing.assert_allclose(float(olosses.masked_smooth_l1(pred, b["gt_full"])), g["smooth_l1"], rtol=1e-6)
+    np.testing.assert_allclose(float(olosses.masked_mse(pred, b["gt_full"])), g["mse"], rtol=1e-6)
+    np.testing.assert_allclose(float(olosses.masked_focal(logits, b["seg"])), g["focal"], rtol=1e-6)
+    m = olosses.test_metrics(pred[0], b["gt_full"][0])
+    np.testing.assert_allclose([m["MAE"], m["RMSE"], m["REL"]], g["metrics"], rtol=1e-5)

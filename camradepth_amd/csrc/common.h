@@ -1,0 +1,105 @@
+// Shared device/host helpers for libcamradepth_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/camradepth_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define CRD_WAVE 64
+#define GN_EPS 1e-5f
+
+void crd_set_error(const char* fmt, ...);
+
+#define CRD_CHECK_ARG(cond, ...)            \
+  do {                                      \
+    if (!(cond)) {                          \
+      crd_set_error(__VA_ARGS__);           \
+      return CRD_E_INVALID;                 \
+    }                                       \
+  } while (0)
+
+#define CRD_UNSUPPORTED(cond, ...)          \
+  do {                                      \
+    if (!(cond)) {                          \
+      crd_set_error(__VA_ARGS__);           \
+      return CRD_E_UNSUPPORTED;             \
+    }                                       \
+  } while (0)
+
+#define CRD_LAUNCH_CHECK(name)                                                   \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      crd_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \
+      return CRD_E_LAUNCH;                                                       \
+    }                                                                            \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even fp32 -> bf16 (NaN not special-cased: the hot path never produces it on purpose)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// load 8 consecutive channels as floats from a bf16 or fp32 row
+__device__ __forceinline__ void load8(const void* base, int64_t elem_off, int is_f32, float (&v)[8]) {
+  if (is_f32) {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+    float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(base) + elem_off);
+    v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
+    v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+  }
+}
+__device__ __forceinline__ void store8_bf16(void* base, int64_t elem_off, const float (&v)[8]) {
+  uint4 u;
+  u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
+  *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(base) + elem_off) = u;
+}
+__device__ __forceinline__ void store8_f32(float* base, int64_t elem_off, const float (&v)[8]) {
+  float4* p = reinterpret_cast<float4*>(base + elem_off);
+  p[0] = make_float4(v[0], v[1], v[2], v[3]);
+  p[1] = make_float4(v[4], v[5], v[6], v[7]);
+}
+
+// mean / rstd of GroupNorm group from g16 slab sums: group = gmul consecutive slabs starting at slab0
+__device__ __forceinline__ void gn_mean_rstd(const float* stats_b, int slab0, int gmul, float inv_count, float& mean,
+                                             float& rstd) {
+  float s = 0.f, ss = 0.f;
+  for (int i = 0; i < gmul; ++i) {
+    s += stats_b[(slab0 + i) * 2];
+    ss += stats_b[(slab0 + i) * 2 + 1];
+  }
+  mean = s * inv_count;
+  float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+  rstd = rsqrtf(var + GN_EPS);
+}
+
+static inline hipStream_t as_stream(crd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,245 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (bf16 operands, fp32 accumulate).
+//
+// One kernel family covers every dense convolution / pointwise linear layer of the CamRaDepth hot
+// path and their data gradients (see include/camradepth_hip.h: crd_conv_igemm).  GEMM view:
+//   M = output pixels of one image (grid.z = image), N = Cout, K = (tap, cin) flattened, where a
+//   16-byte granule (8 channels) never straddles a tap because Cin % 8 == 0.
+// A-operand rows are gathered on the fly from the pixel-major activation tensor (im2col is never
+// materialised); the 3x3 re-reads are absorbed by the XCD L2.  Tiles are staged through LDS with
+// an XOR swizzle so the ds_read_b128 fragment reads of v_mfma_f32_32x32x16_bf16 are conflict-free.
+#include "common.h"
+
+namespace {
+
+struct ConvK {
+  const bf16_t* x; int x_ld; int IH, IW, Cin; long long x_bstride;
+  const bf16_t* w; int Cout, KW, stride, pad, Ktot;
+  int OW, OHW; int gather_mode;
+  void* y; int y_ld; int y_f32; long long y_bstride;
+  int out_mode, patch_k, patch_c, YW;
+  const float* bias; int act;
+  const float* res; int res_ld; long long res_bstride; const float* res_scale;
+  int accumulate; float* stats; int G16;
+};
+
+constexpr int BK = 32;
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void k_igemm(ConvK a) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int A_IT = BM / 64, B_IT = (BN + 63) / 64;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BM + BN) * BK];
+  bf16_t* sA = lds;
+  bf16_t* sB = lds + 2 * BM * BK;
+
+  const int t = threadIdx.x, l = t & 63, wave = t >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const bf16_t* xb = a.x + (long long)b * a.x_bstride;
+  const int g = t & 3, r0 = t >> 2;
+  const int swz = (r0 >> 2) & 3;  // same for r0 + 64*i
+
+  int py[A_IT], px[A_IT];
+  bool mv[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + r0 + 64 * i;
+    mv[i] = m < a.OHW;
+    int oy = m / a.OW, ox = m - oy * a.OW;
+    if (a.gather_mode == 0) { py[i] = oy * a.stride - a.pad; px[i] = ox * a.stride - a.pad; }
+    else { py[i] = oy + a.pad; px[i] = ox + a.pad; }
+  }
+  int kf = g * 8, kc = g * 8, ky = 0, kx = 0;
+  while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
+
+  uint4 ra[A_IT], rb[B_IT];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto gload = [&]() {
+    const bool kok = kf < a.Ktot;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int iy, ix;
+      bool ok = kok && mv[i];
+      if (a.gather_mode == 0) { iy = py[i] + ky; ix = px[i] + kx; }
+      else {
+        int ty = py[i] - ky, tx = px[i] - kx;
+        if (a.stride == 1) { iy = ty; ix = tx; }
+        else {
+          iy = ty / a.stride; ix = tx / a.stride;
+          ok = ok && ty >= 0 && tx >= 0 && iy * a.stride == ty && ix * a.stride == tx;
+        }
+      }
+      ok = ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      ra[i] = zero4;
+      if (ok) ra[i] = *reinterpret_cast<const uint4*>(xb + (long long)(iy * a.IW + ix) * a.x_ld + kc);
+    }
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      int n = r0 + 64 * j, ng = n0 + n;
+      bool ok = kok && n < BN && ng < a.Cout;
+      rb[j] = zero4;
+      if (ok) rb[j] = *reinterpret_cast<const uint4*>(a.w + (long long)ng * a.Ktot + kf);
+    }
+  };
+  auto advance = [&]() {
+    kf += BK; kc += BK;
+    while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      *reinterpret_cast<uint4*>(&sA[buf * BM * BK + (r0 + 64 * i) * BK + ((g ^ swz) << 3)]) = ra[i];
+#pragma unroll
+    for (int j = 0; j < B_IT; ++j) {
+      int n = r0 + 64 * j;
+      if (n < BN) *reinterpret_cast<uint4*>(&sB[buf * BN * BK + n * BK + ((g ^ swz) << 3)]) = rb[j];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nK = (a.Ktot + BK - 1) / BK;
+  gload();
+  lstore(0);
+  advance();
+  __syncthreads();
+  for (int kt = 0; kt < nK; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nK) gload();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[TM], bfr[TN];
+      const int gi = ks * 2 + (l >> 5);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int row = (wm * TM + i) * 32 + (l & 31);
+        af[i] = *reinterpret_cast<const bf16x8*>(&sA[cur * BM * BK + row * BK + ((gi ^ ((row >> 2) & 3)) << 3)]);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        int row = (wn * TN + j) * 32 + (l & 31);
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&sB[cur * BN * BK + row * BK + ((gi ^ ((row >> 2) & 3)) << 3)]);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nK) { lstore(cur ^ 1); advance(); }
+    __syncthreads();
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------
+  const float rscale = (a.res && a.res_scale) ? a.res_scale[b] : 1.f;
+  char* yb = reinterpret_cast<char*>(a.y) + (long long)b * a.y_bstride * (a.y_f32 ? 4 : 2);
+  const float* resb = a.res ? a.res + (long long)b * a.res_bstride : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (l & 31);
+    const bool colok = col < a.Cout;
+    const float bias_v = (a.bias && colok) ? a.bias[col] : 0.f;
+    int pky = 0, pkx = 0, pci = col;
+    if (a.out_mode == 1) {
+      int tap = col / a.patch_c;
+      pci = col - tap * a.patch_c;
+      pky = tap / a.patch_k;
+      pkx = tap - pky * a.patch_k;
+    }
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (row < a.OHW && colok) {
+          float v = acc[i][j][r] + bias_v;
+          if (a.act == 1) v = sigmoidf_(v);
+          long long off;
+          if (a.out_mode == 0) off = (long long)row * a.y_ld + col;
+          else {
+            int oy = row / a.OW, ox = row - oy * a.OW;
+            off = ((long long)(oy * a.patch_k + pky) * a.YW + (ox * a.patch_k + pkx)) * a.y_ld + pci;
+          }
+          if (resb) v = resb[(long long)row * a.res_ld + col] + rscale * bf_round(v);
+          if (a.y_f32) {
+            float* p = reinterpret_cast<float*>(yb) + off;
+            if (a.accumulate) v += *p;
+            *p = v;
+          } else {
+            bf16_t* p = reinterpret_cast<bf16_t*>(yb) + off;
+            if (a.accumulate) v += bf2f(*p);
+            bf16_t q = f2bf(v);
+            *p = q;
+            v = bf2f(q);
+          }
+          s += v; ss += v * v;
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+      s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+      if ((l & 15) == 0 && l < 32 && colok) {
+        float* st = a.stats + ((long long)b * a.G16 + (col >> 4)) * 2;
+        atomicAdd(st, s);
+        atomicAdd(st + 1, ss);
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch(const ConvK& k, int B, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  dim3 grid(cdiv(k.OHW, BM), cdiv(k.Cout, BN), B);
+  hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN>), grid, dim3(256), 0, st, k);
+  CRD_LAUNCH_CHECK("crd_conv_igemm");
+  return CRD_OK;
+}
+
+}  // namespace
+
+extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
+  CRD_CHECK_ARG(d && d->x && d->w && d->y, "crd_conv_igemm: null pointer");
+  CRD_CHECK_ARG(d->Cin % 8 == 0 && d->x_ld % 8 == 0 && d->x_coff % 8 == 0,
+                "crd_conv_igemm: Cin/x_ld/x_coff must be multiples of 8 (got %d/%d/%d)", d->Cin, d->x_ld, d->x_coff);
+  CRD_CHECK_ARG(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0 && d->KH > 0 && d->KW > 0 && d->stride > 0,
+                "crd_conv_igemm: bad dims");
+  CRD_CHECK_ARG(!(d->res && !d->y_f32), "crd_conv_igemm: residual epilogue needs fp32 output");
+  CRD_CHECK_ARG(!d->stats || d->Cout % 16 == 0, "crd_conv_igemm: stats need Cout %% 16 == 0");
+  CRD_CHECK_ARG(d->out_mode == 0 || (d->patch_k > 0 && d->patch_c > 0 && d->Cout == d->patch_k * d->patch_k * d->patch_c),
+                "crd_conv_igemm: bad patch-scatter dims");
+  CRD_UNSUPPORTED((long long)d->IH * d->IW * d->x_ld < (1ll << 31), "crd_conv_igemm: image too large for 32-bit offsets");
+  ConvK k;
+  k.x = reinterpret_cast<const bf16_t*>(d->x) + d->x_coff; k.x_ld = d->x_ld;
+  k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.x_bstride = (long long)d->IH * d->IW * d->x_ld;
+  k.w = reinterpret_cast<const bf16_t*>(d->w);
+  k.Cout = d->Cout; k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.Ktot = d->KH * d->KW * d->Cin;
+  k.OW = d->OW; k.OHW = d->OH * d->OW; k.gather_mode = d->gather_mode;
+  k.y_ld = d->y_ld; k.y_f32 = d->y_f32;
+  k.out_mode = d->out_mode; k.patch_k = d->patch_k; k.patch_c = d->patch_c;
+  int YH = d->OH, YW = d->OW;
+  if (d->out_mode == 1) { YH = d->OH * d->patch_k; YW = d->OW * d->patch_k; }
+  k.YW = YW;
+  k.y_bstride = (long long)YH * YW * d->y_ld;
+  k.y = d->y_f32 ? (void*)(reinterpret_cast<float*>(d->y) + d->y_coff) : (void*)(reinterpret_cast<bf16_t*>(d->y) + d->y_coff);
+  k.bias = d->bias; k.act = d->act;
+  k.res = d->res; k.res_ld = d->res_ld; k.res_bstride = (long long)YH * YW * d->res_ld; k.res_scale = d->res_scale;
+  k.accumulate = d->accumulate; k.stats = d->stats; k.G16 = d->Cout / 16;
+  hipStream_t st = as_stream(stream);
+  if (d->Cout <= 32) return launch<4, 1, 1, 1>(k, d->B, st);
+  if (d->Cout <= 64) return launch<2, 2, 2, 1>(k, d->B, st);
+  if (d->Cout <= 96) return launch<4, 1, 1, 3>(k, d->B, st);
+  if (d->Cout > 128 && d->Cout <= 160) return launch<4, 1, 1, 5>(k, d->B, st);
+  return launch<2, 2, 2, 2>(k, d->B, st);
+}

@@ -1,0 +1,223 @@
+// Convolution weight gradient on MFMA for gfx950.
+//
+//   dw[co][kf] += sum_p dy[p][co] * xcol[p][kf]        p = (b, oy, ox) flattened, kf = (tap, ci)
+//
+// Both operands are pixel-major, i.e. the contraction index p is the SLOW dimension of both
+// tiles.  v_mfma_f32_16x16x32_bf16 wants 8 consecutive-k values per lane, so the fragments are
+// read from the row-major [pixel][channel] LDS tiles with ds_read_b64_tr_b16 (the gfx950
+// transposing LDS read: a 16-lane group fetches a 4x16 block and lane i receives column i),
+// which costs the same as a plain read and removes any explicit transpose.  The pixel range is
+// split across workgroups (split-K); partial tiles are combined with fp32 atomics.
+#include "common.h"
+
+namespace {
+
+struct WgK {
+  const bf16_t* x; int x_ld; int IH, IW, Cin;
+  const bf16_t* dy; int dy_ld; int OH, OW, Cout;
+  int KW, stride, pad, Ktot;
+  long long P;           // B*OH*OW
+  int chunk;             // pixels per split (multiple of 32)
+  float* dw;
+};
+
+constexpr int PK = 32;  // pixels per K-step
+
+__device__ __forceinline__ s16x4 tr_read(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+template <int WMc, int WNc, int TMc, int TNc>
+__global__ __launch_bounds__(256) void k_wgrad(WgK a) {
+  static_assert(WMc * WNc == 4, "4 waves");
+  constexpr int BMc = WMc * TMc * 16, BNk = WNc * TNc * 16;
+  static_assert(BNk == 128, "kf tile is 128 wide");
+  constexpr int LDY = BMc + 16, LDX = BNk + 16;
+  constexpr int GY = BMc / 8;                       // 16-byte granules per dy row
+  constexpr int Y_IT = (PK * GY + 255) / 256;
+  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * PK * (LDY + LDX)];
+  bf16_t* sY = lds;
+  bf16_t* sX = lds + 2 * PK * LDY;
+
+  const int t = threadIdx.x, l = t & 63, wave = t >> 6;
+  const int wm = wave / WNc, wn = wave % WNc;
+  const int n0 = blockIdx.x * BNk, m0 = blockIdx.y * BMc;
+  const long long p_begin = (long long)blockIdx.z * a.chunk;
+  long long p_end = p_begin + a.chunk;
+  if (p_end > a.P) p_end = a.P;
+  if (p_begin >= p_end) return;
+  const int nK = (int)((p_end - p_begin + PK - 1) / PK);
+
+  // ---- X gather state: fixed kf granule per thread, two pixel rows ----
+  const int xg = t & 15, xr0 = t >> 4;
+  const int kf = n0 + xg * 8;
+  const bool kok = kf < a.Ktot;
+  const int tap = kf / a.Cin, kc = kf - tap * a.Cin;
+  const int ky = tap / a.KW, kx = tap - ky * a.KW;
+  int xb[2], xoy[2], xox[2];
+  const int OHW = a.OH * a.OW;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    long long p = p_begin + xr0 + 16 * i;
+    int b = (int)(p / OHW);
+    int rem = (int)(p - (long long)b * OHW);
+    xb[i] = b; xoy[i] = rem / a.OW; xox[i] = rem - xoy[i] * a.OW;
+  }
+  auto x_advance = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      xox[i] += PK;
+      while (xox[i] >= a.OW) { xox[i] -= a.OW; if (++xoy[i] == a.OH) { xoy[i] = 0; ++xb[i]; } }
+    }
+  };
+
+  uint4 rx[2], ry[Y_IT];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  int kt_load = 0;
+  auto gload = [&]() {
+    const long long pbase = p_begin + (long long)kt_load * PK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      long long p = pbase + xr0 + 16 * i;
+      int iy = xoy[i] * a.stride - a.pad + ky, ix = xox[i] * a.stride - a.pad + kx;
+      bool ok = kok && p < p_end && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      rx[i] = zero4;
+      if (ok) rx[i] = *reinterpret_cast<const uint4*>(a.x + ((long long)(xb[i] * a.IH + iy) * a.IW + ix) * a.x_ld + kc);
+    }
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      int idx = t + 256 * i;
+      int r = idx / GY, gcol = idx - r * GY;
+      long long p = pbase + r;
+      int co = m0 + gcol * 8;
+      bool ok = idx < PK * GY && p < p_end && co < a.Cout;   // Cout multiple of 8 or handled by host padding
+      ry[i] = zero4;
+      if (ok) ry[i] = *reinterpret_cast<const uint4*>(a.dy + p * a.dy_ld + co);
+    }
+    x_advance();
+    ++kt_load;
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      *reinterpret_cast<uint4*>(&sX[buf * PK * LDX + (xr0 + 16 * i) * LDX + xg * 8]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      int idx = t + 256 * i;
+      int r = idx / GY, gcol = idx - r * GY;
+      if (idx < PK * GY) *reinterpret_cast<uint4*>(&sY[buf * PK * LDY + r * LDY + gcol * 8]) = ry[i];
+    }
+  };
+
+  f32x4 acc[TMc][TNc];
+#pragma unroll
+  for (int i = 0; i < TMc; ++i)
+#pragma unroll
+    for (int j = 0; j < TNc; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  gload();
+  lstore(0);
+  __syncthreads();
+  // per-lane fragment addressing: 16-lane group q covers pixels 8q..8q+7; inside a read the lane
+  // supplies the address of 4 consecutive channels of pixel row (l&15)>>2.
+  const int q = l >> 4, prow = (l & 15) >> 2, pcol = (l & 3) * 4;
+  for (int kt = 0; kt < nK; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nK) gload();
+    bf16x8 af[TMc], bfr[TNc];
+#pragma unroll
+    for (int i = 0; i < TMc; ++i) {
+      const bf16_t* base = &sY[cur * PK * LDY + (8 * q + prow) * LDY + (wm * TMc + i) * 16 + pcol];
+      s16x4 lo = tr_read(base), hi = tr_read(base + 4 * LDY);
+      union { bf16x8 v; s16x4 h[2]; } u;
+      u.h[0] = lo; u.h[1] = hi;
+      af[i] = u.v;
+    }
+#pragma unroll
+    for (int j = 0; j < TNc; ++j) {
+      const bf16_t* base = &sX[cur * PK * LDX + (8 * q + prow) * LDX + (wn * TNc + j) * 16 + pcol];
+      s16x4 lo = tr_read(base), hi = tr_read(base + 4 * LDX);
+      union { bf16x8 v; s16x4 h[2]; } u;
+      u.h[0] = lo; u.h[1] = hi;
+      bfr[j] = u.v;
+    }
+#pragma unroll
+    for (int i = 0; i < TMc; ++i)
+#pragma unroll
+      for (int j = 0; j < TNc; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (kt + 1 < nK) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // D layout (16x16): col = lane&15 -> kf, row = (lane>>4)*4 + r -> co
+#pragma unroll
+  for (int i = 0; i < TMc; ++i)
+#pragma unroll
+    for (int j = 0; j < TNc; ++j) {
+      const int kfo = n0 + (wn * TNc + j) * 16 + (l & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = m0 + (wm * TMc + i) * 16 + (l >> 4) * 4 + r;
+        if (co < a.Cout && kfo < a.Ktot) atomicAdd(a.dw + (long long)co * a.Ktot + kfo, acc[i][j][r]);
+      }
+    }
+}
+
+// dbias[c] += sum over rows of a bf16 [rows][C] slice
+__global__ __launch_bounds__(256) void k_colsum_bf16(const bf16_t* x, int ld, long long rows, int C, float* out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rl = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (long long r = (long long)blockIdx.y * 4 + rl; r < rows; r += (long long)gridDim.y * 4) s += bf2f(x[r * ld + c]);
+  __shared__ float sm[256];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) atomicAdd(out + c, sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
+}
+
+template <int WMc, int WNc, int TMc, int TNc>
+int launch(const WgK& k0, hipStream_t st) {
+  WgK k = k0;
+  constexpr int BMc = WMc * TMc * 16, BNk = WNc * TNc * 16;
+  const int tn = cdiv(k.Ktot, BNk), tm = cdiv(k.Cout, BMc);
+  long long steps = (k.P + PK - 1) / PK;
+  long long want = (1536 + tn * tm - 1) / (tn * tm);        // aim for ~6 workgroups per CU in flight
+  long long max_splits = (steps + 7) / 8;                   // at least 8 K-steps per workgroup
+  long long splits = want < 1 ? 1 : want;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  long long chunk_steps = (steps + splits - 1) / splits;
+  k.chunk = (int)(chunk_steps * PK);
+  splits = (steps + chunk_steps - 1) / chunk_steps;
+  dim3 grid(tn, tm, (unsigned)splits);
+  hipLaunchKernelGGL((k_wgrad<WMc, WNc, TMc, TNc>), grid, dim3(256), 0, st, k);
+  CRD_LAUNCH_CHECK("crd_conv_wgrad");
+  return CRD_OK;
+}
+
+}  // namespace
+
+extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
+  CRD_CHECK_ARG(d && d->x && d->dy && d->dw, "crd_conv_wgrad: null pointer");
+  CRD_CHECK_ARG(d->Cin % 8 == 0 && d->x_ld % 8 == 0 && d->x_coff % 8 == 0, "crd_conv_wgrad: x channels must be multiples of 8");
+  CRD_CHECK_ARG(d->dy_ld % 8 == 0 && d->dy_coff % 8 == 0, "crd_conv_wgrad: dy_ld/dy_coff must be multiples of 8");
+  CRD_CHECK_ARG(d->Cout % 8 == 0 || d->dy_ld - d->dy_coff >= ((d->Cout + 7) / 8) * 8,
+                "crd_conv_wgrad: dy rows must hold Cout rounded up to 8 channels");
+  WgK k;
+  k.x = reinterpret_cast<const bf16_t*>(d->x) + d->x_coff; k.x_ld = d->x_ld; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin;
+  k.dy = reinterpret_cast<const bf16_t*>(d->dy) + d->dy_coff; k.dy_ld = d->dy_ld; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
+  k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.Ktot = d->KH * d->KW * d->Cin;
+  k.P = (long long)d->B * d->OH * d->OW; k.chunk = 0; k.dw = d->dw;
+  hipStream_t st = as_stream(stream);
+  if (d->dbias) {
+    dim3 grid(cdiv(d->Cout, 64), (unsigned)(k.P >= 4096 ? 64 : (k.P >= 256 ? 8 : 1)));
+    hipLaunchKernelGGL(k_colsum_bf16, grid, dim3(256), 0, st, k.dy, k.dy_ld, k.P, d->Cout, d->dbias);
+    CRD_LAUNCH_CHECK("crd_conv_wgrad(dbias)");
+  }
+  if (d->Cout <= 32) return launch<1, 4, 2, 2>(k, st);
+  if (d->Cout <= 64) return launch<1, 4, 4, 2>(k, st);
+  if (d->Cout <= 96) return launch<2, 2, 3, 4>(k, st);
+  return launch<2, 2, 4, 4>(k, st);
+}

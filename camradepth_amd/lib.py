@@ -1,0 +1,107 @@
+"""ctypes binding of libcamradepth_hip.so (include/camradepth_hip.h).
+
+The product path has no fallback: if the shared library is missing or a call fails, this module
+raises.  PyTorch is used only to own device memory and streams.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcamradepth_hip.so")
+
+
+class CrdError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_ld", C.c_int32), ("x_coff", C.c_int32),
+        ("B", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("Cin", C.c_int32),
+        ("w", C.c_void_p), ("Cout", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+        ("stride", C.c_int32), ("pad", C.c_int32), ("OH", C.c_int32), ("OW", C.c_int32),
+        ("gather_mode", C.c_int32),
+        ("y", C.c_void_p), ("y_ld", C.c_int32), ("y_coff", C.c_int32), ("y_f32", C.c_int32),
+        ("out_mode", C.c_int32), ("patch_k", C.c_int32), ("patch_c", C.c_int32),
+        ("bias", C.c_void_p), ("act", C.c_int32),
+        ("res", C.c_void_p), ("res_ld", C.c_int32), ("res_scale", C.c_void_p),
+        ("accumulate", C.c_int32), ("stats", C.c_void_p),
+    ]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("x_ld", C.c_int32), ("x_coff", C.c_int32),
+        ("B", C.c_int32), ("IH", C.c_int32), ("IW", C.c_int32), ("Cin", C.c_int32),
+        ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_coff", C.c_int32),
+        ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("dw", C.c_void_p), ("dbias", C.c_void_p),
+    ]
+
+
+class PackEntry(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p), ("dst_scatter", C.c_void_p),
+        ("cmap", C.c_void_p),
+        ("Cout", C.c_int32), ("Cin_ref", C.c_int32), ("taps", C.c_int32), ("Cin_pad", C.c_int32),
+        ("Cout_pad", C.c_int32),
+    ]
+
+
+class UnpackEntry(C.Structure):
+    _fields_ = [
+        ("src", C.c_void_p), ("dst", C.c_void_p), ("cmap", C.c_void_p),
+        ("Cout", C.c_int32), ("Cin_ref", C.c_int32), ("taps", C.c_int32), ("Cin_pad", C.c_int32),
+    ]
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises CrdError when it is not built (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CrdError(f"{LIB_PATH} is missing: run `python -m camradepth_amd.build` (hipcc, gfx950). "
+                       "camradepth_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.crd_last_error.restype = C.c_char_p
+    lib.crd_arch.restype = C.c_char_p
+    lib.crd_version.restype = C.c_int
+    missing = [n for n in EXPORTS if not hasattr(lib, n)]
+    if missing:
+        raise CrdError(f"{LIB_PATH} lacks symbols {missing}: rebuild it (python -m camradepth_amd.build)")
+    for name in EXPORTS:
+        getattr(lib, name).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+# every symbol include/camradepth_hip.h declares with an int status (checked by tests/test_abi.py)
+EXPORTS = [
+    "crd_conv_igemm", "crd_conv_wgrad", "crd_gn_stats", "crd_gn_apply", "crd_gn_bwd_reduce", "crd_gn_bwd_apply",
+    "crd_dwconv3x3", "crd_dwconv3x3_wgrad", "crd_attn_scores", "crd_attn_out_residual", "crd_attn_out_bwd",
+    "crd_attn_scores_bwd", "crd_bicubic2x", "crd_bicubic2x_bwd", "crd_nchw_to_pm", "crd_pm_to_nchw",
+    "crd_seg_argmax", "crd_slice_copy", "crd_f32_to_bf16_rows", "crd_weight_pack", "crd_wgrad_unpack",
+    "crd_masked_l1_fwd", "crd_masked_l1_bwd", "crd_ce_fwd", "crd_ce_focal_bwd", "crd_diffgradnorm_step",
+]
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().crd_last_error().decode()
+        raise CrdError(f"{what} failed with status {rc}: {msg}")
+
+
+def stream():
+    """Raw hipStream_t of torch's current stream (kernels are enqueued there)."""
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())

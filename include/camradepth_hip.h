@@ -1,0 +1,231 @@
+/*
+ * camradepth_hip.h -- C ABI of libcamradepth_hip.so (gfx950 / MI355X).
+ *
+ * The reference (TUMFTM/CamRaDepth) has no FFI or operator registry: its hot path is PyTorch ATen
+ * calls made from Python modules.  This header is therefore the boundary a maintainer would bind
+ * with ctypes to replace those calls.  Every entry point cites the reference code it replaces
+ * (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers unless named host_*.  The library never allocates, frees or
+ *     synchronises; the caller owns every buffer and passes the HIP stream to enqueue on.
+ *   - Return value: 0 = ok, negative = error (CRD_E_*); crd_last_error() gives a message
+ *     (thread-local).  No exceptions cross the ABI.
+ *   - Activations are "pixel-major" (NHWC): element (b,y,x,c) of a tensor lives at
+ *     base[((b*H + y)*W + x)*ld + coff + c]; `ld` is the channel stride of the underlying buffer,
+ *     so a producer can write into a channel slice of a wider buffer (this is how torch.cat of the
+ *     reference disappears).  bf16 tensors need ld, coff and C to be multiples of 8 (16-byte rows).
+ *   - The encoder's [B,C,N] tensors of the reference are the same layout with H*W = N.
+ */
+#ifndef CAMRADEPTH_HIP_H
+#define CAMRADEPTH_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* crd_stream_t; /* hipStream_t */
+
+#define CRD_OK 0
+#define CRD_E_INVALID (-1)     /* bad argument (null pointer, misaligned stride, ...) */
+#define CRD_E_UNSUPPORTED (-2) /* shape outside what the kernels implement */
+#define CRD_E_LAUNCH (-3)      /* HIP launch failure */
+
+const char* crd_last_error(void);
+int crd_version(void);          /* ABI version, currently 1 */
+const char* crd_arch(void);     /* "gfx950" */
+
+/* ---------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on MFMA (bf16 in, fp32 accumulate).
+ * Replaces torch conv1d/conv2d on the hot path: OverlapPatchEmbed.proj
+ * (src/models/simplified_attention.py:158,185), Attention_MaxPool.{q,k,proj,sr} (:59-68,92-102),
+ * Mlp.{fc1,fc2} (:17,20,35,41), ConvLayer conv (src/utils/utils.py:211,225), Depth_Activation
+ * convs (utils.py:282-289) and the seg head convs (src/models/CamRaDepth.py:88-94), and -- with
+ * gather_mode 1 / out_mode 1 -- their data gradients (autograd of the same calls).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* x;      /* bf16 activations, pixel-major */
+  int32_t x_ld, x_coff;
+  int32_t B, IH, IW, Cin;       /* Cin multiple of 8 (pad channels must carry zero weights) */
+  const void* w;      /* bf16 weights [Cout][KH*KW][Cin], tap index = ky*KW + kx */
+  int32_t Cout, KH, KW, stride, pad;
+  int32_t OH, OW;               /* output grid */
+  int32_t gather_mode;          /* 0: y[oy,ox] += w[ky,kx] x[oy*s-p+ky, ox*s-p+kx]   (forward)
+                                   1: y[iy,ix] += w[ky,kx] x[(iy+p-ky)/s, (ix+p-kx)/s] (data gradient) */
+  void* y;            /* output, pixel-major */
+  int32_t y_ld, y_coff;
+  int32_t y_f32;                /* 0: bf16 output, 1: fp32 output */
+  int32_t out_mode;             /* 0: y[b,oy,ox,n]; 1: patch scatter: n=(ky*pk+kx)*pc+c ->
+                                   y[b, oy*pk+ky, ox*pk+kx, c] (data gradient of a k=s conv) */
+  int32_t patch_k, patch_c;
+  const float* bias;  /* [Cout] or NULL */
+  int32_t act;                  /* 0 none, 1 sigmoid */
+  const float* res;   /* fp32, same indexing as y (ld = res_ld): y = res + res_scale[b]*v, or NULL */
+  int32_t res_ld;
+  const float* res_scale; /* [B] or NULL (=1) */
+  int32_t accumulate;           /* 1: y += v (read-modify-write in y's dtype) */
+  float* stats;       /* [B][Cout/16][2] += (sum, sum of squares) of the ROUNDED outputs, or NULL */
+} crd_conv_desc;
+
+int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);
+
+/* Weight gradient of the same convolutions: dw[co][tap][ci] += sum_{b,oy,ox} dy[b,oy,ox,co] *
+ * x[b, oy*s-p+ky, ox*s-p+kx, ci]  (fp32 atomics; caller zeroes dw).  Optionally also
+ * dbias[co] += sum dy.  (autograd of the conv calls listed above.) */
+typedef struct {
+  const void* x; int32_t x_ld, x_coff; int32_t B, IH, IW, Cin;
+  const void* dy; int32_t dy_ld, dy_coff; int32_t OH, OW, Cout;
+  int32_t KH, KW, stride, pad;
+  float* dw;          /* fp32 [Cout][KH*KW][Cin] */
+  float* dbias;       /* fp32 [Cout] or NULL */
+} crd_wgrad_desc;
+
+int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * GroupNorm family.  Statistics are kept as raw sums over 16-channel slabs ("g16 stats":
+ * float [B][C/16][2] = sum, sum of squares); a GroupNorm group is `gmul` consecutive slabs, so
+ * the reference's GroupNorm(C/16, C) has gmul = 1 and Mlp.norm2 (groups from out_features,
+ * simplified_attention.py:24) has gmul = hidden/dim.  Replaces torch group_norm + GELU:
+ * simplified_attention.py:23-24,37-40,70,117-118,142,144,162,186; utils.py:213-214,225.
+ * ------------------------------------------------------------------------------------------- */
+/* stats[b][c/16] += sums over pixels of x (bf16 or fp32); optional per-channel sums chan[b][c][2]. */
+int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
+                 float* stats, float* chan_sums, crd_stream_t stream);
+
+/* y = act((x-mean)*rstd*gamma+beta) * mask[b][c];  act: 0 none, 1 exact GELU.  mask may be NULL.
+ * y is bf16 (pixel-major slice).  eps = 1e-5. */
+int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
+                 const float* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
+                 const float* mask, void* y, int32_t y_ld, int32_t y_coff, crd_stream_t stream);
+
+/* Backward, phase 1: per (b, c) sums  r[b][c] = (sum g, sum g*xhat), g = dy*mask*act'(u),
+ * u = xhat*gamma+beta.  dy is bf16 or fp32 pixel-major.  r must be zeroed by the caller. */
+int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
+                      int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
+                      int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
+                      float* r, crd_stream_t stream);
+/* Backward, phase 2: dgamma[c] += sum_b r[b][c][1], dbeta[c] += sum_b r[b][c][0];
+ * dx = (gamma*g - mean_grp(gamma*g) - xhat*mean_grp(gamma*g*xhat)) * rstd, written as bf16
+ * (dx_f32=0) or ADDED into an fp32 tensor (dx_f32=1, accumulate). */
+int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
+                     int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
+                     int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
+                     const float* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
+                     int32_t dx_coff, int32_t dx_accumulate, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Depthwise 3x3 (DWConv, simplified_attention.py:316,318-323).  w9 is fp32 [9][C], bias [C].
+ * flip=1 computes the data gradient (taps mirrored, no bias).  Optional g16 stats of the output.
+ * ------------------------------------------------------------------------------------------- */
+int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
+                  int32_t flip, void* y, float* stats, crd_stream_t stream);
+/* dw9[tap][c] += sum dy*x_shifted ; dbias[c] += sum dy */
+int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw9,
+                        float* dbias, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Max-pool attention (Attention_MaxPool.forward, simplified_attention.py:90-109).
+ * q: bf16 [B][N][C], k: bf16 [B][M][C] (C = heads*d).  S[b][n] = sum_h scale*max_m q.k ,
+ * idx[b][n][h] = argmax m (uint8, M <= 256... M is carried as int16).
+ * ------------------------------------------------------------------------------------------- */
+int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
+                    float scale, float* S, int16_t* idx, crd_stream_t stream);
+/* x1[b][n][c] = x[b][n][c] + dp[b] * (u[b][c]*S[b][n] + bp[c])  (fp32; Block residual, :143).
+ * Optionally accumulates g16 stats / channel sums of x1 (input of Block.norm2). */
+int crd_attn_out_residual(const float* x, const float* u, const float* S, const float* bp, const float* dp,
+                          int32_t B, int32_t N, int32_t C, float* x1, crd_stream_t stream);
+/* Backward of the above w.r.t. the branch y = u*S + bp given dy = dp[b]*dx1 (fp32 [B][N][C]):
+ * t[b][c] += sum_n dy*S ; dbp[c] += sum_{b,n} dy ; dS[b][n] = sum_c dy*u. */
+int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
+                     int32_t C, float* t, float* dbp, float* dS, crd_stream_t stream);
+/* dq[b][n][h*d+j] = scale*dS[b][n]*k[b][idx][h*d+j] (bf16) ; dk[b][m][h*d+j] += scale*dS*q (fp32 atomics). */
+int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
+                        int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Bicubic x2 up-sampling, A=-0.75, align_corners=False (nn.Upsample, utils.py:241,251).
+ * bf16 in (slice) -> bf16 out (slice).  bwd: dx (+)= transpose; dx is bf16.
+ * ------------------------------------------------------------------------------------------- */
+int crd_bicubic2x(const void* x, int32_t x_ld, int32_t x_coff, int32_t B, int32_t H, int32_t W, int32_t C, void* y,
+                  int32_t y_ld, int32_t y_coff, crd_stream_t stream);
+int crd_bicubic2x_bwd(const void* dy, int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                      void* dx, int32_t dx_ld, int32_t dx_coff, int32_t accumulate, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout / small elementwise helpers at the module boundary.
+ * ------------------------------------------------------------------------------------------- */
+/* NCHW fp32 [B][C][H][W] -> pixel-major bf16 slice (channels C..Cpad-1 of the slice are zeroed). */
+int crd_nchw_to_pm(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, void* y, int32_t y_ld, int32_t y_coff,
+                   int32_t Cpad, crd_stream_t stream);
+/* pixel-major (bf16 or fp32) -> NCHW fp32 */
+int crd_pm_to_nchw(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t C, int32_t H,
+                   int32_t W, float* y, crd_stream_t stream);
+/* NCHW fp32 gradient -> pixel-major bf16 slice (used to feed head gradients into the backward) */
+/* Seg_Block (utils.py:95-100): y[b,p,coff] = argmax_c logits[b,p,c] / num_classes  (bf16 slice, 1 channel) */
+int crd_seg_argmax(const void* logits, int32_t ld, int32_t B, int32_t P, int32_t C, int32_t num_classes, void* y,
+                   int32_t y_ld, int32_t y_coff, crd_stream_t stream);
+/* dst[b,p,dcoff+c] = src[b,p,scoff+c]  (bf16 slice copy; accumulate: +=) */
+int crd_slice_copy(const void* src, int32_t s_ld, int32_t s_coff, void* dst, int32_t d_ld, int32_t d_coff,
+                   int64_t rows, int32_t C, int32_t accumulate, crd_stream_t stream);
+/* fp32 [rows][C] -> bf16 slice, optionally scaled per sample: used for residual-gradient hand-off */
+int crd_f32_to_bf16_rows(const float* src, void* dst, int32_t d_ld, int32_t d_coff, int64_t rows, int32_t C,
+                         crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing: fp32 reference layout [Cout][Cin_ref][KH][KW] -> bf16 [Cout][taps][Cin_pad]
+ * (and the two transposed forms the data-gradient kernels read), table-driven, one launch.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* src;    /* [Cout][Cin_ref][taps] fp32 (reference layout) */
+  void* dst_fwd;       /* bf16 [Cout][taps][Cin_pad]  or NULL */
+  void* dst_dgrad;     /* bf16 [Cin_pad][taps][Cout_pad8] or NULL   (gather_mode 1) */
+  void* dst_scatter;   /* bf16 [taps][Cin_pad][Cout_pad8] or NULL   (out_mode 1)    */
+  const int32_t* cmap; /* [Cin_pad]: reference input channel of each packed channel, -1 = zero; NULL = identity */
+  int32_t Cout, Cin_ref, taps, Cin_pad, Cout_pad;
+} crd_pack_entry;
+int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int32_t max_elems, crd_stream_t stream);
+/* grad_ref[co][ci_ref][tap] (+)= dw_packed[co][tap][ci_pad] */
+typedef struct {
+  const float* src;    /* fp32 [Cout][taps][Cin_pad] */
+  float* dst;          /* fp32 [Cout][Cin_ref][taps] */
+  const int32_t* cmap;
+  int32_t Cout, Cin_ref, taps, Cin_pad;
+} crd_unpack_entry;
+int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int32_t max_elems, int32_t accumulate,
+                     crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Losses (src/utils/loss_funcs.py:14-46,77-91; combination src/main/runner.py:197-218).
+ * acc layout (float[8], zeroed by caller): [0]=sum smoothL1, [1]=count, [2]=sum sq err, ...
+ * ------------------------------------------------------------------------------------------- */
+/* pred, target fp32 [n]; acc[0]+=sum smooth_l1(pred-target) over target>0, acc[1]+=count, acc[2]+=sum (t-p)^2 */
+int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, float* acc, crd_stream_t stream);
+/* dpred[i] = gscale * clamp(p-t,-1,1) / acc[1]  on target>0 else 0 ; gscale read from *gscale_dev * gmul */
+int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const float* acc, const float* gout,
+                      float gmul, float* dpred, crd_stream_t stream);
+/* cross entropy over pixel-major fp32 logits [rows][C] (ld), labels int64 [rows], ignore 255:
+ * acc[0] += sum -log softmax[label], acc[1] += count */
+int crd_ce_fwd(const float* logits, int32_t ld, const int64_t* labels, int64_t rows, int32_t C, float* acc,
+               crd_stream_t stream);
+/* focal on the mean CE: F=(1-e^-ce)^2 ce ; dlogits = gmul*gout*dF/dce*(softmax-onehot)/count */
+int crd_ce_focal_bwd(const float* logits, int32_t ld, const int64_t* labels, int64_t rows, int32_t C,
+                     const float* acc, const float* gout, float gmul, float* dlogits, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * diffGradNorm.step (src/models/diffGradNorm.py:41-113) over flat fp32 buffers.
+ * seg_off[t]..seg_off[t+1] delimits tensor t inside the flat buffers (n_tensors+1 int64 entries).
+ * norm_sq: float[n_tensors] scratch.  exp_grad_norm: float[n_tensors] state.
+ * active: uint8[n_tensors] or NULL (tensors whose grad is None are skipped, :54-55).
+ * ------------------------------------------------------------------------------------------- */
+int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* prev_grad,
+                          float* exp_grad_norm, float* norm_sq, const int64_t* seg_off, const int32_t* blk2seg,
+                          int32_t n_tensors, int32_t n_blocks, const uint8_t* active, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int32_t step, crd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

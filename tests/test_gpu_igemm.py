@@ -1,0 +1,197 @@
+"""GPU parity of the implicit-GEMM convolution kernel (crd_conv_igemm) against torch fp32 on the
+same bf16-rounded operands.  Tolerance: fp32 accumulation-order noise + one bf16 output rounding
+(rel 2^-8) -> |err| <= 1e-2 * max|ref| elementwise, rel-L2 < 4e-3."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _lib():
+    from camradepth_amd import lib
+    return lib
+
+
+def bf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def to_pm(x, ld=None, coff=0):
+    """NCHW fp32 cpu -> pixel-major bf16 cuda buffer [B,H,W,ld] with x at channel offset coff."""
+    B, Cc, H, W = x.shape
+    ld = ld or Cc
+    buf = torch.zeros(B, H, W, ld, dtype=torch.bfloat16)
+    buf[..., coff:coff + Cc] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    return buf.cuda()
+
+
+def pack_w(w, cin_pad=None):
+    """[Cout,Cin,KH,KW] fp32 -> bf16 [Cout][KH*KW][Cin_pad] cuda."""
+    Co, Ci, KH, KW = w.shape
+    cin_pad = cin_pad or Ci
+    p = torch.zeros(Co, KH * KW, cin_pad, dtype=torch.bfloat16)
+    p[:, :, :Ci] = w.permute(0, 2, 3, 1).reshape(Co, KH * KW, Ci).to(torch.bfloat16)
+    return p.cuda()
+
+
+def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, OH, OW, y, y_ld, y_coff, y_f32=0,
+             gather_mode=0, out_mode=0, patch_k=0, patch_c=0, bias=None, act=0, res=None, res_ld=0, res_scale=None,
+             accumulate=0, stats=None):
+    lib = _lib()
+    L = lib.load()
+    d = lib.ConvDesc()
+    d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = xpm.data_ptr(), x_ld, x_coff, B, IH, IW, Cin
+    d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = wp.data_ptr(), Cout, KH, KW, stride, pad, OH, OW
+    d.gather_mode = gather_mode
+    d.y, d.y_ld, d.y_coff, d.y_f32 = y.data_ptr(), y_ld, y_coff, y_f32
+    d.out_mode, d.patch_k, d.patch_c = out_mode, patch_k, patch_c
+    d.bias = bias.data_ptr() if bias is not None else None
+    d.act = act
+    d.res = res.data_ptr() if res is not None else None
+    d.res_ld = res_ld
+    d.res_scale = res_scale.data_ptr() if res_scale is not None else None
+    d.accumulate = accumulate
+    d.stats = stats.data_ptr() if stats is not None else None
+    lib.check(L.crd_conv_igemm(C.byref(d), lib.stream()), "crd_conv_igemm")
+    torch.cuda.synchronize()
+
+
+def assert_close(got, ref, what, rel=4e-3, elem=1e-2):
+    got, ref = got.double(), ref.double()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    rl2 = ((got - ref).norm() / (ref.norm() + 1e-30)).item()
+    assert err <= elem * scale and rl2 < rel, f"{what}: max err {err:.3e} (scale {scale:.3e}), rel-L2 {rl2:.3e}"
+
+
+CASES = [
+    # B, Cin(ref), Cin_pad, H, W, Cout, k, stride, pad
+    (2, 136, 136, 19, 23, 96, 3, 1, 1),
+    (1, 232, 232, 16, 20, 64, 3, 1, 1),
+    (2, 296, 296, 9, 14, 128, 3, 1, 1),
+    (1, 129, 136, 12, 13, 32, 3, 1, 1),
+    (2, 128, 128, 10, 11, 21, 3, 1, 1),
+    (1, 32, 32, 13, 9, 1, 3, 1, 1),
+    (2, 7, 8, 32, 48, 64, 7, 4, 3),
+    (2, 64, 64, 16, 24, 128, 3, 2, 1),
+    (1, 128, 128, 9, 13, 160, 3, 2, 1),
+    (2, 64, 64, 16, 24, 64, 8, 8, 0),
+    (2, 160, 160, 8, 6, 160, 2, 2, 0),
+    (3, 256, 256, 4, 7, 256, 1, 1, 0),
+    (2, 64, 64, 20, 26, 512, 1, 1, 0),
+    (1, 640, 640, 6, 7, 160, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_conv_forward(case):
+    B, Ci, Cp, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5)
+    bias = torch.randn(Co, generator=g) * 0.1
+    ref = F.conv2d(x, w, bias, stride=s, padding=p)
+    OH, OW = ref.shape[2], ref.shape[3]
+    xpm = to_pm(x, ld=Cp + 16, coff=8)
+    wp = pack_w(w, Cp)
+    ld_y = ((Co + 7) // 8) * 8 + 8
+    y = torch.zeros(B, OH, OW, ld_y, dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(B, Co // 16, 2, device="cuda") if Co % 16 == 0 else None
+    run_conv(xpm, Cp + 16, 8, B, H, W, Cp, wp, Co, k, k, s, p, OH, OW, y, ld_y, 8 if Co % 8 == 0 else 0,
+             bias=bias.cuda(), stats=stats)
+    coff = 8 if Co % 8 == 0 else 0
+    got = y[..., coff:coff + Co].float().cpu().permute(0, 3, 1, 2)
+    assert_close(got, ref, f"conv {case}")
+    # untouched channels of the wider buffer stay zero
+    if coff:
+        assert float(y[..., :coff].float().abs().max()) == 0.0
+    if stats is not None:
+        gq = got.reshape(B, Co // 16, 16, OH * OW)
+        ref_s = torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1)
+        assert_close(stats.cpu(), ref_s, f"stats {case}", rel=1e-3, elem=2e-3)
+
+
+def test_epilogues_sigmoid_residual_accumulate():
+    g = torch.Generator().manual_seed(3)
+    B, Ci, H, W, Co = 2, 64, 7, 9, 64
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 1, 1, generator=g) / 8)
+    bias = torch.randn(Co, generator=g) * 0.1
+    conv = F.conv2d(x, w, bias)
+    xpm, wp = to_pm(x), pack_w(w)
+    # sigmoid
+    y = torch.zeros(B, H, W, Co, dtype=torch.bfloat16, device="cuda")
+    run_conv(xpm, Ci, 0, B, H, W, Ci, wp, Co, 1, 1, 1, 0, H, W, y, Co, 0, bias=bias.cuda(), act=1)
+    assert_close(y.float().cpu().permute(0, 3, 1, 2), torch.sigmoid(conv), "sigmoid")
+    # residual: y = res + scale[b] * bf16(conv)
+    res = torch.randn(B, H, W, Co, generator=g)
+    scale = torch.tensor([0.0, 1.25])
+    yf = torch.zeros(B, H, W, Co, device="cuda")
+    run_conv(xpm, Ci, 0, B, H, W, Ci, wp, Co, 1, 1, 1, 0, H, W, yf, Co, 0, y_f32=1, bias=bias.cuda(), res=res.cuda(),
+             res_ld=Co, res_scale=scale.cuda())
+    ref = res + scale.view(B, 1, 1, 1) * bf(conv).permute(0, 2, 3, 1)
+    assert_close(yf.cpu(), ref, "residual", rel=2e-3, elem=6e-3)
+    # accumulate into bf16
+    y0 = bf(torch.randn(B, H, W, Co, generator=g))
+    y = y0.to(torch.bfloat16).cuda()
+    run_conv(xpm, Ci, 0, B, H, W, Ci, wp, Co, 1, 1, 1, 0, H, W, y, Co, 0, accumulate=1)
+    assert_close(y.float().cpu(), y0 + F.conv2d(x, w).permute(0, 2, 3, 1), "accumulate")
+
+
+DGRAD_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad   (forward conv geometry; we test its data gradient)
+    (2, 136, 11, 13, 96, 3, 1, 1),
+    (1, 64, 16, 24, 128, 3, 2, 1),
+    (2, 128, 9, 13, 160, 3, 2, 1),
+    (2, 64, 10, 10, 64, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", DGRAD_CASES)
+def test_conv_dgrad_gather_mode(case):
+    B, Ci, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(11)
+    w = bf(torch.randn(Co, Ci, k, k, generator=g) / (Co * k * k) ** 0.5)
+    x = torch.randn(B, Ci, H, W, generator=g, requires_grad=True)
+    yref = F.conv2d(x, w, None, stride=s, padding=p)
+    OH, OW = yref.shape[2], yref.shape[3]
+    dy = bf(torch.randn(B, Co, OH, OW, generator=g))
+    yref.backward(dy)
+    # dgrad weights: [Cin][tap][Cout]
+    wd = w.permute(1, 2, 3, 0).contiguous().reshape(Ci, k * k, Co).to(torch.bfloat16).cuda()
+    dypm = to_pm(dy)
+    dx = torch.zeros(B, H, W, Ci, dtype=torch.bfloat16, device="cuda")
+    run_conv(dypm, Co, 0, B, OH, OW, Co, wd, Ci, k, k, s, p, H, W, dx, Ci, 0, gather_mode=1)
+    assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, f"dgrad {case}")
+
+
+@pytest.mark.parametrize("k,C", [(8, 64), (4, 128), (2, 160)])
+def test_conv_dgrad_patch_scatter(k, C):
+    g = torch.Generator().manual_seed(5)
+    B, PH, PW = 2, 3, 5
+    H, W = PH * k, PW * k
+    w = bf(torch.randn(C, C, k, k, generator=g) / (C * k * k) ** 0.5)
+    x = torch.randn(B, C, H, W, generator=g, requires_grad=True)
+    yref = F.conv2d(x, w, None, stride=k)
+    dy = bf(torch.randn(B, C, PH, PW, generator=g))
+    yref.backward(dy)
+    # scatter weights: [(tap, ci)][co]
+    ws = w.permute(2, 3, 1, 0).contiguous().reshape(k * k * C, 1, C).to(torch.bfloat16).cuda()
+    dypm = to_pm(dy)
+    dx = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda")
+    run_conv(dypm, C, 0, B, PH, PW, C, ws, k * k * C, 1, 1, 1, 0, PH, PW, dx, C, 0, out_mode=1, patch_k=k, patch_c=C)
+    assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, f"scatter k={k}")
+
+
+def test_bad_arguments_are_reported():
+    lib = _lib()
+    L = lib.load()
+    d = lib.ConvDesc()
+    rc = L.crd_conv_igemm(C.byref(d), lib.stream())
+    assert rc == -1 and b"null" in L.crd_last_error()
+    with pytest.raises(lib.CrdError):
+        lib.check(rc, "crd_conv_igemm")

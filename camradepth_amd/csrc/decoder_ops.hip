@@ -1,0 +1,314 @@
+// Decoder-side streaming kernels for gfx950: bicubic x2 (forward / transpose), layout conversion at
+// the module boundary, Seg_Block argmax, slice copies and small elementwise helpers.
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+// PyTorch upsample_bicubic2d, A = -0.75, scale 2, align_corners=False:
+// odd output o=2k+1 reads inputs k-1..k+2 with WO, even output o=2k reads k-2..k+1 with WE.
+__device__ __constant__ float WO[4] = {-0.10546875f, 0.87890625f, 0.26171875f, -0.03515625f};
+__device__ __constant__ float WE[4] = {-0.03515625f, 0.26171875f, 0.87890625f, -0.10546875f};
+
+__device__ __forceinline__ void taps_of(int o, int n, int (&idx)[4], float (&w)[4]) {
+  const int k = o >> 1;
+  const bool odd = o & 1;
+  const int base = odd ? k - 1 : k - 2;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    int i = base + t;
+    idx[t] = i < 0 ? 0 : (i > n - 1 ? n - 1 : i);
+    w[t] = odd ? WO[t] : WE[t];
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_bicubic(const bf16_t* x, int x_ld, int H, int W, int C, bf16_t* y, int y_ld) {
+  const int b = blockIdx.y;
+  const int CG = C >> 3;
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = (long long)OH * OW * CG;
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % CG);
+  const int pix = (int)(i / CG);
+  const int oy = pix / OW, ox = pix - oy * OW;
+  int iy[4], ix[4];
+  float wy[4], wx[4];
+  taps_of(oy, H, iy, wy);
+  taps_of(ox, W, ix, wx);
+  const bf16_t* xb = x + (long long)b * H * W * x_ld + cg * 8;
+  float out[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float row[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) row[j] = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float v[8];
+      load8(xb, ((long long)iy[r] * W + ix[c]) * x_ld, 0, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) row[j] += wx[c] * v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] += wy[r] * row[j];
+  }
+  store8_bf16(y, ((long long)b * OH * OW + pix) * y_ld + cg * 8, out);
+}
+
+// transpose: dx[iy][ix] (+)= sum_{oy,ox} By[oy][iy]*Bx[ox][ix]*dy[oy][ox]; candidates o in [2i-4, 2i+5]
+__device__ __forceinline__ void bwd_weights(int i, int n, float (&w)[10]) {
+#pragma unroll
+  for (int k = 0; k < 10; ++k) {
+    const int o = 2 * i - 4 + k;
+    float acc = 0.f;
+    if (o >= 0 && o < 2 * n) {
+      int idx[4];
+      float ww[4];
+      taps_of(o, n, idx, ww);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (idx[t] == i) acc += ww[t];
+    }
+    w[k] = acc;
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_bicubic_bwd(const bf16_t* dy, int dy_ld, int H, int W, int C, bf16_t* dx, int dx_ld,
+                                                     int accumulate) {
+  const int b = blockIdx.y;
+  const int CG = C >> 3;
+  const int OH = 2 * H, OW = 2 * W;
+  const long long total = (long long)H * W * CG;
+  const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
+  if (i >= total) return;
+  const int cg = (int)(i % CG);
+  const int pix = (int)(i / CG);
+  const int iy = pix / W, ix = pix - iy * W;
+  float wy[10], wx[10];
+  bwd_weights(iy, H, wy);
+  bwd_weights(ix, W, wx);
+  const bf16_t* db = dy + (long long)b * OH * OW * dy_ld + cg * 8;
+  float out[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = 0.f;
+  // border pixels collect clamped taps from further away: widen the window there
+  const bool border = iy < 2 || iy > H - 3 || ix < 2 || ix > W - 3;
+  if (!border) {
+#pragma unroll
+    for (int a = 1; a < 9; ++a) {
+      const int oy = 2 * iy - 4 + a;
+#pragma unroll
+      for (int c = 1; c < 9; ++c) {
+        const int ox = 2 * ix - 4 + c;
+        float v[8];
+        load8(db, ((long long)oy * OW + ox) * dy_ld, 0, v);
+        const float w = wy[a] * wx[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] += w * v[j];
+      }
+    }
+  } else {
+    for (int a = 0; a < 10; ++a) {
+      const int oy = 2 * iy - 4 + a;
+      if (oy < 0 || oy >= OH || wy[a] == 0.f) continue;
+      for (int c = 0; c < 10; ++c) {
+        const int ox = 2 * ix - 4 + c;
+        if (ox < 0 || ox >= OW || wx[c] == 0.f) continue;
+        float v[8];
+        load8(db, ((long long)oy * OW + ox) * dy_ld, 0, v);
+        const float w = wy[a] * wx[c];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] += w * v[j];
+      }
+    }
+  }
+  const long long off = ((long long)b * H * W + pix) * dx_ld + cg * 8;
+  if (accumulate) {
+    float o[8];
+    load8(dx, off, 0, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] += o[j];
+  }
+  store8_bf16(dx, off, out);
+}
+
+__global__ __launch_bounds__(TPB) void k_nchw_to_pm(const float* x, int C, long long HW, bf16_t* y, int y_ld, int Cpad) {
+  const int b = blockIdx.y;
+  const int CG = Cpad >> 3;
+  const long long total = HW * CG;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const long long p = i % HW;          // pixel fastest: coalesced reads of each channel plane
+    const int cg = (int)(i / HW);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      v[j] = c < C ? x[((long long)b * C + c) * HW + p] : 0.f;
+    }
+    store8_bf16(y, ((long long)b * HW + p) * y_ld + cg * 8, v);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_pm_to_nchw(const void* x, int x_f32, int x_ld, int C, long long HW, float* y) {
+  const int b = blockIdx.y;
+  const long long total = HW * C;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const long long p = i % HW;
+    const int c = (int)(i / HW);
+    const long long off = ((long long)b * HW + p) * x_ld + c;
+    y[((long long)b * C + c) * HW + p] = x_f32 ? reinterpret_cast<const float*>(x)[off] : bf2f(reinterpret_cast<const bf16_t*>(x)[off]);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_seg_argmax(const float* logits, int ld, long long rows, int C, float inv_classes,
+                                                    bf16_t* y, int y_ld) {
+  for (long long r = (long long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long long)gridDim.x * TPB) {
+    const float* p = logits + r * ld;
+    float best = p[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) {
+      float v = p[c];
+      if (v > best) { best = v; bi = c; }
+    }
+    y[r * y_ld] = f2bf((float)bi * inv_classes);
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_slice_copy(const bf16_t* src, int s_ld, bf16_t* dst, int d_ld, long long rows, int C,
+                                                    int accumulate) {
+  const int CG = C >> 3;
+  const long long total = rows * CG;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int cg = (int)(i % CG);
+    const long long r = i / CG;
+    uint4 u = *reinterpret_cast<const uint4*>(src + r * s_ld + cg * 8);
+    if (accumulate) {
+      float a[8], o[8];
+      load8(src, r * s_ld + cg * 8, 0, a);
+      load8(dst, r * d_ld + cg * 8, 0, o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a[j] += o[j];
+      store8_bf16(dst, r * d_ld + cg * 8, a);
+    } else {
+      *reinterpret_cast<uint4*>(dst + r * d_ld + cg * 8) = u;
+    }
+  }
+}
+
+// dst[r][c] = bf16(scale[r / rows_per_sample] * src[r*s_ld + c]) for c < C  (scalar path: any C / alignment)
+__global__ __launch_bounds__(TPB) void k_f32_to_bf16_rows(const float* src, int s_ld, bf16_t* dst, int d_ld, long long rows,
+                                                          int C, const float* scale, long long rows_per_sample) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int c = (int)(i % C);
+    const long long r = i / C;
+    float s = scale ? scale[r / rows_per_sample] : 1.f;
+    dst[r * d_ld + c] = f2bf(s * src[r * s_ld + c]);
+  }
+}
+
+// dz = da * a * (1-a), in place on da (bf16 contiguous)
+__global__ __launch_bounds__(TPB) void k_sigmoid_bwd(const bf16_t* a, bf16_t* da, long long n8) {
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n8; i += (long long)gridDim.x * TPB) {
+    float av[8], dv[8];
+    load8(a, i * 8, 0, av);
+    load8(da, i * 8, 0, dv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dv[j] *= av[j] * (1.f - av[j]);
+    store8_bf16(da, i * 8, dv);
+  }
+}
+
+inline int blocks_for(long long total) {
+  long long n = (total + TPB - 1) / TPB;
+  if (n > 4096) n = 4096;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+}  // namespace
+
+extern "C" int crd_bicubic2x(const void* x, int32_t x_ld, int32_t x_coff, int32_t B, int32_t H, int32_t W, int32_t C, void* y,
+                             int32_t y_ld, int32_t y_coff, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && y, "crd_bicubic2x: null pointer");
+  CRD_CHECK_ARG(C % 8 == 0 && x_ld % 8 == 0 && x_coff % 8 == 0 && y_ld % 8 == 0 && y_coff % 8 == 0, "crd_bicubic2x: alignment");
+  const long long total = 4ll * H * W * (C / 8);
+  hipLaunchKernelGGL(k_bicubic, dim3((unsigned)cdiv(total, TPB), B), dim3(TPB), 0, as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(x) + x_coff, x_ld, H, W, C, reinterpret_cast<bf16_t*>(y) + y_coff, y_ld);
+  CRD_LAUNCH_CHECK("crd_bicubic2x");
+  return CRD_OK;
+}
+
+extern "C" int crd_bicubic2x_bwd(const void* dy, int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t H, int32_t W, int32_t C,
+                                 void* dx, int32_t dx_ld, int32_t dx_coff, int32_t accumulate, crd_stream_t stream) {
+  CRD_CHECK_ARG(dy && dx, "crd_bicubic2x_bwd: null pointer");
+  CRD_CHECK_ARG(C % 8 == 0 && dy_ld % 8 == 0 && dy_coff % 8 == 0 && dx_ld % 8 == 0 && dx_coff % 8 == 0, "crd_bicubic2x_bwd: alignment");
+  const long long total = (long long)H * W * (C / 8);
+  hipLaunchKernelGGL(k_bicubic_bwd, dim3((unsigned)cdiv(total, TPB), B), dim3(TPB), 0, as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(dy) + dy_coff, dy_ld, H, W, C, reinterpret_cast<bf16_t*>(dx) + dx_coff, dx_ld,
+                     accumulate);
+  CRD_LAUNCH_CHECK("crd_bicubic2x_bwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_nchw_to_pm(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, void* y, int32_t y_ld, int32_t y_coff,
+                              int32_t Cpad, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && y, "crd_nchw_to_pm: null pointer");
+  CRD_CHECK_ARG(Cpad % 8 == 0 && Cpad >= C && y_ld % 8 == 0 && y_coff % 8 == 0, "crd_nchw_to_pm: alignment");
+  const long long HW = (long long)H * W;
+  hipLaunchKernelGGL(k_nchw_to_pm, dim3(blocks_for(HW * (Cpad / 8)), B), dim3(TPB), 0, as_stream(stream), x, C, HW,
+                     reinterpret_cast<bf16_t*>(y) + y_coff, y_ld, Cpad);
+  CRD_LAUNCH_CHECK("crd_nchw_to_pm");
+  return CRD_OK;
+}
+
+extern "C" int crd_pm_to_nchw(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t C, int32_t H,
+                              int32_t W, float* y, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && y, "crd_pm_to_nchw: null pointer");
+  const long long HW = (long long)H * W;
+  const void* xp = x_f32 ? (const void*)(reinterpret_cast<const float*>(x) + x_coff) : (const void*)(reinterpret_cast<const bf16_t*>(x) + x_coff);
+  hipLaunchKernelGGL(k_pm_to_nchw, dim3(blocks_for(HW * C), B), dim3(TPB), 0, as_stream(stream), xp, x_f32, x_ld, C, HW, y);
+  CRD_LAUNCH_CHECK("crd_pm_to_nchw");
+  return CRD_OK;
+}
+
+extern "C" int crd_seg_argmax(const void* logits, int32_t ld, int32_t B, int32_t P, int32_t C, int32_t num_classes, void* y,
+                              int32_t y_ld, int32_t y_coff, crd_stream_t stream) {
+  CRD_CHECK_ARG(logits && y && C >= 1 && num_classes >= 1, "crd_seg_argmax: bad argument");
+  const long long rows = (long long)B * P;
+  hipLaunchKernelGGL(k_seg_argmax, dim3(blocks_for(rows)), dim3(TPB), 0, as_stream(stream), reinterpret_cast<const float*>(logits),
+                     ld, rows, C, 1.f / (float)num_classes, reinterpret_cast<bf16_t*>(y) + y_coff, y_ld);
+  CRD_LAUNCH_CHECK("crd_seg_argmax");
+  return CRD_OK;
+}
+
+extern "C" int crd_slice_copy(const void* src, int32_t s_ld, int32_t s_coff, void* dst, int32_t d_ld, int32_t d_coff,
+                              int64_t rows, int32_t C, int32_t accumulate, crd_stream_t stream) {
+  CRD_CHECK_ARG(src && dst, "crd_slice_copy: null pointer");
+  CRD_CHECK_ARG(C % 8 == 0 && s_ld % 8 == 0 && s_coff % 8 == 0 && d_ld % 8 == 0 && d_coff % 8 == 0, "crd_slice_copy: alignment");
+  hipLaunchKernelGGL(k_slice_copy, dim3(blocks_for(rows * (C / 8))), dim3(TPB), 0, as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(src) + s_coff, s_ld, reinterpret_cast<bf16_t*>(dst) + d_coff, d_ld,
+                     (long long)rows, C, accumulate);
+  CRD_LAUNCH_CHECK("crd_slice_copy");
+  return CRD_OK;
+}
+
+extern "C" int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, int32_t d_ld, int32_t d_coff, int64_t rows,
+                                    int32_t C, const float* scale, int64_t rows_per_sample, crd_stream_t stream) {
+  CRD_CHECK_ARG(src && dst && rows_per_sample > 0, "crd_f32_to_bf16_rows: bad argument");
+  hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3(blocks_for(rows * C)), dim3(TPB), 0, as_stream(stream), src, s_ld,
+                     reinterpret_cast<bf16_t*>(dst) + d_coff, d_ld, (long long)rows, C, scale, (long long)rows_per_sample);
+  CRD_LAUNCH_CHECK("crd_f32_to_bf16_rows");
+  return CRD_OK;
+}
+
+extern "C" int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream) {
+  CRD_CHECK_ARG(a && da && n % 8 == 0, "crd_sigmoid_bwd: bad argument");
+  hipLaunchKernelGGL(k_sigmoid_bwd, dim3(blocks_for(n / 8)), dim3(TPB), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(a),
+                     reinterpret_cast<bf16_t*>(da), (long long)(n / 8));
+  CRD_LAUNCH_CHECK("crd_sigmoid_bwd");
+  return CRD_OK;
+}

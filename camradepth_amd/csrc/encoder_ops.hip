@@ -1,0 +1,397 @@
+// Encoder-side kernels for gfx950: depthwise 3x3 (+wgrad) and the max-pool attention of the
+// Simplified Transformer (fused QK^T + scale + row-max on MFMA, rank-1 output, backward).
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+// ------------------------------------------------------------------------------------------------
+// Depthwise 3x3, stride 1, pad 1, pixel-major bf16 [B][H][W][C] (ld = C).  One thread = 8 channels
+// of one pixel; the 3x3 neighbourhood comes from L1/L2 (each line is reused by 9 pixels).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, int C, const float* w9, const float* bias,
+                                                int flip, bf16_t* y, float* stats) {
+  extern __shared__ float sm[];  // [C/16][2] when stats
+  const int b = blockIdx.y;
+  const int CG = C >> 3;
+  const int G16 = C >> 4;
+  if (stats) {
+    for (int i = threadIdx.x; i < 2 * G16; i += TPB) sm[i] = 0.f;
+    __syncthreads();
+  }
+  const long long total = (long long)H * W * CG;
+  const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
+  float s = 0.f, ss = 0.f;
+  int cg = 0;
+  if (idx < total) {
+    cg = (int)(idx % CG);
+    const int pix = (int)(idx / CG);
+    const int py = pix / W, px = pix - py * W;
+    const int c0 = cg * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c0 + j] : 0.f;
+    const bf16_t* xb = x + (long long)b * H * W * C;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = py + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = px + kx - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const int tap = flip ? (8 - (ky * 3 + kx)) : (ky * 3 + kx);
+        float v[8], wv[8];
+        load8(xb, ((long long)iy * W + ix) * C + c0, 0, v);
+        load8(w9, (long long)tap * C + c0, 1, wv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += v[j] * wv[j];
+      }
+    }
+    uint4 u;
+    u.x = pack_bf2(acc[0], acc[1]); u.y = pack_bf2(acc[2], acc[3]); u.z = pack_bf2(acc[4], acc[5]); u.w = pack_bf2(acc[6], acc[7]);
+    *reinterpret_cast<uint4*>(y + ((long long)b * H * W + pix) * C + c0) = u;
+    if (stats) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { float q = bf_round(acc[j]); s += q; ss += q * q; }
+    }
+  }
+  if (stats) {
+    if (idx < total) { atomicAdd(&sm[(cg >> 1) * 2], s); atomicAdd(&sm[(cg >> 1) * 2 + 1], ss); }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * G16; i += TPB)
+      if (sm[i] != 0.f) atomicAdd(&stats[(long long)b * G16 * 2 + i], sm[i]);
+  }
+}
+
+// dw9[tap][c] += sum_{b,p} dy[p][c]*x[p+tap][c] ; dbias[c] += sum dy
+__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, int chunk,
+                                                      float* dw9, float* dbias) {
+  extern __shared__ float sm[];  // [10][C]
+  for (int i = threadIdx.x; i < 10 * C; i += TPB) sm[i] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int CG = C >> 3;
+  int PL = TPB / CG; if (PL < 1) PL = 1;
+  const bool active = threadIdx.x < PL * CG;
+  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG, c0 = cg * 8;
+  if (active) {
+    float acc[10][8];
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+    const bf16_t* xb = x + (long long)b * H * W * C;
+    const bf16_t* db = dy + (long long)b * H * W * C;
+    int p0 = blockIdx.x * chunk, p1 = p0 + chunk;
+    if (p1 > H * W) p1 = H * W;
+    for (int pix = p0 + pl; pix < p1; pix += PL) {
+      const int py = pix / W, px = pix - py * W;
+      float d[8];
+      load8(db, (long long)pix * C + c0, 0, d);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[9][j] += d[j];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = py + ky - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          const int ix = px + kx - 1;
+          if ((unsigned)ix >= (unsigned)W) continue;
+          float v[8];
+          load8(xb, ((long long)iy * W + ix) * C + c0, 0, v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += d[j] * v[j];
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 10; ++t)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&sm[t * C + c0 + j], acc[t][j]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 9 * C; i += TPB) atomicAdd(&dw9[i], sm[i]);
+  for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(&dbias[i], sm[9 * C + i]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Attention scores: per head h,  s[n] = max_m bf16(bf16(q_n . k_m) * scale)  (the reference's
+// autocast rounding points), S[n] = sum_h s_h[n].  MFMA operands are swapped -- A = K tile (rows =
+// keys), B = Q tile (cols = queries) -- so each lane owns ONE query column and the 16 accumulator
+// registers hold 16 keys: the max over keys is in-register plus one cross-half shuffle.
+// One wave = 32 queries; K/Q fragments are read straight from L2-resident global memory.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_attn_scores(const bf16_t* q, const bf16_t* k, int N, int M, int heads, int d,
+                                                     float scale, float* S, short* idx) {
+  const int b = blockIdx.y;
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0 = (blockIdx.x * 4 + wave) * 32;
+  if (n0 >= N) return;
+  const int C = heads * d;
+  const int n = n0 + (l & 31);
+  const bool nok = n < N;
+  const bf16_t* qb = q + ((long long)b * N + (nok ? n : 0)) * C;
+  const bf16_t* kb = k + (long long)b * M * C;
+  const int half = l >> 5;
+  float Ssum = 0.f;
+  const int nks = (d + 15) / 16;
+  for (int h = 0; h < heads; ++h) {
+    // query fragments for this head (B operand: col = lane&31, k = 8*half + j within each 16-chunk)
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 u = make_uint4(0, 0, 0, 0);
+      int kk = ks * 16 + half * 8;
+      if (ks < nks && kk < d && nok) u = *reinterpret_cast<const uint4*>(qb + h * d + kk);
+      qf[ks] = *reinterpret_cast<bf16x8*>(&u);
+    }
+    float best = -INFINITY;
+    int besti = 0;
+    for (int m0 = 0; m0 < M; m0 += 32) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const int mrow = m0 + (l & 31);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < nks) {
+          uint4 u = make_uint4(0, 0, 0, 0);
+          int kk = ks * 16 + half * 8;
+          if (kk < d && mrow < M) u = *reinterpret_cast<const uint4*>(kb + (long long)mrow * C + h * d + kk);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&u), qf[ks], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float v = bf_round(bf_round(acc[r]) * scale);
+        if (m < M && v > best) { best = v; besti = m; }
+      }
+    }
+    // combine the two half-waves (same query column, other 16 rows of every tile)
+    float ob = __shfl_xor(best, 32);
+    int oi = __shfl_xor(besti, 32);
+    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+    Ssum += best;
+    if (nok && half == 0) idx[((long long)b * N + n) * heads + h] = (short)besti;
+  }
+  if (nok && half == 0) S[(long long)b * N + n] = Ssum;
+}
+
+// xbar[b][c] = mean_n GN(x)[b][n][c] = gamma_c*(mean_n x_c - mu_g)*rstd_g + beta_c   (bf16 out)
+__global__ void k_attn_xbar(const float* chan, const float* stats, const float* gamma, const float* beta, int N, int C,
+                            bf16_t* xbar) {
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float mean, rstd;
+    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
+    float mc = chan[((long long)b * C + c) * 2] / (float)N;
+    xbar[(long long)b * C + c] = f2bf(gamma[c] * (mc - mean) * rstd + beta[c]);
+  }
+}
+
+// x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])
+__global__ __launch_bounds__(TPB) void k_attn_out_residual(const float* x, const float* u, const float* S, const float* bp,
+                                                           const float* dp, long long N, int C, float* x1) {
+  const int b = blockIdx.y;
+  const int CG = C >> 3;
+  const long long total = N * CG;
+  const float dps = dp ? dp[b] : 1.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int cg = (int)(i % CG);
+    const long long n = i / CG;
+    const float s = S[(long long)b * N + n];
+    float v[8], uu[8], bb[8];
+    const long long off = ((long long)b * N + n) * C + cg * 8;
+    load8(x, off, 1, v);
+    load8(u, (long long)b * C + cg * 8, 1, uu);
+    load8(bp, cg * 8, 1, bb);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] += dps * bf_round(uu[j] * s + bb[j]);
+    store8_f32(x1, off, v);
+  }
+}
+
+// dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp[c] += sum dy ; dS[b][n] = sum_c dy*u[b][c]
+__global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp,
+                                                      long long N, int C, int chunk, float* t, float* dbp, float* dS) {
+  extern __shared__ float sm[];  // [2][C]
+  for (int i = threadIdx.x; i < 2 * C; i += TPB) sm[i] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int CG = C >> 3;
+  int W2 = 1;
+  while (W2 < CG) W2 <<= 1;           // lanes per pixel (power of two, <= 64 since C <= 512)
+  const int PPW = 64 / W2;            // pixels per wave-iteration
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = l / W2, cg = l % W2;
+  const bool cok = cg < CG;
+  const float dps = dp ? dp[b] : 1.f;
+  float uu[8], ta[8], ba[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { uu[j] = cok ? u[(long long)b * C + cg * 8 + j] : 0.f; ta[j] = ba[j] = 0.f; }
+  long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
+  if (p1 > N) p1 = N;
+  for (long long nb = p0 + wave * PPW; nb < p1; nb += 4 * PPW) {
+    const long long n = nb + sub;
+    const bool ok = cok && n < p1;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    float s = 0.f;
+    if (ok) { load8(dx1, ((long long)b * N + n) * C + cg * 8, 1, v); s = S[(long long)b * N + n]; }
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { v[j] *= dps; dot += v[j] * uu[j]; ta[j] += v[j] * s; ba[j] += v[j]; }
+    for (int o = W2 >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+    if (ok && cg == 0) dS[(long long)b * N + n] = dot;
+  }
+  if (cok) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { atomicAdd(&sm[cg * 8 + j], ta[j]); atomicAdd(&sm[C + cg * 8 + j], ba[j]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += TPB) {
+    atomicAdd(&t[(long long)b * C + i], sm[i]);
+    atomicAdd(&dbp[i], sm[C + i]);
+  }
+}
+
+// dq[b][n][c] = scale*dS[b][n]*k[b][idx[b][n][h(c)]][c] ; dk[b][m][c] += scale*dS[b][n]*q[b][n][c]
+__global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const bf16_t* k, const float* dS, const short* idx,
+                                                         long long N, int M, int heads, int d, float scale, int chunk,
+                                                         bf16_t* dq, float* dk, int use_lds) {
+  extern __shared__ float sdk[];  // [M][C] when use_lds
+  const int b = blockIdx.y;
+  const int C = heads * d, CG = C >> 3;
+  if (use_lds) {
+    for (int i = threadIdx.x; i < M * C; i += TPB) sdk[i] = 0.f;
+    __syncthreads();
+  }
+  long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
+  if (p1 > N) p1 = N;
+  const long long total = (p1 - p0) * CG;
+  for (long long i = threadIdx.x; i < total; i += TPB) {
+    const int cg = (int)(i % CG);
+    const long long n = p0 + i / CG;
+    const int h = (cg * 8) / d;
+    const int m = idx[((long long)b * N + n) * heads + h];
+    const float g = scale * dS[(long long)b * N + n];
+    float kv[8], qv[8];
+    load8(k, ((long long)b * M + m) * C + cg * 8, 0, kv);
+    load8(q, ((long long)b * N + n) * C + cg * 8, 0, qv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kv[j] *= g;
+    store8_bf16(dq, ((long long)b * N + n) * C + cg * 8, kv);
+    float* dst = use_lds ? &sdk[m * C + cg * 8] : &dk[((long long)b * M + m) * C + cg * 8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(dst + j, g * qv[j]);
+  }
+  if (use_lds) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < M * C; i += TPB)
+      if (sdk[i] != 0.f) atomicAdd(&dk[(long long)b * M * C + i], sdk[i]);
+  }
+}
+
+}  // namespace
+
+extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
+                             int32_t flip, void* y, float* stats, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && w9 && y, "crd_dwconv3x3: null pointer");
+  CRD_CHECK_ARG(C % 16 == 0, "crd_dwconv3x3: C must be a multiple of 16");
+  const long long total = (long long)H * W * (C / 8);
+  dim3 grid((unsigned)cdiv(total, TPB), B);
+  hipLaunchKernelGGL(k_dwconv, grid, dim3(TPB), stats ? (C / 16) * 2 * sizeof(float) : 0, as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(x), H, W, C, w9, bias, flip, reinterpret_cast<bf16_t*>(y), stats);
+  CRD_LAUNCH_CHECK("crd_dwconv3x3");
+  return CRD_OK;
+}
+
+extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw9,
+                                   float* dbias, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && dy && dw9 && dbias, "crd_dwconv3x3_wgrad: null pointer");
+  CRD_CHECK_ARG(C % 16 == 0 && C <= 2048, "crd_dwconv3x3_wgrad: C must be a multiple of 16, <= 2048");
+  const int CG = C / 8;
+  int PL = TPB / CG; if (PL < 1) PL = 1;
+  const int P = H * W;
+  int nblk = cdiv(P, PL * 8);
+  int cap = 1024 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  if (nblk > cap) nblk = cap;
+  int chunk = cdiv(P, nblk);
+  nblk = cdiv(P, chunk);
+  hipLaunchKernelGGL(k_dwconv_wgrad, dim3(nblk, B), dim3(TPB), 10 * C * sizeof(float), as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), H, W, C, chunk, dw9, dbias);
+  CRD_LAUNCH_CHECK("crd_dwconv3x3_wgrad");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
+                               float scale, float* S, int16_t* idx, crd_stream_t stream) {
+  CRD_CHECK_ARG(q && k && S && idx, "crd_attn_scores: null pointer");
+  CRD_UNSUPPORTED(d % 8 == 0 && d <= 64 && M < 32768, "crd_attn_scores: head dim must be a multiple of 8, <= 64 (got %d)", d);
+  dim3 grid(cdiv(N, 128), B);
+  hipLaunchKernelGGL(k_attn_scores, grid, dim3(TPB), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(q),
+                     reinterpret_cast<const bf16_t*>(k), N, M, heads, d, scale, S, idx);
+  CRD_LAUNCH_CHECK("crd_attn_scores");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma, const float* beta, int32_t B,
+                             int32_t N, int32_t C, void* xbar, crd_stream_t stream) {
+  CRD_CHECK_ARG(chan_sums && stats && gamma && beta && xbar, "crd_attn_xbar: null pointer");
+  hipLaunchKernelGGL(k_attn_xbar, dim3(B), dim3(256), 0, as_stream(stream), chan_sums, stats, gamma, beta, N, C,
+                     reinterpret_cast<bf16_t*>(xbar));
+  CRD_LAUNCH_CHECK("crd_attn_xbar");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_out_residual(const float* x, const float* u, const float* S, const float* bp, const float* dp,
+                                     int32_t B, int32_t N, int32_t C, float* x1, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && u && S && bp && x1, "crd_attn_out_residual: null pointer");
+  CRD_CHECK_ARG(C % 8 == 0, "crd_attn_out_residual: C %% 8");
+  const long long total = (long long)N * (C / 8);
+  int nblk = cdiv(total, TPB);
+  if (nblk > 2048) nblk = 2048;
+  hipLaunchKernelGGL(k_attn_out_residual, dim3(nblk, B), dim3(TPB), 0, as_stream(stream), x, u, S, bp, dp, (long long)N, C, x1);
+  CRD_LAUNCH_CHECK("crd_attn_out_residual");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
+                                int32_t C, float* t, float* dbp, float* dS, crd_stream_t stream) {
+  CRD_CHECK_ARG(dx1 && u && S && t && dbp && dS, "crd_attn_out_bwd: null pointer");
+  CRD_UNSUPPORTED(C % 8 == 0 && C <= 512, "crd_attn_out_bwd: C must be a multiple of 8 and <= 512");
+  int nblk = cdiv(N, 256);
+  int cap = 1024 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  if (nblk > cap) nblk = cap;
+  int chunk = cdiv(N, nblk);
+  nblk = cdiv(N, chunk);
+  hipLaunchKernelGGL(k_attn_out_bwd, dim3(nblk, B), dim3(TPB), 2 * C * sizeof(float), as_stream(stream), dx1, u, S, dp,
+                     (long long)N, C, chunk, t, dbp, dS);
+  CRD_LAUNCH_CHECK("crd_attn_out_bwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
+                                   int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk,
+                                   crd_stream_t stream) {
+  CRD_CHECK_ARG(q && k && dS && idx && dq && dk, "crd_attn_scores_bwd: null pointer");
+  CRD_CHECK_ARG(d % 8 == 0, "crd_attn_scores_bwd: head dim must be a multiple of 8");
+  const int C = heads * d;
+  const size_t lds = (size_t)M * C * sizeof(float);
+  const int use_lds = lds <= 64 * 1024;
+  int nblk = cdiv(N, use_lds ? 512 : 64);
+  int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  if (nblk > cap) nblk = cap;
+  int chunk = cdiv(N, nblk);
+  nblk = cdiv(N, chunk);
+  hipLaunchKernelGGL(k_attn_scores_bwd, dim3(nblk, B), dim3(TPB), use_lds ? lds : 0, as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), dS, reinterpret_cast<const short*>(idx),
+                     (long long)N, M, heads, d, scale, chunk, reinterpret_cast<bf16_t*>(dq), dk, use_lds);
+  CRD_LAUNCH_CHECK("crd_attn_scores_bwd");
+  return CRD_OK;
+}

@@ -17,7 +17,7 @@ struct ConvK {
   int OW, OHW; int gather_mode;
   void* y; int y_ld; int y_f32; long long y_bstride;
   int out_mode, patch_k, patch_c, YW;
-  const float* bias; int act;
+  const float* bias; int bias_bstride; int act;
   const float* res; int res_ld; long long res_bstride; const float* res_scale;
   int accumulate; float* stats; int G16;
 };
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (l & 31);
     const bool colok = col < a.Cout;
-    const float bias_v = (a.bias && colok) ? a.bias[col] : 0.f;
+    const float bias_v = (a.bias && colok) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
     int pky = 0, pkx = 0, pci = col;
     if (a.out_mode == 1) {
       int tap = col / a.patch_c;
@@ -233,7 +233,7 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   k.YW = YW;
   k.y_bstride = (long long)YH * YW * d->y_ld;
   k.y = d->y_f32 ? (void*)(reinterpret_cast<float*>(d->y) + d->y_coff) : (void*)(reinterpret_cast<bf16_t*>(d->y) + d->y_coff);
-  k.bias = d->bias; k.act = d->act;
+  k.bias = d->bias; k.bias_bstride = d->bias_bstride; k.act = d->act;
   k.res = d->res; k.res_ld = d->res_ld; k.res_bstride = (long long)YH * YW * d->res_ld; k.res_scale = d->res_scale;
   k.accumulate = d->accumulate; k.stats = d->stats; k.G16 = d->Cout / 16;
   hipStream_t st = as_stream(stream);

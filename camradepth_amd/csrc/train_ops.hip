@@ -1,0 +1,279 @@
+// Training-step kernels for gfx950: masked losses, the multi-tensor diffGradNorm optimizer and the
+// table-driven weight pack / gradient unpack between the reference's parameter layout and the
+// bf16 [Cout][tap][Cin] layout the MFMA kernels read.  All are HBM-bound streaming kernels.
+#include <math.h>
+#include "common.h"
+
+namespace {
+
+constexpr int TPB = 256;
+
+__device__ __forceinline__ void block_atomic3(float a, float b, float c, float* acc) {
+  a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
+  __shared__ float sm[3][4];
+  const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (l == 0) { sm[0][w] = a; sm[1][w] = b; sm[2][w] = c; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(acc + 0, sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]);
+    atomicAdd(acc + 1, sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
+    atomicAdd(acc + 2, sm[2][0] + sm[2][1] + sm[2][2] + sm[2][3]);
+  }
+}
+
+// MaskedSmoothL1Loss / MaskedMSELoss partial sums (loss_funcs.py:40-46, 83-91)
+__global__ __launch_bounds__(TPB) void k_masked_l1_fwd(const float* pred, const float* target, long long n, float* acc) {
+  float s = 0.f, cnt = 0.f, sq = 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const float t = target[i];
+    if (t > 0.f) {
+      const float e = pred[i] - t, ae = fabsf(e);
+      s += ae < 1.f ? 0.5f * e * e : ae - 0.5f;
+      sq += e * e;
+      cnt += 1.f;
+    }
+  }
+  block_atomic3(s, cnt, sq, acc);
+}
+
+__global__ __launch_bounds__(TPB) void k_masked_l1_bwd(const float* pred, const float* target, long long n, const float* acc,
+                                                       const float* gout, float gmul, float* dpred) {
+  const float g = gmul * (gout ? gout[0] : 1.f) / acc[1];
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const float t = target[i];
+    float d = 0.f;
+    if (t > 0.f) {
+      const float e = pred[i] - t;
+      d = g * fminf(fmaxf(e, -1.f), 1.f);
+    }
+    dpred[i] = d;
+  }
+}
+
+// Cross entropy over NCHW fp32 logits, labels int64 [B][HW], ignore_index 255 (loss_funcs.py:22,27)
+__global__ __launch_bounds__(TPB) void k_ce_fwd(const float* logits, const long long* labels, int C, long long HW, long long rows,
+                                                float* acc) {
+  float s = 0.f, cnt = 0.f;
+  for (long long r = (long long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long long)gridDim.x * TPB) {
+    const long long lab = labels[r];
+    if (lab == 255) continue;
+    const long long b = r / HW, p = r - b * HW;
+    const float* base = logits + (b * C) * HW + p;
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, base[(long long)c * HW]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(base[(long long)c * HW] - mx);
+    s += mx + logf(se) - base[lab * HW];
+    cnt += 1.f;
+  }
+  block_atomic3(s, cnt, 0.f, acc);
+}
+
+// focal on the scalar mean CE: F=(1-e^-ce)^2 ce ; dF/dce = 2(1-pt)pt ce + (1-pt)^2
+__global__ __launch_bounds__(TPB) void k_ce_focal_bwd(const float* logits, const long long* labels, int C, long long HW,
+                                                      long long rows, const float* acc, const float* gout, float gmul,
+                                                      float* dlogits) {
+  const float ce = acc[0] / acc[1];
+  const float pt = expf(-ce);
+  const float dF = 2.f * (1.f - pt) * pt * ce + (1.f - pt) * (1.f - pt);
+  const float g = gmul * (gout ? gout[0] : 1.f) * dF / acc[1];
+  for (long long r = (long long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long long)gridDim.x * TPB) {
+    const long long lab = labels[r];
+    const long long b = r / HW, p = r - b * HW;
+    const float* base = logits + (b * C) * HW + p;
+    float* dbase = dlogits + (b * C) * HW + p;
+    if (lab == 255) {
+      for (int c = 0; c < C; ++c) dbase[(long long)c * HW] = 0.f;
+      continue;
+    }
+    float mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, base[(long long)c * HW]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(base[(long long)c * HW] - mx);
+    const float inv = 1.f / se;
+    for (int c = 0; c < C; ++c) {
+      float sm = expf(base[(long long)c * HW] - mx) * inv;
+      dbase[(long long)c * HW] = g * (sm - (c == lab ? 1.f : 0.f));
+    }
+  }
+}
+
+// ---- diffGradNorm (src/models/diffGradNorm.py:73-110) -------------------------------------------
+constexpr int OPT_CHUNK = 4096;  // elements per workgroup
+
+__global__ __launch_bounds__(TPB) void k_dgn_norm(const float* p, const float* g, const long long* seg_off, const int* blk2seg,
+                                                  const int* blk2chunk, float wd, float* norm_sq) {
+  const int t = blk2seg[blockIdx.x];
+  const long long beg = seg_off[t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
+  long long end = beg + OPT_CHUNK;
+  if (end > seg_off[t + 1]) end = seg_off[t + 1];
+  float s = 0.f;
+  for (long long i = beg + threadIdx.x; i < end; i += TPB) {
+    float gv = g[i];
+    if (wd != 0.f) gv += wd * p[i];
+    s += gv * gv;
+  }
+  s = wave_sum(s);
+  __shared__ float sm[4];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&norm_sq[t], sm[0] + sm[1] + sm[2] + sm[3]);
+}
+
+// per tensor: e <- 0.95 e + 0.05 n ; factor = e > n ? e/(n+1e-8) : 1 ; norm_sq reset for the next step
+__global__ void k_dgn_scalar(float* exp_grad_norm, float* norm_sq, float* factor, const unsigned char* active, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  if (active && !active[t]) { factor[t] = 1.f; norm_sq[t] = 0.f; return; }
+  const float nrm = sqrtf(norm_sq[t]);
+  const float e = 0.95f * exp_grad_norm[t] + 0.05f * nrm;
+  factor[t] = e > nrm ? e / (nrm + 1e-8f) : 1.f;
+  exp_grad_norm[t] = e;
+  norm_sq[t] = 0.f;
+}
+
+__global__ __launch_bounds__(TPB) void k_dgn_update(float* p, const float* g, float* m, float* v, float* pg, const float* factor,
+                                                    const long long* seg_off, const int* blk2seg, const int* blk2chunk,
+                                                    const unsigned char* active, float beta1, float beta2, float eps, float wd,
+                                                    float step_size) {
+  const int t = blk2seg[blockIdx.x];
+  if (active && !active[t]) return;
+  const long long beg = seg_off[t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
+  long long end = beg + OPT_CHUNK;
+  if (end > seg_off[t + 1]) end = seg_off[t + 1];
+  const float f = factor[t];
+  for (long long i = beg + threadIdx.x; i < end; i += TPB) {
+    float gv = g[i];
+    const float pv = p[i];
+    if (wd != 0.f) gv += wd * pv;
+    const float g1 = gv * f;
+    const float mv = beta1 * m[i] + (1.f - beta1) * g1;
+    const float vv = beta2 * v[i] + (1.f - beta2) * gv * gv;
+    const float dfc = 1.f / (1.f + expf(-fabsf(pg[i] - gv)));
+    m[i] = mv; v[i] = vv; pg[i] = gv;
+    p[i] = pv - step_size * (mv * dfc) / (sqrtf(vv) + eps);
+  }
+}
+
+// ---- weight pack / gradient unpack ------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_weight_pack(const crd_pack_entry* tab) {
+  const crd_pack_entry e = tab[blockIdx.y];
+  const long long n_fwd = (long long)e.Cout * e.taps * e.Cin_pad;
+  const long long n_tr = (long long)e.Cin_pad * e.taps * e.Cout_pad;
+  const long long nmax = n_fwd > n_tr ? n_fwd : n_tr;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < nmax; i += (long long)gridDim.x * TPB) {
+    if (e.dst_fwd && i < n_fwd) {
+      const int ci = (int)(i % e.Cin_pad);
+      const long long r = i / e.Cin_pad;
+      const int tap = (int)(r % e.taps), co = (int)(r / e.taps);
+      const int cr = e.cmap ? e.cmap[ci] : (ci < e.Cin_ref ? ci : -1);
+      float v = cr >= 0 ? e.src[((long long)co * e.Cin_ref + cr) * e.taps + tap] : 0.f;
+      reinterpret_cast<bf16_t*>(e.dst_fwd)[i] = f2bf(v);
+    }
+    if ((e.dst_dgrad || e.dst_scatter) && i < n_tr) {
+      // i enumerates [ci][tap][co_pad] (dgrad order)
+      const int co = (int)(i % e.Cout_pad);
+      const long long r = i / e.Cout_pad;
+      const int tap = (int)(r % e.taps), ci = (int)(r / e.taps);
+      const int cr = e.cmap ? e.cmap[ci] : (ci < e.Cin_ref ? ci : -1);
+      float v = (cr >= 0 && co < e.Cout) ? e.src[((long long)co * e.Cin_ref + cr) * e.taps + tap] : 0.f;
+      const bf16_t q = f2bf(v);
+      if (e.dst_dgrad) reinterpret_cast<bf16_t*>(e.dst_dgrad)[i] = q;
+      if (e.dst_scatter) reinterpret_cast<bf16_t*>(e.dst_scatter)[((long long)tap * e.Cin_pad + ci) * e.Cout_pad + co] = q;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TPB) void k_wgrad_unpack(const crd_unpack_entry* tab, int accumulate) {
+  const crd_unpack_entry e = tab[blockIdx.y];
+  const long long n = (long long)e.Cout * e.taps * e.Cin_pad;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    const int ci = (int)(i % e.Cin_pad);
+    const long long r = i / e.Cin_pad;
+    const int tap = (int)(r % e.taps), co = (int)(r / e.taps);
+    const int cr = e.cmap ? e.cmap[ci] : (ci < e.Cin_ref ? ci : -1);
+    if (cr < 0) continue;
+    float* d = e.dst + ((long long)co * e.Cin_ref + cr) * e.taps + tap;
+    *d = accumulate ? *d + e.src[i] : e.src[i];
+  }
+}
+
+inline int blocks_for(long long total, int cap = 2048) {
+  long long n = (total + TPB - 1) / TPB;
+  if (n > cap) n = cap;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+
+}  // namespace
+
+extern "C" int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, float* acc, crd_stream_t stream) {
+  CRD_CHECK_ARG(pred && target && acc && n > 0, "crd_masked_l1_fwd: bad argument");
+  hipLaunchKernelGGL(k_masked_l1_fwd, dim3(blocks_for(n, 512)), dim3(TPB), 0, as_stream(stream), pred, target, (long long)n, acc);
+  CRD_LAUNCH_CHECK("crd_masked_l1_fwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const float* acc, const float* gout,
+                                 float gmul, float* dpred, crd_stream_t stream) {
+  CRD_CHECK_ARG(pred && target && acc && dpred && n > 0, "crd_masked_l1_bwd: bad argument");
+  hipLaunchKernelGGL(k_masked_l1_bwd, dim3(blocks_for(n)), dim3(TPB), 0, as_stream(stream), pred, target, (long long)n, acc, gout,
+                     gmul, dpred);
+  CRD_LAUNCH_CHECK("crd_masked_l1_bwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_ce_fwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, float* acc,
+                          crd_stream_t stream) {
+  CRD_CHECK_ARG(logits && labels && acc && B > 0 && C > 0 && HW > 0, "crd_ce_fwd: bad argument");
+  const long long rows = (long long)B * HW;
+  hipLaunchKernelGGL(k_ce_fwd, dim3(blocks_for(rows, 1024)), dim3(TPB), 0, as_stream(stream), logits,
+                     reinterpret_cast<const long long*>(labels), C, (long long)HW, rows, acc);
+  CRD_LAUNCH_CHECK("crd_ce_fwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, const float* acc,
+                                const float* gout, float gmul, float* dlogits, crd_stream_t stream) {
+  CRD_CHECK_ARG(logits && labels && acc && dlogits && B > 0 && C > 0 && HW > 0, "crd_ce_focal_bwd: bad argument");
+  const long long rows = (long long)B * HW;
+  hipLaunchKernelGGL(k_ce_focal_bwd, dim3(blocks_for(rows)), dim3(TPB), 0, as_stream(stream), logits,
+                     reinterpret_cast<const long long*>(labels), C, (long long)HW, rows, acc, gout, gmul, dlogits);
+  CRD_LAUNCH_CHECK("crd_ce_focal_bwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* prev_grad,
+                                     float* exp_grad_norm, float* norm_sq, float* factor, const int64_t* seg_off,
+                                     const int32_t* blk2seg, const int32_t* blk2chunk, int32_t n_tensors, int32_t n_blocks,
+                                     const uint8_t* active, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                     int32_t step, crd_stream_t stream) {
+  CRD_CHECK_ARG(p && g && exp_avg && exp_avg_sq && prev_grad && exp_grad_norm && norm_sq && factor && seg_off && blk2seg &&
+                    blk2chunk && n_tensors > 0 && n_blocks > 0 && step >= 1,
+                "crd_diffgradnorm_step: bad argument");
+  hipStream_t st = as_stream(stream);
+  const long long* so = reinterpret_cast<const long long*>(seg_off);
+  hipLaunchKernelGGL(k_dgn_norm, dim3(n_blocks), dim3(TPB), 0, st, p, g, so, blk2seg, blk2chunk, weight_decay, norm_sq);
+  hipLaunchKernelGGL(k_dgn_scalar, dim3(cdiv(n_tensors, 256)), dim3(256), 0, st, exp_grad_norm, norm_sq, factor, active, n_tensors);
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr * sqrt(bc2) / (bc1 + 1e-8));
+  hipLaunchKernelGGL(k_dgn_update, dim3(n_blocks), dim3(TPB), 0, st, p, g, exp_avg, exp_avg_sq, prev_grad, factor, so, blk2seg,
+                     blk2chunk, active, beta1, beta2, eps, weight_decay, step_size);
+  CRD_LAUNCH_CHECK("crd_diffgradnorm_step");
+  return CRD_OK;
+}
+
+extern "C" int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int64_t max_elems, crd_stream_t stream) {
+  CRD_CHECK_ARG(table_dev && n > 0 && max_elems > 0, "crd_weight_pack: bad argument");
+  hipLaunchKernelGGL(k_weight_pack, dim3(blocks_for(max_elems, 256), n), dim3(TPB), 0, as_stream(stream), table_dev);
+  CRD_LAUNCH_CHECK("crd_weight_pack");
+  return CRD_OK;
+}
+
+extern "C" int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int64_t max_elems, int32_t accumulate,
+                                crd_stream_t stream) {
+  CRD_CHECK_ARG(table_dev && n > 0 && max_elems > 0, "crd_wgrad_unpack: bad argument");
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3(blocks_for(max_elems, 256), n), dim3(TPB), 0, as_stream(stream), table_dev, accumulate);
+  CRD_LAUNCH_CHECK("crd_wgrad_unpack");
+  return CRD_OK;
+}

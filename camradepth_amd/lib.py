@@ -25,7 +25,7 @@ class ConvDesc(C.Structure):
         ("gather_mode", C.c_int32),
         ("y", C.c_void_p), ("y_ld", C.c_int32), ("y_coff", C.c_int32), ("y_f32", C.c_int32),
         ("out_mode", C.c_int32), ("patch_k", C.c_int32), ("patch_c", C.c_int32),
-        ("bias", C.c_void_p), ("act", C.c_int32),
+        ("bias", C.c_void_p), ("bias_bstride", C.c_int32), ("act", C.c_int32),
         ("res", C.c_void_p), ("res_ld", C.c_int32), ("res_scale", C.c_void_p),
         ("accumulate", C.c_int32), ("stats", C.c_void_p),
     ]
@@ -76,20 +76,32 @@ def load():
     missing = [n for n in EXPORTS if not hasattr(lib, n)]
     if missing:
         raise CrdError(f"{LIB_PATH} lacks symbols {missing}: rebuild it (python -m camradepth_amd.build)")
-    for name in EXPORTS:
-        getattr(lib, name).restype = C.c_int
+    for name, sig in _SIGS.items():
+        fn = getattr(lib, name)
+        fn.restype = C.c_int
+        fn.argtypes = [_CT[ch] for ch in sig]
     _lib = lib
     return lib
 
 
-# every symbol include/camradepth_hip.h declares with an int status (checked by tests/test_abi.py)
-EXPORTS = [
-    "crd_conv_igemm", "crd_conv_wgrad", "crd_gn_stats", "crd_gn_apply", "crd_gn_bwd_reduce", "crd_gn_bwd_apply",
-    "crd_dwconv3x3", "crd_dwconv3x3_wgrad", "crd_attn_scores", "crd_attn_out_residual", "crd_attn_out_bwd",
-    "crd_attn_scores_bwd", "crd_bicubic2x", "crd_bicubic2x_bwd", "crd_nchw_to_pm", "crd_pm_to_nchw",
-    "crd_seg_argmax", "crd_slice_copy", "crd_f32_to_bf16_rows", "crd_weight_pack", "crd_wgrad_unpack",
-    "crd_masked_l1_fwd", "crd_masked_l1_bwd", "crd_ce_fwd", "crd_ce_focal_bwd", "crd_diffgradnorm_step",
-]
+# Signatures of include/camradepth_hip.h (all return int status). p = pointer, i = int32, l = int64, f = float
+_SIGS = {
+    "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp",
+    "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
+    "crd_gn_bwd_reduce": "piiipiiiiiipippippp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiip",
+    "crd_dwconv3x3": "piiiippippp", "crd_dwconv3x3_wgrad": "ppiiiippp",
+    "crd_attn_scores": "ppiiiiifppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_out_residual": "pppppiiipp",
+    "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifppp",
+    "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
+    "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiip",
+    "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiilipLp".replace("L", "l"), "crd_sigmoid_bwd": "pplp",
+    "crd_weight_pack": "pilp", "crd_wgrad_unpack": "pilip",
+    "crd_masked_l1_fwd": "pplpp", "crd_masked_l1_bwd": "pplppfpp", "crd_ce_fwd": "ppiilpp",
+    "crd_ce_focal_bwd": "ppiilppfpp",
+    "crd_diffgradnorm_step": "pppppppppppiipfffffip",
+}
+_CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float}
+EXPORTS = list(_SIGS)
 
 
 def check(rc, what=""):

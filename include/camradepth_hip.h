@@ -60,7 +60,8 @@ typedef struct {
   int32_t out_mode;             /* 0: y[b,oy,ox,n]; 1: patch scatter: n=(ky*pk+kx)*pc+c ->
                                    y[b, oy*pk+ky, ox*pk+kx, c] (data gradient of a k=s conv) */
   int32_t patch_k, patch_c;
-  const float* bias;  /* [Cout] or NULL */
+  const float* bias;  /* [Cout] or NULL; element (b, co) is bias[b*bias_bstride + co] */
+  int32_t bias_bstride;         /* 0: shared by all images; >0: one bias row per image */
   int32_t act;                  /* 0 none, 1 sigmoid */
   const float* res;   /* fp32, same indexing as y (ld = res_ld): y = res + res_scale[b]*v, or NULL */
   int32_t res_ld;
@@ -96,10 +97,10 @@ int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int
                  float* stats, float* chan_sums, crd_stream_t stream);
 
 /* y = act((x-mean)*rstd*gamma+beta) * mask[b][c];  act: 0 none, 1 exact GELU.  mask may be NULL.
- * y is bf16 (pixel-major slice).  eps = 1e-5. */
+ * y is a bf16 (y_f32=0) or fp32 (y_f32=1) pixel-major slice.  eps = 1e-5. */
 int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
                  const float* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
-                 const float* mask, void* y, int32_t y_ld, int32_t y_coff, crd_stream_t stream);
+                 const float* mask, void* y, int32_t y_f32, int32_t y_ld, int32_t y_coff, crd_stream_t stream);
 
 /* Backward, phase 1: per (b, c) sums  r[b][c] = (sum g, sum g*xhat), g = dy*mask*act'(u),
  * u = xhat*gamma+beta.  dy is bf16 or fp32 pixel-major.  r must be zeroed by the caller. */
@@ -117,37 +118,41 @@ int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff,
                      int32_t dx_coff, int32_t dx_accumulate, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Depthwise 3x3 (DWConv, simplified_attention.py:316,318-323).  w9 is fp32 [9][C], bias [C].
- * flip=1 computes the data gradient (taps mirrored, no bias).  Optional g16 stats of the output.
+ * Depthwise 3x3 (DWConv, simplified_attention.py:316,318-323), pixel-major bf16 [B][H][W][C].
+ * w9 is fp32 [9][C] (tap-major), bias [C] or NULL.  flip=1 mirrors the taps (data gradient).
+ * Optional g16 stats of the rounded output.
  * ------------------------------------------------------------------------------------------- */
 int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
                   int32_t flip, void* y, float* stats, crd_stream_t stream);
-/* dw9[tap][c] += sum dy*x_shifted ; dbias[c] += sum dy */
+/* dw9[tap][c] += sum dy*x_shifted ; dbias[c] += sum dy   (fp32 atomics; caller zeroes) */
 int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw9,
                         float* dbias, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Max-pool attention (Attention_MaxPool.forward, simplified_attention.py:90-109).
- * q: bf16 [B][N][C], k: bf16 [B][M][C] (C = heads*d).  S[b][n] = sum_h scale*max_m q.k ,
- * idx[b][n][h] = argmax m (uint8, M <= 256... M is carried as int16).
+ * q: bf16 [B][N][C], k: bf16 [B][M][C], C = heads*d.
+ *   S[b][n] = sum_h max_m bf16(bf16(q_h.k_h)*scale)      idx[b][n][h] = argmax m
+ * Since v = mean_n(x) is shared by all heads (:103) the output of `proj` is rank one:
+ *   proj(out)[b][n][c] = u[b][c]*S[b][n] + bp[c],  u[b] = Wp xbar[b],  xbar = mean_n GroupNorm(x).
  * ------------------------------------------------------------------------------------------- */
 int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
                     float scale, float* S, int16_t* idx, crd_stream_t stream);
-/* x1[b][n][c] = x[b][n][c] + dp[b] * (u[b][c]*S[b][n] + bp[c])  (fp32; Block residual, :143).
- * Optionally accumulates g16 stats / channel sums of x1 (input of Block.norm2). */
+/* xbar[b][c] (bf16) from per-channel sums chan[b][c][2] and g16 stats of x (gmul = 1). */
+int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma, const float* beta, int32_t B,
+                  int32_t N, int32_t C, void* xbar, crd_stream_t stream);
+/* x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])   (fp32 residual stream; Block.forward :143; dp may be NULL) */
 int crd_attn_out_residual(const float* x, const float* u, const float* S, const float* bp, const float* dp,
                           int32_t B, int32_t N, int32_t C, float* x1, crd_stream_t stream);
-/* Backward of the above w.r.t. the branch y = u*S + bp given dy = dp[b]*dx1 (fp32 [B][N][C]):
- * t[b][c] += sum_n dy*S ; dbp[c] += sum_{b,n} dy ; dS[b][n] = sum_c dy*u. */
+/* with dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp[c] += sum_{b,n} dy ; dS[b][n] = sum_c dy*u[b][c] */
 int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
                      int32_t C, float* t, float* dbp, float* dS, crd_stream_t stream);
-/* dq[b][n][h*d+j] = scale*dS[b][n]*k[b][idx][h*d+j] (bf16) ; dk[b][m][h*d+j] += scale*dS*q (fp32 atomics). */
+/* dq[b][n][c] = scale*dS[b][n]*k[b][idx][c] (bf16) ; dk[b][m][c] += scale*dS*q (fp32, caller zeroes) */
 int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
                         int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Bicubic x2 up-sampling, A=-0.75, align_corners=False (nn.Upsample, utils.py:241,251).
- * bf16 in (slice) -> bf16 out (slice).  bwd: dx (+)= transpose; dx is bf16.
+ * Bicubic x2 up-sampling, A=-0.75, align_corners=False, clamped borders (nn.Upsample, utils.py:241,
+ * 251).  bf16 slice -> bf16 slice; the backward is the exact transpose.
  * ------------------------------------------------------------------------------------------- */
 int crd_bicubic2x(const void* x, int32_t x_ld, int32_t x_coff, int32_t B, int32_t H, int32_t W, int32_t C, void* y,
                   int32_t y_ld, int32_t y_coff, crd_stream_t stream);
@@ -157,36 +162,37 @@ int crd_bicubic2x_bwd(const void* dy, int32_t dy_ld, int32_t dy_coff, int32_t B,
 /* ---------------------------------------------------------------------------------------------
  * Layout / small elementwise helpers at the module boundary.
  * ------------------------------------------------------------------------------------------- */
-/* NCHW fp32 [B][C][H][W] -> pixel-major bf16 slice (channels C..Cpad-1 of the slice are zeroed). */
+/* NCHW fp32 [B][C][H][W] -> pixel-major bf16 slice; channels C..Cpad-1 of the slice are zeroed. */
 int crd_nchw_to_pm(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, void* y, int32_t y_ld, int32_t y_coff,
                    int32_t Cpad, crd_stream_t stream);
 /* pixel-major (bf16 or fp32) -> NCHW fp32 */
 int crd_pm_to_nchw(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t C, int32_t H,
                    int32_t W, float* y, crd_stream_t stream);
-/* NCHW fp32 gradient -> pixel-major bf16 slice (used to feed head gradients into the backward) */
-/* Seg_Block (utils.py:95-100): y[b,p,coff] = argmax_c logits[b,p,c] / num_classes  (bf16 slice, 1 channel) */
+/* Seg_Block (utils.py:95-100): y[row][y_coff] = argmax_c logits[row][c] / num_classes (first max wins) */
 int crd_seg_argmax(const void* logits, int32_t ld, int32_t B, int32_t P, int32_t C, int32_t num_classes, void* y,
                    int32_t y_ld, int32_t y_coff, crd_stream_t stream);
-/* dst[b,p,dcoff+c] = src[b,p,scoff+c]  (bf16 slice copy; accumulate: +=) */
+/* dst[row][d_coff+c] (+)= src[row][s_coff+c]   (bf16 slices) */
 int crd_slice_copy(const void* src, int32_t s_ld, int32_t s_coff, void* dst, int32_t d_ld, int32_t d_coff,
                    int64_t rows, int32_t C, int32_t accumulate, crd_stream_t stream);
-/* fp32 [rows][C] -> bf16 slice, optionally scaled per sample: used for residual-gradient hand-off */
-int crd_f32_to_bf16_rows(const float* src, void* dst, int32_t d_ld, int32_t d_coff, int64_t rows, int32_t C,
-                         crd_stream_t stream);
+/* dst[row][d_coff+c] = bf16(scale[row / rows_per_sample] * src[row*s_ld + c]), c < C (scale may be NULL) */
+int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, int32_t d_ld, int32_t d_coff, int64_t rows,
+                         int32_t C, const float* scale, int64_t rows_per_sample, crd_stream_t stream);
+/* da <- da * a * (1-a)   (bf16, n elements, n % 8 == 0): backward of the sigmoid in Depth_Activation */
+int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Weight packing: fp32 reference layout [Cout][Cin_ref][KH][KW] -> bf16 [Cout][taps][Cin_pad]
- * (and the two transposed forms the data-gradient kernels read), table-driven, one launch.
+ * Weight packing: fp32 reference layout [Cout][Cin_ref][taps] -> bf16 [Cout][taps][Cin_pad]
+ * and the two transposed forms the data-gradient kernels read; table-driven, one launch.
  * ------------------------------------------------------------------------------------------- */
 typedef struct {
   const float* src;    /* [Cout][Cin_ref][taps] fp32 (reference layout) */
-  void* dst_fwd;       /* bf16 [Cout][taps][Cin_pad]  or NULL */
-  void* dst_dgrad;     /* bf16 [Cin_pad][taps][Cout_pad8] or NULL   (gather_mode 1) */
-  void* dst_scatter;   /* bf16 [taps][Cin_pad][Cout_pad8] or NULL   (out_mode 1)    */
+  void* dst_fwd;       /* bf16 [Cout][taps][Cin_pad]      or NULL */
+  void* dst_dgrad;     /* bf16 [Cin_pad][taps][Cout_pad]  or NULL   (gather_mode 1) */
+  void* dst_scatter;   /* bf16 [taps][Cin_pad][Cout_pad]  or NULL   (out_mode 1)    */
   const int32_t* cmap; /* [Cin_pad]: reference input channel of each packed channel, -1 = zero; NULL = identity */
   int32_t Cout, Cin_ref, taps, Cin_pad, Cout_pad;
 } crd_pack_entry;
-int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int32_t max_elems, crd_stream_t stream);
+int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int64_t max_elems, crd_stream_t stream);
 /* grad_ref[co][ci_ref][tap] (+)= dw_packed[co][tap][ci_pad] */
 typedef struct {
   const float* src;    /* fp32 [Cout][taps][Cin_pad] */
@@ -194,36 +200,37 @@ typedef struct {
   const int32_t* cmap;
   int32_t Cout, Cin_ref, taps, Cin_pad;
 } crd_unpack_entry;
-int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int32_t max_elems, int32_t accumulate,
+int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int64_t max_elems, int32_t accumulate,
                      crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses (src/utils/loss_funcs.py:14-46,77-91; combination src/main/runner.py:197-218).
- * acc layout (float[8], zeroed by caller): [0]=sum smoothL1, [1]=count, [2]=sum sq err, ...
  * ------------------------------------------------------------------------------------------- */
-/* pred, target fp32 [n]; acc[0]+=sum smooth_l1(pred-target) over target>0, acc[1]+=count, acc[2]+=sum (t-p)^2 */
+/* acc[0] += sum smooth_l1(pred-target), acc[1] += #(target>0), acc[2] += sum (target-pred)^2 ; caller zeroes acc */
 int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, float* acc, crd_stream_t stream);
-/* dpred[i] = gscale * clamp(p-t,-1,1) / acc[1]  on target>0 else 0 ; gscale read from *gscale_dev * gmul */
+/* dpred = gmul * gout[0] * clamp(pred-target,-1,1) / acc[1] on target>0, else 0   (gout may be NULL = 1) */
 int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const float* acc, const float* gout,
                       float gmul, float* dpred, crd_stream_t stream);
-/* cross entropy over pixel-major fp32 logits [rows][C] (ld), labels int64 [rows], ignore 255:
- * acc[0] += sum -log softmax[label], acc[1] += count */
-int crd_ce_fwd(const float* logits, int32_t ld, const int64_t* labels, int64_t rows, int32_t C, float* acc,
+/* NCHW fp32 logits [B][C][HW], int64 labels [B][HW], ignore_index 255:
+ * acc[0] += sum -log softmax[label], acc[1] += #valid */
+int crd_ce_fwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, float* acc,
                crd_stream_t stream);
-/* focal on the mean CE: F=(1-e^-ce)^2 ce ; dlogits = gmul*gout*dF/dce*(softmax-onehot)/count */
-int crd_ce_focal_bwd(const float* logits, int32_t ld, const int64_t* labels, int64_t rows, int32_t C,
-                     const float* acc, const float* gout, float gmul, float* dlogits, crd_stream_t stream);
+/* focal on the scalar mean CE (loss_funcs.py:27-29): dlogits = gmul*gout[0]*dF/dce*(softmax-onehot)/acc[1] */
+int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, const float* acc,
+                     const float* gout, float gmul, float* dlogits, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * diffGradNorm.step (src/models/diffGradNorm.py:41-113) over flat fp32 buffers.
- * seg_off[t]..seg_off[t+1] delimits tensor t inside the flat buffers (n_tensors+1 int64 entries).
- * norm_sq: float[n_tensors] scratch.  exp_grad_norm: float[n_tensors] state.
- * active: uint8[n_tensors] or NULL (tensors whose grad is None are skipped, :54-55).
+ * Tensor t occupies [seg_off[t], seg_off[t+1]) of every flat buffer.  Workgroup w processes chunk
+ * blk2chunk[w] (4096 elements) of tensor blk2seg[w].  exp_grad_norm / norm_sq / factor are
+ * float[n_tensors] (norm_sq must be zero on entry and is left zero).  active[t]=0 skips tensor t
+ * (`p.grad is None`, :54-55).  `step` is the 1-based step count used for the bias corrections.
  * ------------------------------------------------------------------------------------------- */
 int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* prev_grad,
-                          float* exp_grad_norm, float* norm_sq, const int64_t* seg_off, const int32_t* blk2seg,
-                          int32_t n_tensors, int32_t n_blocks, const uint8_t* active, float lr, float beta1,
-                          float beta2, float eps, float weight_decay, int32_t step, crd_stream_t stream);
+                          float* exp_grad_norm, float* norm_sq, float* factor, const int64_t* seg_off,
+                          const int32_t* blk2seg, const int32_t* blk2chunk, int32_t n_tensors, int32_t n_blocks,
+                          const uint8_t* active, float lr, float beta1, float beta2, float eps, float weight_decay,
+                          int32_t step, crd_stream_t stream);
 
 #ifdef __cplusplus
 }

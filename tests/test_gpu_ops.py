@@ -1,0 +1,417 @@
+"""GPU parity of the non-GEMM kernels and the weight-gradient kernel against torch fp32 references
+computed on the same bf16-rounded operands (through the C ABI, ctypes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_igemm import assert_close, bf, to_pm
+
+pytestmark = pytest.mark.gpu
+
+
+def L():
+    from camradepth_amd import lib
+    return lib, lib.load()
+
+
+def P(t):
+    return None if t is None else t.data_ptr()
+
+
+def ok(rc, what):
+    lib, _ = L()
+    lib.check(rc, what)
+    torch.cuda.synchronize()
+
+
+WG_CASES = [
+    # B, Cin, Cin_pad, H, W, Cout, k, s, p
+    (2, 136, 136, 19, 23, 96, 3, 1, 1),
+    (1, 232, 232, 16, 20, 64, 3, 1, 1),
+    (2, 296, 296, 9, 14, 128, 3, 1, 1),
+    (2, 129, 136, 12, 13, 32, 3, 1, 1),
+    (2, 128, 128, 10, 11, 21, 3, 1, 1),
+    (1, 32, 32, 13, 9, 1, 3, 1, 1),
+    (2, 7, 8, 32, 48, 64, 7, 4, 3),
+    (2, 64, 64, 16, 24, 128, 3, 2, 1),
+    (2, 64, 64, 16, 24, 64, 8, 8, 0),
+    (3, 256, 256, 4, 7, 256, 1, 1, 0),
+    (2, 64, 64, 40, 52, 512, 1, 1, 0),
+    (1, 640, 640, 6, 7, 160, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_conv_wgrad(case):
+    lib, lb = L()
+    B, Ci, Cp, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(7)
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    bias = torch.zeros(Co, requires_grad=True)
+    y = F.conv2d(x, w, bias, stride=s, padding=p)
+    OH, OW = y.shape[2], y.shape[3]
+    dy = bf(torch.randn(B, Co, OH, OW, generator=g))
+    y.backward(dy)
+    Cop = ((Co + 7) // 8) * 8
+    xpm, dypm = to_pm(x, ld=Cp), to_pm(dy, ld=Cop)
+    dw = torch.zeros(Co, k * k, Cp, device="cuda")
+    db = torch.zeros(Co, device="cuda")
+    d = lib.WgradDesc()
+    d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = P(xpm), Cp, 0, B, H, W, Cp
+    d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = P(dypm), Cop, 0, OH, OW, Co
+    d.KH, d.KW, d.stride, d.pad, d.dw, d.dbias = k, k, s, p, P(dw), P(db)
+    ok(lb.crd_conv_wgrad(C.byref(d), lib.stream()), "crd_conv_wgrad")
+    got = dw.cpu()[:, :, :Ci].reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
+    assert_close(got, w.grad, f"wgrad {case}", rel=2e-3, elem=4e-3)
+    assert_close(db.cpu(), bias.grad, f"dbias {case}", rel=2e-3, elem=4e-3)
+    if Cp > Ci:
+        assert float(dw[:, :, Ci:].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C_,gmul,xf32,act", [(64, 1, 1, 0), (96, 1, 0, 1), (512, 8, 0, 1), (160, 1, 1, 0), (640, 4, 0, 1),
+                                               (1024, 4, 0, 0)])
+def test_groupnorm_forward_backward(C_, gmul, xf32, act):
+    lib, lb = L()
+    g = torch.Generator().manual_seed(1)
+    B, Pn = 2, 77
+    x = torch.randn(B, C_, Pn, generator=g) * 1.5 + 0.3
+    if not xf32:
+        x = bf(x)
+    gamma = (1 + 0.1 * torch.randn(C_, generator=g)).requires_grad_(True)
+    beta = (0.1 * torch.randn(C_, generator=g)).requires_grad_(True)
+    mask = (torch.rand(B, C_, generator=g) < 0.8).float() / 0.8
+    xr = x.clone().requires_grad_(True)
+    groups = C_ // (16 * gmul)
+    yref = F.group_norm(xr, groups, gamma, beta, 1e-5)
+    if act:
+        yref = F.gelu(yref)
+    yref = yref * mask.view(B, C_, 1)
+    dy = bf(torch.randn(B, C_, Pn, generator=g))
+    yref.backward(dy)
+    xpm = x.permute(0, 2, 1).contiguous()
+    xd = (xpm if xf32 else xpm.to(torch.bfloat16)).cuda()
+    stats = torch.zeros(B, C_ // 16, 2, device="cuda")
+    chan = torch.zeros(B, C_, 2, device="cuda")
+    ok(lb.crd_gn_stats(P(xd), xf32, C_, 0, B, Pn, C_, P(stats), P(chan), lib.stream()), "gn_stats")
+    ref_chan = torch.stack([x.sum(2), (x ** 2).sum(2)], -1)
+    assert_close(chan.cpu(), ref_chan, "chan sums", rel=1e-4, elem=1e-4)
+    assert_close(stats.cpu(), ref_chan.reshape(B, C_ // 16, 16, 2).sum(2), "g16 stats", rel=1e-4, elem=1e-4)
+    y = torch.zeros(B, Pn, C_ + 8, dtype=torch.bfloat16, device="cuda")
+    gc, bc, mc = gamma.detach().cuda(), beta.detach().cuda(), mask.cuda()
+    ok(lb.crd_gn_apply(P(xd), xf32, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(y), 0, C_ + 8, 8,
+                       lib.stream()), "gn_apply")
+    assert_close(y[..., 8:].float().cpu().permute(0, 2, 1), yref.detach(), "gn_apply", rel=4e-3, elem=1e-2)
+    # fp32 output variant
+    yf = torch.zeros(B, Pn, C_, device="cuda")
+    ok(lb.crd_gn_apply(P(xd), xf32, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(yf), 1, C_, 0,
+                       lib.stream()), "gn_apply f32")
+    assert_close(yf.cpu().permute(0, 2, 1), yref.detach(), "gn_apply f32", rel=1e-4, elem=1e-4)
+    # backward
+    dyd = dy.permute(0, 2, 1).contiguous().to(torch.bfloat16).cuda()
+    r = torch.zeros(B, C_, 2, device="cuda")
+    ok(lb.crd_gn_bwd_reduce(P(xd), xf32, C_, 0, P(dyd), 0, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(r),
+                            lib.stream()), "gn_bwd_reduce")
+    dgam, dbet = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    dx = torch.zeros(B, Pn, C_, dtype=torch.bfloat16, device="cuda")
+    ok(lb.crd_gn_bwd_apply(P(xd), xf32, C_, 0, P(dyd), 0, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(r),
+                           P(dgam), P(dbet), P(dx), 0, C_, 0, 0, lib.stream()), "gn_bwd_apply")
+    assert_close(dx.float().cpu().permute(0, 2, 1), xr.grad, "gn dx", rel=6e-3, elem=2e-2)
+    assert_close(dgam.cpu(), gamma.grad, "dgamma", rel=2e-3, elem=4e-3)
+    assert_close(dbet.cpu(), beta.grad, "dbeta", rel=2e-3, elem=4e-3)
+    # fp32 accumulate variant
+    base = torch.randn(B, Pn, C_, generator=g)
+    dxf = base.clone().cuda()
+    ok(lb.crd_gn_bwd_apply(P(xd), xf32, C_, 0, P(dyd), 0, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(r),
+                           None, None, P(dxf), 1, C_, 0, 1, lib.stream()), "gn_bwd_apply f32")
+    assert_close(dxf.cpu() - base, xr.grad.permute(0, 2, 1), "gn dx f32 acc", rel=1e-3, elem=2e-3)
+
+
+@pytest.mark.parametrize("C_,H,W", [(64, 9, 13), (512, 8, 12), (160, 5, 7)])
+def test_dwconv(C_, H, W):
+    lib, lb = L()
+    g = torch.Generator().manual_seed(2)
+    B = 2
+    x = bf(torch.randn(B, C_, H, W, generator=g))
+    w = (torch.randn(C_, 1, 3, 3, generator=g) / 3).requires_grad_(True)
+    b = (torch.randn(C_, generator=g) * 0.1).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yref = F.conv2d(xr, w, b, padding=1, groups=C_)
+    dy = bf(torch.randn(B, C_, H, W, generator=g))
+    yref.backward(dy)
+    w9 = w.detach().reshape(C_, 9).t().contiguous().cuda()
+    xd = to_pm(x)
+    y = torch.zeros(B, H, W, C_, dtype=torch.bfloat16, device="cuda")
+    stats = torch.zeros(B, C_ // 16, 2, device="cuda")
+    bc = b.detach().cuda()
+    ok(lb.crd_dwconv3x3(P(xd), B, H, W, C_, P(w9), P(bc), 0, P(y), P(stats), lib.stream()), "dwconv")
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    assert_close(got, yref.detach(), "dwconv")
+    gq = got.reshape(B, C_ // 16, 16, H * W)
+    assert_close(stats.cpu(), torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1), "dwconv stats", rel=1e-3, elem=2e-3)
+    dyd = to_pm(dy)
+    dx = torch.zeros_like(y)
+    ok(lb.crd_dwconv3x3(P(dyd), B, H, W, C_, P(w9), None, 1, P(dx), None, lib.stream()), "dwconv dgrad")
+    assert_close(dx.float().cpu().permute(0, 3, 1, 2), xr.grad, "dwconv dx")
+    dw9, db = torch.zeros(9, C_, device="cuda"), torch.zeros(C_, device="cuda")
+    ok(lb.crd_dwconv3x3_wgrad(P(xd), P(dyd), B, H, W, C_, P(dw9), P(db), lib.stream()), "dwconv wgrad")
+    assert_close(dw9.cpu().t().reshape(C_, 1, 3, 3), w.grad, "dwconv dw", rel=2e-3, elem=4e-3)
+    assert_close(db.cpu(), b.grad, "dwconv db", rel=2e-3, elem=4e-3)
+
+
+@pytest.mark.parametrize("N,M,heads,d", [(200, 104, 1, 64), (130, 104, 2, 64), (70, 35, 4, 40), (104, 104, 8, 32)])
+def test_attention_scores_and_backward(N, M, heads, d):
+    lib, lb = L()
+    g = torch.Generator().manual_seed(4)
+    B, C_ = 2, heads * d
+    scale = d ** -0.5
+    q = bf(torch.randn(B, N, C_, generator=g))
+    k = bf(torch.randn(B, M, C_, generator=g))
+    qh = q.reshape(B, N, heads, d).permute(0, 2, 1, 3)
+    kh = k.reshape(B, M, heads, d).permute(0, 2, 3, 1)
+    att = bf(bf(qh @ kh) * scale)                       # [B,h,N,M]
+    smax, imax = att.max(-1)
+    S_ref = smax.sum(1)                                 # [B,N]
+    qd, kd = q.to(torch.bfloat16).cuda(), k.to(torch.bfloat16).cuda()
+    S = torch.zeros(B, N, device="cuda")
+    idx = torch.zeros(B, N, heads, dtype=torch.int16, device="cuda")
+    ok(lb.crd_attn_scores(P(qd), P(kd), B, N, M, heads, d, scale, P(S), P(idx), lib.stream()), "attn_scores")
+    assert_close(S.cpu(), S_ref, "S", rel=2e-3, elem=1e-2)
+    # argmax may differ only where two scores tie after bf16 rounding: check the chosen score is the max
+    chosen = torch.gather(att, 3, idx.cpu().long().permute(0, 2, 1).unsqueeze(-1)).squeeze(-1)
+    assert float((chosen - smax).abs().max()) <= 1e-2 * float(smax.abs().max())
+    # backward of the score path
+    dS = torch.randn(B, N, generator=g)
+    dq = torch.zeros(B, N, C_, dtype=torch.bfloat16, device="cuda")
+    dk = torch.zeros(B, M, C_, device="cuda")
+    dSc = dS.cuda()
+    ok(lb.crd_attn_scores_bwd(P(qd), P(kd), P(dSc), P(idx), B, N, M, heads, d, scale, P(dq), P(dk), lib.stream()),
+       "attn_scores_bwd")
+    ii = idx.cpu().long()
+    dq_ref = torch.zeros(B, N, heads, d)
+    dk_ref = torch.zeros(B, M, heads, d)
+    k4, q4 = k.reshape(B, M, heads, d), q.reshape(B, N, heads, d)
+    for b in range(B):
+        for h in range(heads):
+            dq_ref[b, :, h] = scale * dS[b].unsqueeze(1) * k4[b, ii[b, :, h], h]
+            dk_ref[b, :, h].index_add_(0, ii[b, :, h], scale * dS[b].unsqueeze(1) * q4[b, :, h])
+    assert_close(dq.float().cpu(), dq_ref.reshape(B, N, C_), "dq")
+    assert_close(dk.cpu(), dk_ref.reshape(B, M, C_), "dk", rel=1e-4, elem=1e-4)
+
+
+def test_attention_output_path():
+    lib, lb = L()
+    g = torch.Generator().manual_seed(6)
+    B, N, C_ = 2, 150, 160
+    x = torch.randn(B, N, C_, generator=g)
+    u, S, bp = torch.randn(B, C_, generator=g), torch.randn(B, N, generator=g), torch.randn(C_, generator=g)
+    dp = torch.tensor([1.0 / 0.9, 0.0])
+    x1 = torch.zeros(B, N, C_, device="cuda")
+    xc, uc, Sc, bpc, dpc = x.cuda(), u.cuda(), S.cuda(), bp.cuda(), dp.cuda()
+    ok(lb.crd_attn_out_residual(P(xc), P(uc), P(Sc), P(bpc), P(dpc), B, N, C_, P(x1), lib.stream()), "attn_out_residual")
+    ref = x + dp.view(B, 1, 1) * bf(u.unsqueeze(1) * S.unsqueeze(2) + bp)
+    assert_close(x1.cpu(), ref, "x1", rel=1e-5, elem=1e-5)
+    dx1 = torch.randn(B, N, C_, generator=g)
+    t, dbp, dS = torch.zeros(B, C_, device="cuda"), torch.zeros(C_, device="cuda"), torch.zeros(B, N, device="cuda")
+    dx1c = dx1.cuda()
+    ok(lb.crd_attn_out_bwd(P(dx1c), P(uc), P(Sc), P(dpc), B, N, C_, P(t), P(dbp), P(dS), lib.stream()), "attn_out_bwd")
+    dy = dp.view(B, 1, 1) * dx1
+    assert_close(t.cpu(), (dy * S.unsqueeze(2)).sum(1), "t", rel=1e-4, elem=1e-4)
+    assert_close(dbp.cpu(), dy.sum((0, 1)), "dbp", rel=1e-4, elem=1e-4)
+    assert_close(dS.cpu(), (dy * u.unsqueeze(1)).sum(2), "dS", rel=1e-4, elem=1e-4)
+    # xbar
+    gamma, beta = 1 + 0.1 * torch.randn(C_, generator=g), 0.1 * torch.randn(C_, generator=g)
+    xd = x.cuda()
+    stats, chan = torch.zeros(B, C_ // 16, 2, device="cuda"), torch.zeros(B, C_, 2, device="cuda")
+    ok(lb.crd_gn_stats(P(xd), 1, C_, 0, B, N, C_, P(stats), P(chan), lib.stream()), "gn_stats")
+    xbar = torch.zeros(B, C_, dtype=torch.bfloat16, device="cuda")
+    gac, bec = gamma.cuda(), beta.cuda()
+    ok(lb.crd_attn_xbar(P(chan), P(stats), P(gac), P(bec), B, N, C_, P(xbar), lib.stream()), "xbar")
+    xn = F.group_norm(x.permute(0, 2, 1), C_ // 16, gamma, beta, 1e-5)
+    assert_close(xbar.float().cpu(), xn.mean(2), "xbar", rel=4e-3, elem=1e-2)
+
+
+@pytest.mark.parametrize("H,W,C_", [(5, 7, 16), (8, 13, 136), (3, 4, 8), (16, 26, 128)])
+def test_bicubic(H, W, C_):
+    lib, lb = L()
+    g = torch.Generator().manual_seed(8)
+    B = 2
+    x = bf(torch.randn(B, C_, H, W, generator=g))
+    xr = x.clone().requires_grad_(True)
+    yref = F.interpolate(xr, scale_factor=2, mode="bicubic")
+    dy = bf(torch.randn(B, C_, 2 * H, 2 * W, generator=g))
+    yref.backward(dy)
+    xd = to_pm(x, ld=C_ + 8, coff=8)
+    y = torch.zeros(B, 2 * H, 2 * W, C_ + 16, dtype=torch.bfloat16, device="cuda")
+    ok(lb.crd_bicubic2x(P(xd), C_ + 8, 8, B, H, W, C_, P(y), C_ + 16, 0, lib.stream()), "bicubic")
+    assert_close(y[..., :C_].float().cpu().permute(0, 3, 1, 2), yref.detach(), "bicubic", rel=3e-3, elem=8e-3)
+    dyd = to_pm(dy)
+    dx = torch.zeros(B, H, W, C_, dtype=torch.bfloat16, device="cuda")
+    ok(lb.crd_bicubic2x_bwd(P(dyd), C_, 0, B, H, W, C_, P(dx), C_, 0, 0, lib.stream()), "bicubic_bwd")
+    assert_close(dx.float().cpu().permute(0, 3, 1, 2), xr.grad, "bicubic bwd", rel=3e-3, elem=8e-3)
+
+
+def test_layout_and_small_ops():
+    lib, lb = L()
+    g = torch.Generator().manual_seed(9)
+    B, C_, H, W = 2, 7, 6, 10
+    x = torch.randn(B, C_, H, W, generator=g)
+    y = torch.full((B, H, W, 16), 7.0, dtype=torch.bfloat16, device="cuda")
+    xc = x.cuda()
+    ok(lb.crd_nchw_to_pm(P(xc), B, C_, H, W, P(y), 16, 8, 8, lib.stream()), "nchw_to_pm")
+    assert torch.equal(y[..., 8:15].float().cpu(), bf(x).permute(0, 2, 3, 1))
+    assert float(y[..., 15].float().abs().max()) == 0 and float((y[..., :8].float() - 7).abs().max()) == 0
+    # pm -> nchw (fp32 logits with ld 24)
+    lg = torch.randn(B, H * W, 24, generator=g)
+    out = torch.zeros(B, 21, H, W, device="cuda")
+    lgc = lg.cuda()
+    ok(lb.crd_pm_to_nchw(P(lgc), 1, 24, 0, B, 21, H, W, P(out), lib.stream()), "pm_to_nchw")
+    assert torch.equal(out.cpu(), lg[..., :21].reshape(B, H, W, 21).permute(0, 3, 1, 2))
+    # seg argmax
+    sm = torch.zeros(B, H * W, 8, dtype=torch.bfloat16, device="cuda")
+    ok(lb.crd_seg_argmax(P(lgc), 24, B, H * W, 21, 21, P(sm), 8, 3, lib.stream()), "seg_argmax")
+    ref = (lg[..., :21].argmax(-1) / 21)
+    assert torch.equal(sm[..., 3].float().cpu(), bf(ref))
+    # slice copy + accumulate
+    a = bf(torch.randn(30, 24, generator=g))
+    dst = torch.zeros(30, 40, dtype=torch.bfloat16, device="cuda")
+    ad = a.to(torch.bfloat16).cuda()
+    ok(lb.crd_slice_copy(P(ad), 24, 8, P(dst), 40, 16, 30, 16, 0, lib.stream()), "slice_copy")
+    ok(lb.crd_slice_copy(P(ad), 24, 8, P(dst), 40, 16, 30, 16, 1, lib.stream()), "slice_copy acc")
+    assert torch.equal(dst[:, 16:32].float().cpu(), bf(2 * a[:, 8:24]))
+    # f32 -> bf16 rows with per-sample scale
+    src = torch.randn(2 * 15, 1, generator=g)
+    sc = torch.tensor([0.5, 2.0])
+    d2 = torch.zeros(30, 8, dtype=torch.bfloat16, device="cuda")
+    srcc, scc = src.cuda(), sc.cuda()
+    ok(lb.crd_f32_to_bf16_rows(P(srcc), 1, P(d2), 8, 0, 30, 1, P(scc), 15, lib.stream()), "f32_to_bf16_rows")
+    assert torch.equal(d2[:, 0].float().cpu(), bf(src[:, 0] * sc.repeat_interleave(15)))
+    # sigmoid backward
+    av = bf(torch.rand(64, generator=g))
+    dv = bf(torch.randn(64, generator=g))
+    dd = dv.to(torch.bfloat16).cuda()
+    avc = av.to(torch.bfloat16).cuda()
+    ok(lb.crd_sigmoid_bwd(P(avc), P(dd), 64, lib.stream()), "sigmoid_bwd")
+    assert_close(dd.float().cpu(), dv * av * (1 - av), "sigmoid bwd")
+
+
+def test_losses():
+    from camradepth_amd import synth
+    lib, lb = L()
+    g = torch.Generator().manual_seed(10)
+    b = synth.make_batch(2, 24, 40, seed=3)
+    pred = (torch.rand(2, 1, 24, 40, generator=g) * 3.4 - 1.2).requires_grad_(True)
+    tgt = b["gt_full"]
+    m = tgt > 0
+    l1 = F.smooth_l1_loss(pred[m], tgt[m])
+    mse = ((tgt - pred)[m] ** 2).mean()
+    l1.backward()
+    acc = torch.zeros(4, device="cuda")
+    pd, td = pred.detach().cuda(), tgt.cuda()
+    ok(lb.crd_masked_l1_fwd(P(pd), P(td), pd.numel(), P(acc), lib.stream()), "l1 fwd")
+    a = acc.cpu()
+    np.testing.assert_allclose(float(a[0] / a[1]), float(l1), rtol=1e-5)
+    np.testing.assert_allclose(float(a[2] / a[1]), float(mse), rtol=1e-5)
+    assert int(a[1]) == int(m.sum())
+    dpred = torch.zeros_like(pd)
+    gout = torch.tensor([2.0], device="cuda")
+    ok(lb.crd_masked_l1_bwd(P(pd), P(td), pd.numel(), P(acc), P(gout), 0.5, P(dpred), lib.stream()), "l1 bwd")
+    assert_close(dpred.cpu(), pred.grad, "dpred", rel=1e-5, elem=1e-5)
+    # focal CE
+    logits = (torch.randn(2, 21, 24, 40, generator=g) * 2).requires_grad_(True)
+    ce = F.cross_entropy(logits, b["seg"], ignore_index=255)
+    focal = (1 - torch.exp(-ce)) ** 2 * ce
+    focal.backward()
+    acc2 = torch.zeros(4, device="cuda")
+    ld, lab = logits.detach().cuda(), b["seg"].cuda()
+    ok(lb.crd_ce_fwd(P(ld), P(lab), 2, 21, 24 * 40, P(acc2), lib.stream()), "ce fwd")
+    a2 = acc2.cpu()
+    np.testing.assert_allclose(float(a2[0] / a2[1]), float(ce), rtol=1e-5)
+    dl = torch.zeros_like(ld)
+    ok(lb.crd_ce_focal_bwd(P(ld), P(lab), 2, 21, 24 * 40, P(acc2), None, 1.0, P(dl), lib.stream()), "ce bwd")
+    assert_close(dl.cpu(), logits.grad, "dlogits", rel=1e-4, elem=1e-4)
+
+
+def test_diffgradnorm_matches_golden_trajectory():
+    """40 steps of the reference optimizer (tests/golden/diffgradnorm_40steps.npz), flat-buffer kernel."""
+    from tests.util import load_npz
+    lib, lb = L()
+    gd = load_npz("diffgradnorm_40steps.npz")
+    ps = [torch.from_numpy(gd[f"p{j}_init"]).reshape(-1) for j in range(3)]
+    # add a large tensor that spans several 4096-element chunks, checked against the CPU oracle
+    from oracle import optim as ooptim
+    g = torch.Generator().manual_seed(0)
+    big = torch.randn(10000, generator=g)
+    big_ref = big.clone()
+    big_state = ooptim.new_state(big_ref)
+    sizes = [p.numel() for p in ps] + [big.numel()]
+    off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    flat = torch.cat(ps + [big]).cuda()
+    n = flat.numel()
+    m, v, pg = (torch.zeros(n, device="cuda") for _ in range(3))
+    egn, nsq, fac = (torch.zeros(4, device="cuda") for _ in range(3))
+    b2s, b2c = [], []
+    for t, sz in enumerate(sizes):
+        for c in range((sz + 4095) // 4096):
+            b2s.append(t)
+            b2c.append(c)
+    seg = torch.from_numpy(off).cuda()
+    b2s_d, b2c_d = torch.tensor(b2s, dtype=torch.int32).cuda(), torch.tensor(b2c, dtype=torch.int32).cuda()
+    for it in range(40):
+        lr, b1, b2 = (float(z) for z in gd["hp"][it])
+        gb = torch.randn(10000, generator=g) * (0.02 if 10 <= it < 14 else 1.0)
+        grads = torch.cat([torch.from_numpy(gd[f"p{j}_grads"][it]).reshape(-1) for j in range(3)] + [gb]).cuda()
+        ok(lb.crd_diffgradnorm_step(P(flat), P(grads), P(m), P(v), P(pg), P(egn), P(nsq), P(fac), P(seg), P(b2s_d), P(b2c_d),
+                                    4, len(b2s), None, lr, b1, b2, 1e-8, 0.0, it + 1, lib.stream()), "dgn")
+        ooptim.step_tensor(big_ref, gb, big_state, lr, b1, b2)
+        fc = flat.cpu()
+        for j in range(3):
+            np.testing.assert_allclose(fc[off[j]:off[j + 1]].numpy(), gd[f"p{j}_traj"][it].reshape(-1), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(fc[off[3]:off[4]].numpy(), big_ref.numpy(), rtol=2e-5, atol=1e-7)
+        np.testing.assert_allclose(egn.cpu().numpy()[:3], gd["exp_grad_norm"][it], rtol=1e-5)
+    assert float(nsq.abs().max()) == 0.0
+
+
+def test_weight_pack_and_unpack():
+    lib, lb = L()
+    g = torch.Generator().manual_seed(12)
+    Co, Ci, k, Cp = 21, 129, 3, 136
+    w = torch.randn(Co, Ci, k, k, generator=g)
+    cmap = torch.full((Cp,), -1, dtype=torch.int32)
+    cmap[:Ci] = torch.arange(Ci, dtype=torch.int32)
+    cmap[130] = 5  # arbitrary remap of a pad slot
+    Cop = 24
+    wd = w.cuda()
+    fwd = torch.zeros(Co, 9, Cp, dtype=torch.bfloat16, device="cuda")
+    dg = torch.zeros(Cp, 9, Cop, dtype=torch.bfloat16, device="cuda")
+    sc = torch.zeros(9, Cp, Cop, dtype=torch.bfloat16, device="cuda")
+    cm = cmap.cuda()
+    e = lib.PackEntry()
+    e.src, e.dst_fwd, e.dst_dgrad, e.dst_scatter, e.cmap = P(wd), P(fwd), P(dg), P(sc), P(cm)
+    e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad = Co, Ci, 9, Cp, Cop
+    tab = torch.frombuffer(bytearray(bytes(e)), dtype=torch.uint8).cuda()
+    ok(lb.crd_weight_pack(P(tab), 1, Cp * 9 * Cop, lib.stream()), "weight_pack")
+    ref = torch.zeros(Co, 9, Cp)
+    wr = w.reshape(Co, Ci, 9)
+    for cp in range(Cp):
+        if cmap[cp] >= 0:
+            ref[:, :, cp] = wr[:, cmap[cp], :]
+    assert torch.equal(fwd.float().cpu(), bf(ref))
+    refd = torch.zeros(Cp, 9, Cop)
+    refd[:, :, :Co] = ref.permute(2, 1, 0)
+    assert torch.equal(dg.float().cpu(), bf(refd))
+    assert torch.equal(sc.float().cpu(), bf(refd.permute(1, 0, 2)))
+    # unpack: identity map back to the reference layout
+    cmap2 = torch.full((Cp,), -1, dtype=torch.int32)
+    cmap2[:Ci] = torch.arange(Ci, dtype=torch.int32)
+    src = torch.randn(Co, 9, Cp, generator=g)
+    dst = torch.ones(Co, Ci, 9)
+    u = lib.UnpackEntry()
+    sd, dd, c2 = src.cuda(), dst.cuda(), cmap2.cuda()
+    u.src, u.dst, u.cmap, u.Cout, u.Cin_ref, u.taps, u.Cin_pad = P(sd), P(dd), P(c2), Co, Ci, 9, Cp
+    tab2 = torch.frombuffer(bytearray(bytes(u)), dtype=torch.uint8).cuda()
+    ok(lb.crd_wgrad_unpack(P(tab2), 1, Co * 9 * Cp, 1, lib.stream()), "wgrad_unpack")
+    assert_close(dd.cpu(), 1 + src[:, :, :Ci].permute(0, 2, 1), "unpack", rel=1e-6, elem=1e-6)

@@ -163,8 +163,12 @@ __global__ __launch_bounds__(TPB) void k_pm_to_nchw(const void* x, int x_f32, in
   }
 }
 
-__global__ __launch_bounds__(TPB) void k_seg_argmax(const float* logits, int ld, long long rows, int C, float inv_classes,
-                                                    bf16_t* y, int y_ld) {
+__global__ __launch_bounds__(TPB) void k_scale_f32(const float* src, float* dst, long long n, float scale) {
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) dst[i] = scale * src[i];
+}
+
+__global__ __launch_bounds__(TPB) void k_seg_argmax(const float* logits, int ld, long long rows, int C, int num_classes,
+                                                    void* y, int y_f32, int y_ld) {
   for (long long r = (long long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long long)gridDim.x * TPB) {
     const float* p = logits + r * ld;
     float best = p[0];
@@ -173,7 +177,9 @@ __global__ __launch_bounds__(TPB) void k_seg_argmax(const float* logits, int ld,
       float v = p[c];
       if (v > best) { best = v; bi = c; }
     }
-    y[r * y_ld] = f2bf((float)bi * inv_classes);
+    const float v = (float)bi / (float)num_classes;
+    if (y_f32) reinterpret_cast<float*>(y)[r * y_ld] = v;
+    else reinterpret_cast<bf16_t*>(y)[r * y_ld] = f2bf(v);
   }
 }
 
@@ -198,15 +204,39 @@ __global__ __launch_bounds__(TPB) void k_slice_copy(const bf16_t* src, int s_ld,
   }
 }
 
-// dst[r][c] = bf16(scale[r / rows_per_sample] * src[r*s_ld + c]) for c < C  (scalar path: any C / alignment)
+// dst[r][c] = bf16(scale[r / rows_per_sample] * src[r*s_ld + c] + add[r*add_ld + c]) for c < C
 __global__ __launch_bounds__(TPB) void k_f32_to_bf16_rows(const float* src, int s_ld, bf16_t* dst, int d_ld, long long rows,
-                                                          int C, const float* scale, long long rows_per_sample) {
+                                                          int C, const float* scale, long long rows_per_sample,
+                                                          const bf16_t* add, int add_ld, int vec) {
+  if (vec) {  // C % 8 == 0 and all strides / offsets 8-aligned
+    const int CG = C >> 3;
+    const long long total = rows * CG;
+    for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+      const int cg = (int)(i % CG);
+      const long long r = i / CG;
+      const float s = scale ? scale[r / rows_per_sample] : 1.f;
+      float v[8];
+      load8(src, r * s_ld + cg * 8, 1, v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= s;
+      if (add) {
+        float a[8];
+        load8(add, r * add_ld + cg * 8, 0, a);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += a[j];
+      }
+      store8_bf16(dst, r * d_ld + cg * 8, v);
+    }
+    return;
+  }
   const long long total = rows * C;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
     const int c = (int)(i % C);
     const long long r = i / C;
     float s = scale ? scale[r / rows_per_sample] : 1.f;
-    dst[r * d_ld + c] = f2bf(s * src[r * s_ld + c]);
+    float v = s * src[r * s_ld + c];
+    if (add) v += bf2f(add[r * add_ld + c]);
+    dst[r * d_ld + c] = f2bf(v);
   }
 }
 
@@ -276,12 +306,20 @@ extern "C" int crd_pm_to_nchw(const void* x, int32_t x_f32, int32_t x_ld, int32_
 }
 
 extern "C" int crd_seg_argmax(const void* logits, int32_t ld, int32_t B, int32_t P, int32_t C, int32_t num_classes, void* y,
-                              int32_t y_ld, int32_t y_coff, crd_stream_t stream) {
+                              int32_t y_f32, int32_t y_ld, int32_t y_coff, crd_stream_t stream) {
   CRD_CHECK_ARG(logits && y && C >= 1 && num_classes >= 1, "crd_seg_argmax: bad argument");
   const long long rows = (long long)B * P;
+  void* yp = y_f32 ? (void*)(reinterpret_cast<float*>(y) + y_coff) : (void*)(reinterpret_cast<bf16_t*>(y) + y_coff);
   hipLaunchKernelGGL(k_seg_argmax, dim3(blocks_for(rows)), dim3(TPB), 0, as_stream(stream), reinterpret_cast<const float*>(logits),
-                     ld, rows, C, 1.f / (float)num_classes, reinterpret_cast<bf16_t*>(y) + y_coff, y_ld);
+                     ld, rows, C, num_classes, yp, y_f32, y_ld);
   CRD_LAUNCH_CHECK("crd_seg_argmax");
+  return CRD_OK;
+}
+
+extern "C" int crd_scale_f32(const float* src, float* dst, int64_t n, float scale, crd_stream_t stream) {
+  CRD_CHECK_ARG(src && dst && n > 0, "crd_scale_f32: bad argument");
+  hipLaunchKernelGGL(k_scale_f32, dim3(blocks_for(n)), dim3(TPB), 0, as_stream(stream), src, dst, (long long)n, scale);
+  CRD_LAUNCH_CHECK("crd_scale_f32");
   return CRD_OK;
 }
 
@@ -297,10 +335,14 @@ extern "C" int crd_slice_copy(const void* src, int32_t s_ld, int32_t s_coff, voi
 }
 
 extern "C" int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, int32_t d_ld, int32_t d_coff, int64_t rows,
-                                    int32_t C, const float* scale, int64_t rows_per_sample, crd_stream_t stream) {
+                                    int32_t C, const float* scale, int64_t rows_per_sample, const void* add, int32_t add_ld,
+                                    int32_t add_coff, crd_stream_t stream) {
   CRD_CHECK_ARG(src && dst && rows_per_sample > 0, "crd_f32_to_bf16_rows: bad argument");
-  hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3(blocks_for(rows * C)), dim3(TPB), 0, as_stream(stream), src, s_ld,
-                     reinterpret_cast<bf16_t*>(dst) + d_coff, d_ld, (long long)rows, C, scale, (long long)rows_per_sample);
+  const int vec = (C % 8 == 0) && (s_ld % 8 == 0) && (d_ld % 8 == 0) && (d_coff % 8 == 0) &&
+                  (!add || (add_ld % 8 == 0 && add_coff % 8 == 0)) && ((reinterpret_cast<uintptr_t>(src) & 31) == 0);
+  hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3(blocks_for(vec ? rows * (C / 8) : rows * C)), dim3(TPB), 0, as_stream(stream), src,
+                     s_ld, reinterpret_cast<bf16_t*>(dst) + d_coff, d_ld, (long long)rows, C, scale, (long long)rows_per_sample,
+                     add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr, add_ld, vec);
   CRD_LAUNCH_CHECK("crd_f32_to_bf16_rows");
   return CRD_OK;
 }

@@ -104,9 +104,9 @@ constexpr int OPT_CHUNK = 4096;  // elements per workgroup
 __global__ __launch_bounds__(TPB) void k_dgn_norm(const float* p, const float* g, const long long* seg_off, const int* blk2seg,
                                                   const int* blk2chunk, float wd, float* norm_sq) {
   const int t = blk2seg[blockIdx.x];
-  const long long beg = seg_off[t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
+  const long long beg = seg_off[2 * t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
   long long end = beg + OPT_CHUNK;
-  if (end > seg_off[t + 1]) end = seg_off[t + 1];
+  if (end > seg_off[2 * t + 1]) end = seg_off[2 * t + 1];
   float s = 0.f;
   for (long long i = beg + threadIdx.x; i < end; i += TPB) {
     float gv = g[i];
@@ -138,9 +138,9 @@ __global__ __launch_bounds__(TPB) void k_dgn_update(float* p, const float* g, fl
                                                     float step_size) {
   const int t = blk2seg[blockIdx.x];
   if (active && !active[t]) return;
-  const long long beg = seg_off[t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
+  const long long beg = seg_off[2 * t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
   long long end = beg + OPT_CHUNK;
-  if (end > seg_off[t + 1]) end = seg_off[t + 1];
+  if (end > seg_off[2 * t + 1]) end = seg_off[2 * t + 1];
   const float f = factor[t];
   for (long long i = beg + threadIdx.x; i < end; i += TPB) {
     float gv = g[i];
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(TPB) void k_weight_pack(const crd_pack_entry* tab) 
       const int tap = (int)(r % e.taps), co = (int)(r / e.taps);
       const int cr = e.cmap ? e.cmap[ci] : (ci < e.Cin_ref ? ci : -1);
       float v = cr >= 0 ? e.src[((long long)co * e.Cin_ref + cr) * e.taps + tap] : 0.f;
-      reinterpret_cast<bf16_t*>(e.dst_fwd)[i] = f2bf(v);
+      if (e.dst_f32) reinterpret_cast<float*>(e.dst_fwd)[i] = v;
+      else reinterpret_cast<bf16_t*>(e.dst_fwd)[i] = f2bf(v);
     }
     if ((e.dst_dgrad || e.dst_scatter) && i < n_tr) {
       // i enumerates [ci][tap][co_pad] (dgrad order)
@@ -197,6 +198,28 @@ __global__ __launch_bounds__(TPB) void k_wgrad_unpack(const crd_unpack_entry* ta
     *d = accumulate ? *d + e.src[i] : e.src[i];
   }
 }
+
+// out[r][c] = u(r,c) < keep[r] ? 1/keep[r] : 0 with a counter-based hash RNG; *counter advances once per launch,
+// so a captured graph draws fresh masks on every replay.
+__device__ __forceinline__ unsigned long long splitmix64(unsigned long long x) {
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return x ^ (x >> 31);
+}
+__global__ __launch_bounds__(TPB) void k_dropout_masks(float* out, const float* keep, int rows, int cols, unsigned long long seed,
+                                                       unsigned long long* counter) {
+  const unsigned long long epoch = *counter;
+  const long long total = (long long)rows * cols;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int r = (int)(i / cols);
+    const float kp = keep[r];
+    const unsigned long long h = splitmix64(splitmix64(seed ^ (epoch * 0xD1342543DE82EF95ull)) + (unsigned long long)i);
+    const float u = (float)(h >> 40) * (1.0f / 16777216.0f);
+    out[i] = u < kp ? 1.0f / kp : 0.0f;
+  }
+}
+__global__ void k_counter_inc(unsigned long long* counter) { *counter += 1; }
 
 inline int blocks_for(long long total, int cap = 2048) {
   long long n = (total + TPB - 1) / TPB;
@@ -260,6 +283,16 @@ extern "C" int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, f
   hipLaunchKernelGGL(k_dgn_update, dim3(n_blocks), dim3(TPB), 0, st, p, g, exp_avg, exp_avg_sq, prev_grad, factor, so, blk2seg,
                      blk2chunk, active, beta1, beta2, eps, weight_decay, step_size);
   CRD_LAUNCH_CHECK("crd_diffgradnorm_step");
+  return CRD_OK;
+}
+
+extern "C" int crd_dropout_masks(float* out, const float* keep, int32_t rows, int32_t cols, uint64_t seed, uint64_t* counter,
+                                 crd_stream_t stream) {
+  CRD_CHECK_ARG(out && keep && counter && rows > 0 && cols > 0, "crd_dropout_masks: bad argument");
+  hipLaunchKernelGGL(k_dropout_masks, dim3(blocks_for((long long)rows * cols, 64)), dim3(TPB), 0, as_stream(stream), out, keep, rows,
+                     cols, (unsigned long long)seed, reinterpret_cast<unsigned long long*>(counter));
+  hipLaunchKernelGGL(k_counter_inc, dim3(1), dim3(1), 0, as_stream(stream), reinterpret_cast<unsigned long long*>(counter));
+  CRD_LAUNCH_CHECK("crd_dropout_masks");
   return CRD_OK;
 }
 

@@ -1,0 +1,761 @@
+"""Execution plan of the CamRaDepth hot path on one MI355X.
+
+A Plan is built once per (batch, height, width, train/eval): every activation, gradient and
+scratch buffer is allocated up front (288 GB of HBM make recomputation pointless), every kernel
+call of the forward and backward pass is recorded as (C-ABI function, ctypes arguments), and
+running a pass is a flat loop over those records on the current HIP stream -- which is also what
+makes the whole step capturable into a HIP graph (no allocation, no host sync inside).
+
+PyTorch is used for memory (torch.empty / zero_) and streams only; all arithmetic is in
+libcamradepth_hip.so.  Forward structure follows the reference: CamRaDepth.forward
+(src/models/CamRaDepth.py:99-176), SimplifiedTransformer.forward_features
+(src/models/simplified_attention.py:265-306), Block/Attention_MaxPool/Mlp (:34-43,90-109,141-145),
+Decoder/ShortResBlock/ConvLayer/Depth_Activation (src/utils/utils.py:127-135,223-228,249-257,285-289).
+The backward pass is hand-derived.
+"""
+import ctypes as C
+import os
+
+import torch
+
+from . import lib as L
+from .config import MID_CHANNELS, UNSUP_CLASSES, ModelConfig
+from .params import short_res_block_plan
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def rup(x, m=8):
+    return (x + m - 1) // m * m
+
+
+class PM:
+    """Pixel-major view: element (b, p, c) at t[b, p, coff + c]; t has shape [B, H*W, ld]."""
+    __slots__ = ("t", "ld", "coff", "C", "H", "W", "f32")
+
+    def __init__(self, t, C_, H, W, coff=0):
+        self.t, self.ld, self.coff, self.C, self.H, self.W = t, t.shape[-1], coff, C_, H, W
+        self.f32 = 1 if t.dtype == F32 else 0
+
+    def sl(self, c0, c1):
+        return PM(self.t, c1 - c0, self.H, self.W, self.coff + c0)
+
+    @property
+    def P(self):
+        return self.H * self.W
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr()
+
+
+class Op:
+    __slots__ = ("fn", "args", "name", "region", "acc_slot", "zero")
+
+    def __init__(self, fn, args, name, region=None, acc_slot=None, zero=None):
+        self.fn, self.args, self.name, self.region, self.acc_slot, self.zero = fn, args, name, region, acc_slot, zero
+
+
+class ConvW:
+    """A dense convolution's parameters and packed forms."""
+
+    def __init__(self, name, cout, cin_ref, k, cmap, bias, need_dgrad, scatter=False, dgrad_rows=None):
+        self.name, self.cout, self.cin_ref, self.k, self.taps = name, cout, cin_ref, k, k * k
+        self.cmap = cmap                      # list[int] internal channel -> reference channel (or -1), len = cin_pad
+        self.cin_pad = len(cmap) if cmap is not None else rup(cin_ref)
+        self.cout_pad = rup(cout)
+        self.bias, self.need_dgrad, self.scatter = bias, need_dgrad, scatter
+        self.identity = (cmap is None and self.cin_pad == cin_ref and self.taps == 1)
+        self.w_fwd = self.w_dgrad = self.w_scatter = None   # bf16 tensors
+        self.dw = None                                        # fp32 [cout][taps][cin_pad] (scratch or direct grad view)
+        self.cmap_dev = None
+
+
+class Plan:
+    def __init__(self, model, B, H, W, training):
+        cfg = model.cfg
+        assert H % 32 == 0 and W % 32 == 0, "H and W must be multiples of 32 (SURVEY.md section 8 note on 900x1600)"
+        self.model, self.cfg, self.B, self.H, self.W, self.training = model, cfg, B, H, W, training
+        self.dev = model.flat.device
+        self.lib = L.load()
+        self.fwd, self.bwd_groups = [], []
+        self.zero_fwd, self.zero_bwd = [], []       # (numel) requests into the two zero arenas
+        self._zf_views, self._zb_views = [], []
+        self.convs = []
+        self.keep = []                              # keep ctypes structs / tensors alive
+        self.dw_entries, self.dw_grads = [], []
+        self.buffers = []
+        self._build()
+
+    # ------------------------------------------------------------------ allocation helpers
+    def new(self, shape, dtype=BF16):
+        t = torch.zeros(shape, dtype=dtype, device=self.dev)
+        self.buffers.append(t)                     # ops hold raw pointers only: the plan owns every buffer
+        if os.environ.get("CRD_DEBUG_NAN"):
+            import traceback
+            fr = [f"{f.name}:{f.lineno}" for f in traceback.extract_stack()[-5:-1]]
+            self.keep.append(("buf", len(self.keep), tuple(shape), str(dtype), fr, t))
+        return t
+
+    def act(self, C_, H, W, dtype=BF16, ld=None):
+        return PM(self.new((self.B, H * W, ld or C_), dtype), C_, H, W)
+
+    def zf(self, *shape):
+        """fp32 scratch that must be zero at the start of every forward."""
+        v = _Lazy(shape)
+        self._zf_views.append(v)
+        return v
+
+    def zb(self, *shape):
+        """fp32 scratch that must be zero at the start of every backward."""
+        v = _Lazy(shape)
+        self._zb_views.append(v)
+        return v
+
+    def _materialise(self, views):
+        n = sum(v.numel for v in views)
+        arena = torch.zeros(max(n, 1), dtype=F32, device=self.dev)
+        off = 0
+        for v in views:
+            v.t = arena[off:off + v.numel].view(v.shape)
+            off += v.numel
+        return arena
+
+    # ------------------------------------------------------------------ op emitters
+    def _emit(self, lst, fn_name, args, region=None, acc_slot=None):
+        op = Op(getattr(self.lib, fn_name), list(args), fn_name, region, acc_slot)
+        lst.append(op)
+        return op
+
+    def conv_desc(self, x, w_t, cout, k, stride, pad, OH, OW, y, cin=None, gather=0, out_mode=0, patch_k=0, patch_c=0,
+                  bias=None, bias_bstride=0, act=0, res=None, res_scale=None, stats=None, accumulate=0):
+        """Specification of one crd_conv_igemm call; turned into a ctypes ConvDesc in _finalise."""
+        return dict(x=x, w=w_t, cout=cout, k=k, stride=stride, pad=pad, OH=OH, OW=OW, y=y, cin=cin if cin is not None else x.C,
+                    gather=gather, out_mode=out_mode, patch_k=patch_k, patch_c=patch_c, bias=bias, bias_bstride=bias_bstride,
+                    act=act, res=res, res_scale=res_scale, stats=stats, accumulate=accumulate)
+
+    def conv(self, lst, spec, region=None):
+        op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None)
+        lst.append(op)
+        return op
+
+    def wgrad(self, lst, x, dy, cw, k, stride, pad, OH, OW, dbias=None, cin=None):
+        spec = dict(wg=True, x=x, dy=dy, cw=cw, k=k, stride=stride, pad=pad, OH=OH, OW=OW, dbias=dbias,
+                    cin=cin if cin is not None else x.C)
+        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad"))
+
+    def _make_desc(self, sp):
+        def P(v):
+            if v is None:
+                return None
+            if isinstance(v, PM):
+                return v.t.data_ptr()
+            return v.data_ptr()
+        if sp.get("wg"):
+            x, dy, cw = sp["x"], sp["dy"], sp["cw"]
+            d = L.WgradDesc()
+            d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = P(x), x.ld, x.coff, self.B, x.H, x.W, sp["cin"]
+            d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = P(dy), dy.ld, dy.coff, sp["OH"], sp["OW"], cw.cout
+            d.KH, d.KW, d.stride, d.pad = sp["k"], sp["k"], sp["stride"], sp["pad"]
+            d.dw, d.dbias = P(cw.dw), P(sp["dbias"])
+        else:
+            x, y, w = sp["x"], sp["y"], sp["w"]
+            if isinstance(w, tuple):
+                w = w[1].w_dgrad if w[0] == "dgrad" else w[1].w_scatter
+                assert w is not None, "packed data-gradient weights were not requested for this convolution"
+            elif isinstance(w, ConvW):
+                w = w.w_fwd
+            d = L.ConvDesc()
+            d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = P(x), x.ld, x.coff, self.B, x.H, x.W, sp["cin"]
+            d.w, d.Cout, d.KH, d.KW, d.stride, d.pad = P(w), sp["cout"], sp["k"], sp["k"], sp["stride"], sp["pad"]
+            d.OH, d.OW, d.gather_mode = sp["OH"], sp["OW"], sp["gather"]
+            d.y, d.y_ld, d.y_coff, d.y_f32 = P(y), y.ld, y.coff, y.f32
+            d.out_mode, d.patch_k, d.patch_c = sp["out_mode"], sp["patch_k"], sp["patch_c"]
+            d.bias, d.bias_bstride, d.act = P(sp["bias"]), sp["bias_bstride"], sp["act"]
+            res = sp["res"]
+            d.res, d.res_ld, d.res_scale = P(res), (res.ld if res is not None else 0), P(sp["res_scale"])
+            d.accumulate, d.stats = sp["accumulate"], P(sp["stats"])
+        self.keep.append(d)
+        return C.byref(d)
+
+    # parameter access: fp32 views into the flat parameter / gradient buffers
+    def p(self, name):
+        return self.model.param_view(name)
+
+    def g(self, name):
+        return self.model.grad_view(name)
+
+    def new_conv(self, name, cmap=None, need_dgrad=True, scatter=False):
+        w = self.p(name + ".weight")
+        cout, cin_ref = w.shape[0], w.shape[1]
+        k = w.shape[2] if w.dim() == 4 else 1
+        bias = self.p(name + ".bias") if self.model.has_param(name + ".bias") else None
+        cw = ConvW(name, cout, cin_ref, k, cmap, bias, need_dgrad, scatter)
+        self.convs.append(cw)
+        return cw
+
+    # ------------------------------------------------------------------ building blocks
+    def gn_fwd(self, x, stats, gmul, gname, act, mask, y):
+        self._emit(self.fwd, "crd_gn_apply", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, gmul, self.p(gname + ".weight"),
+                                              self.p(gname + ".bias"), act, mask, y.t, y.f32, y.ld, y.coff])
+
+    def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0):
+        r = self.zb(self.B, x.C, 2)
+        common = [x.t, x.f32, x.ld, x.coff, dy.t, dy.f32, dy.ld, dy.coff, self.B, x.P, x.C, stats, gmul,
+                  self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask]
+        self._emit(grp, "crd_gn_bwd_reduce", common + [r])
+        args = common + [r, self.g(gname + ".weight"), self.g(gname + ".bias"), dx.t, dx.f32, dx.ld, dx.coff, dx_acc]
+        self._emit(grp, "crd_gn_bwd_apply", args, region, len(args) - 1 if region else None)
+
+    def conv_layer(self, name, x, k, out, mask=None, dout=None, dx=None, dx_region=None):
+        """ConvLayer (utils.py:210-228): conv(no bias) -> GN(Cout/16) -> GELU [-> Dropout2d mask].
+        x: input PM (Cin = x.C incl. padding, cmap given by caller through self._cmap), out: PM slice
+        to write; dout: PM slice holding d(out); dx: PM slice receiving d(x)."""
+        cw = self.new_conv(name + ".model.0", cmap=self._cmap, need_dgrad=dx is not None)
+        H, W = x.H, x.W
+        raw = self.act(cw.cout, H, W)
+        stats = self.zf(self.B, cw.cout // 16, 2)
+        self.conv(self.fwd, self.conv_desc(x, cw, cw.cout, k, 1, k // 2, H, W, raw, stats=stats))
+        self.gn_fwd(raw, stats, 1, name + ".model.1", 1, mask, out)
+        if dout is None:
+            return
+        grp = []
+        draw = self.act(cw.cout, H, W)
+        self.gn_bwd(grp, raw, stats, 1, name + ".model.1", 1, mask, dout, draw)
+        self.wgrad(grp, x, draw, cw, k, 1, k // 2, H, W)
+        if dx is not None:
+            self.conv(grp, self.conv_desc(draw, ("dgrad", cw), dx.C, k, 1, k // 2, H, W, dx, gather=1), region=dx_region)
+        self.bwd_groups.append(grp)
+
+    # ------------------------------------------------------------------ the model
+    def _build(self):
+        cfg, B, H, W = self.cfg, self.B, self.H, self.W
+        m = self.model
+        tr = self.training
+        nblk = sum(cfg.depths)
+        seg = cfg.supervised_seg or cfg.unsupervised_seg
+        n_drop = 5 + (2 if seg else 0)
+        # train-mode masks (device, regenerated per forward unless injected)
+        self.dp_masks = self.new((nblk, B), F32) if tr else None
+        self.d2_masks = self.new((n_drop, B, MID_CHANNELS), F32) if tr else None
+        if tr:
+            self.dp_keep = torch.tensor([1.0 - r for r in cfg.drop_path_rates], dtype=F32, device=self.dev)
+            self.d2_keep = torch.full((n_drop * B,), 0.8, dtype=F32, device=self.dev)
+            self.rng_counter = torch.zeros(1, dtype=torch.int64, device=self.dev)
+        self._drop_i = 0
+
+        def dmask():
+            i = self._drop_i
+            self._drop_i += 1
+            return self.d2_masks[i] if tr else None
+
+        Cin = cfg.input_channels
+        # ---- input: NCHW fp32 -> pixel-major bf16 (8 channels) ----
+        self.x_in = torch.zeros((B, Cin, H, W), dtype=F32, device=self.dev)   # static input (graph-safe)
+        X8 = self.act(8, H, W)
+        self._emit(self.fwd, "crd_nchw_to_pm", [self.x_in, B, Cin, H, W, X8.t, X8.ld, 0, 8])
+
+        # ---- encoder ----
+        enc_out_b = []          # bf16 copies of the four stage outputs
+        d_enc_out = []          # fp32 gradients of the four stage outputs
+        src, bi = X8, 0
+        for s in range(4):
+            Cs, heads, ratio, sr = cfg.dims[s], cfg.heads[s], cfg.ff_expansion[s], cfg.reduction_ratio[s]
+            k, stride = (7, 4) if s == 0 else (3, 2)
+            Hs, Ws = src.H // stride, src.W // stride
+            N = Hs * Ws
+            pe = f"dest_encoder.patch_embed{s + 1}"
+            cmap = list(range(Cin)) + [-1] * (8 - Cin) if s == 0 else None
+            cw = self.new_conv(pe + ".proj", cmap=cmap, need_dgrad=s > 0)
+            raw = self.act(Cs, Hs, Ws)
+            st = self.zf(B, Cs // 16, 2)
+            self.conv(self.fwd, self.conv_desc(src, cw, Cs, k, stride, k // 2, Hs, Ws, raw, bias=cw.bias, stats=st))
+            X = self.act(Cs, Hs, Ws, F32)
+            self.gn_fwd(raw, st, 1, pe + ".norm", 0, None, X)
+            DX = self.act(Cs, Hs, Ws, F32)       # running residual-stream gradient of this stage
+            grp = []
+            draw = self.act(Cs, Hs, Ws)
+            self.gn_bwd(grp, raw, st, 1, pe + ".norm", 0, None, DX, draw)
+            self.wgrad(grp, src, draw, cw, k, stride, k // 2, Hs, Ws, dbias=self.g(pe + ".proj.bias"))
+            if s > 0:
+                self.conv(grp, self.conv_desc(draw, ("dgrad", cw), src.C, k, stride, k // 2, src.H, src.W, d_enc_out[s - 1],
+                                              gather=1), region=("dxs", s - 1, 0, src.C))
+            self.bwd_groups.append(grp)
+            # per-stage scratch shared by all blocks of the stage
+            hid = Cs * ratio
+            sc = {"DH": self.act(Cs, Hs, Ws), "DHID": self.act(hid, Hs, Ws), "DHID2": self.act(hid, Hs, Ws),
+                  "DXN": self.act(Cs, Hs, Ws), "DQ": self.act(Cs, Hs, Ws)}
+            for i in range(cfg.depths[s]):
+                X = self.block(f"dest_encoder.block{s + 1}.{i}", X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc)
+                bi += 1
+            Xb = self.act(Cs, Hs, Ws)
+            self._emit(self.fwd, "crd_f32_to_bf16_rows", [X.t, Cs, Xb.t, Cs, 0, B * N, Cs, None, 1, None, 0, 0])
+            enc_out_b.append(Xb)
+            d_enc_out.append(DX)
+            src = Xb
+
+        # ---- decoder ----
+        d = cfg.dims
+        hs = [(H // 32, W // 32), (H // 16, W // 16), (H // 8, W // 8), (H // 4, W // 4), (H // 2, W // 2), (H, W)]
+        # from_encoder_1 -> own buffer E1 (bicubic source of stage 0); from_encoder_2..4 write into skip slices
+        cup = [d[3], MID_CHANNELS, MID_CHANNELS, MID_CHANNELS + 1, MID_CHANNELS + 1]
+        cskip = [d[2], d[1], d[0], 0, Cin]
+        CB, dCB, lay = [], [], []
+        for j in range(5):
+            up_p, sk_p = rup(cup[j]), rup(cskip[j])
+            ld = up_p + sk_p + 96 + 64
+            Hj, Wj = hs[j + 1]
+            CB.append(self.act(ld, Hj, Wj))
+            dCB.append(self.act(ld, Hj, Wj))
+            lay.append((up_p, sk_p))
+        self._cmap = None
+        E1, dE1 = self.act(d[3], *hs[0]), self.act(d[3], *hs[0])
+        # gradient regions of encoder outputs: from_encoder dgrad stores (fp32), patch-embed dgrad accumulates
+        self.conv_layer("from_encoder_1", enc_out_b[3], 1, E1, dout=dE1, dx=d_enc_out[3], dx_region=("dxs", 3, 0, d[3]))
+        for j, e in ((0, 2), (1, 1), (2, 0)):
+            up_p, sk_p = lay[j]
+            self.conv_layer(f"from_encoder_{j + 2}", enc_out_b[e], 1, CB[j].sl(up_p, up_p + d[e]),
+                            dout=dCB[j].sl(up_p, up_p + d[e]), dx=d_enc_out[e], dx_region=("dxs", e, 0, d[e]))
+
+        def cat_map(j, nseg_out, head_extra=None):
+            """internal->reference channel map of stage j's concat buffer prefix covering up|skip|out0..out{n-1}."""
+            up_p, sk_p = lay[j]
+            mp = list(range(cup[j])) + [-1] * (up_p - cup[j])
+            mp += [cup[j] + c for c in range(cskip[j])] + [-1] * (sk_p - cskip[j])
+            base = cup[j] + cskip[j]
+            if nseg_out >= 1:
+                mp += [base + c for c in range(96)]
+            if nseg_out >= 2:
+                mp += [base + 96 + c for c in range(64)]
+            return mp
+
+        def stage(j, name, cb, dcb, up_src, d_up_src, up_region, out, dout, mask):
+            """Decoder stage (utils.py:249-257 + ShortResBlock :127-135) on concat buffer cb."""
+            up_p, sk_p = lay[j]
+            Hj, Wj = cb.H, cb.W
+            self._emit(self.fwd, "crd_bicubic2x", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb.t, cb.ld, 0])
+            o0, o1 = up_p + sk_p, up_p + sk_p + 96
+            grp = []
+            args = [dcb.t, dcb.ld, 0, B, up_src.H, up_src.W, up_p, d_up_src.t, d_up_src.ld, d_up_src.coff, 0]
+            self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
+            self.bwd_groups.append(grp)
+            self._cmap = cat_map(j, 0)
+            self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, cb.sl(o0, o0 + 96), dout=dcb.sl(o0, o0 + 96),
+                            dx=dcb.sl(0, o0), dx_region=("dcb", id(dcb), 0, o0))
+            self._cmap = cat_map(j, 1)
+            self.conv_layer(f"{name}.conv.layers.1", cb.sl(0, o1), 3, cb.sl(o1, o1 + 64), dout=dcb.sl(o1, o1 + 64),
+                            dx=dcb.sl(0, o1), dx_region=("dcb", id(dcb), 0, o1))
+            self._cmap = cat_map(j, 2)
+            self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, dout=dout,
+                            dx=dcb.sl(0, o1 + 64), dx_region=("dcb", id(dcb), 0, o1 + 64))
+            self._cmap = None
+
+        n_extra = int(cfg.supervised_seg) + int(cfg.unsupervised_seg)
+        # source buffers S[j] = output of stage j (128 ch) | depth (1) | pad | [seg maps]; S[0..1] plain 128
+        S, dS = [], []
+        for j in range(5):
+            Hj, Wj = hs[j + 1]
+            ld = 128 if j < 2 else (136 + (8 if (n_extra and j >= 3) else 0))
+            S.append(self.act(ld, Hj, Wj))
+            dS.append(self.act(ld, Hj, Wj))
+        self.out_depth = {}
+
+        def head(j, name, src, dsrc, cin_ref, cmap):
+            """Depth_Activation (utils.py:285-289) on src[0:len(cmap)]; writes fp32 depth [B,P,1] and the bf16 copy
+            into src channel 128 (the reference's torch.cat([stage, depth]) -- CamRaDepth.py:120,146)."""
+            Hj, Wj = src.H, src.W
+            self._cmap = cmap
+            c1 = self.new_conv(name + ".conv_1", cmap=cmap)
+            self._cmap = None
+            c2 = self.new_conv(name + ".conv_2")
+            A = self.act(32, Hj, Wj)
+            xin = src.sl(0, len(cmap))
+            self.conv(self.fwd, self.conv_desc(xin, c1, 32, 3, 1, 1, Hj, Wj, A, bias=c1.bias, act=1))
+            depth = PM(self.new((B, Hj * Wj, 1), F32), 1, Hj, Wj)
+            self.conv(self.fwd, self.conv_desc(A, c2, 1, 3, 1, 1, Hj, Wj, depth, bias=c2.bias))
+            if j < 5:
+                self._emit(self.fwd, "crd_f32_to_bf16_rows", [depth.t, 1, src.t, src.ld, 128, B * Hj * Wj, 1, None, 1, None, 0, 0])
+            self.out_depth[j] = depth
+            # backward: dy = loss gradient (fp32 [B,P,1]) [+ d(src[128]) from the next stage]
+            gd = PM(self.new((B, Hj * Wj, 1), F32), 1, Hj, Wj)
+            self.out_depth[("grad", j)] = gd
+            DY8 = self.act(8, Hj, Wj)
+            grp = []
+            add = (dsrc.t, dsrc.ld, 128) if j < 5 else (None, 0, 0)
+            self._emit(grp, "crd_f32_to_bf16_rows", [gd.t, 1, DY8.t, 8, 0, B * Hj * Wj, 1, None, 1, add[0], add[1], add[2]])
+            self.wgrad(grp, A, DY8, c2, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_2.bias"))
+            dA = self.act(32, Hj, Wj)
+            self.conv(grp, self.conv_desc(DY8, ("dgrad", c2), 32, 3, 1, 1, Hj, Wj, dA, gather=1))
+            self._emit(grp, "crd_sigmoid_bwd", [A.t, dA.t, B * Hj * Wj * 32])
+            self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_1.bias"))
+            self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
+                      region=("ds", id(dsrc), 0, 128))
+            self.bwd_groups.append(grp)
+
+        stage(0, "depth_upsample.0", CB[0], dCB[0], E1, dE1, ("de1", 0, 0, d[3]), S[0].sl(0, 128), dS[0].sl(0, 128), dmask())
+        stage(1, "depth_upsample.1", CB[1], dCB[1], S[0], dS[0], ("ds", id(dS[0]), 0, 128), S[1].sl(0, 128), dS[1].sl(0, 128), dmask())
+        stage(2, "depth_upsample.2", CB[2], dCB[2], S[1], dS[1], ("ds", id(dS[1]), 0, 128), S[2].sl(0, 128), dS[2].sl(0, 128), dmask())
+        head(3, "depth_activation_3", S[2], dS[2], 128, list(range(128)))
+        stage(3, "depth_upsample.3", CB[3], dCB[3], S[2], dS[2], ("ds", id(dS[2]), 0, 136), S[3].sl(0, 128), dS[3].sl(0, 128), dmask())
+        self.seg_logits = None
+        self.seg_logits_grad = None
+        self.unsup_map = None
+
+        def seg_head(name, feat, classes, dests, with_grad):
+            """3x3 conv to class logits (+bias) then Seg_Block argmax/num_classes (CamRaDepth.py:128-134,155-161)."""
+            cw = self.new_conv(name, need_dgrad=with_grad)
+            Hj, Wj = feat.H, feat.W
+            logits = PM(self.new((B, Hj * Wj, rup(classes)), F32), classes, Hj, Wj)
+            self.conv(self.fwd, self.conv_desc(feat.sl(0, 128), cw, classes, 3, 1, 1, Hj, Wj, logits, bias=cw.bias))
+            for (buf, ch) in dests:
+                if ch is None:    # fp32 [B,1,H,W] module output
+                    self._emit(self.fwd, "crd_seg_argmax", [logits.t, logits.ld, B, Hj * Wj, classes, classes, buf, 1, 1, 0])
+                else:
+                    self._emit(self.fwd, "crd_seg_argmax", [logits.t, logits.ld, B, Hj * Wj, classes, classes, buf.t, 0, buf.ld, ch])
+            return cw, logits
+
+        if seg:
+            CBs0, dCBs0 = self.act(CB[3].ld, *hs[4]), self.act(CB[3].ld, *hs[4])
+            SF0, dSF0 = self.act(136, *hs[4]), self.act(136, *hs[4])
+            has_seg_grad = cfg.supervised_seg        # only the supervised branch has a loss (runner.py:197)
+            stage_seg = stage if has_seg_grad else self._stage_fwd_only(stage)
+            stage_seg(3, "seg_upsample.0", CBs0, dCBs0, S[2], dS[2], ("ds", id(dS[2]), 0, 136), SF0.sl(0, 128), dSF0.sl(0, 128), dmask())
+            ch = 136
+            if cfg.supervised_seg:
+                seg_head("seg_conv_stage_4", SF0, cfg.num_classes, [(S[3], ch), (SF0, 128)], False)
+                ch += 1
+            if cfg.unsupervised_seg:
+                dests = [(S[3], ch)] + ([] if cfg.supervised_seg else [(SF0, 128)])
+                seg_head("unsup_stage_4", SF0, UNSUP_CLASSES, dests, False)
+        hmap = list(range(128)) + ([-1] * 8 + [128 + c for c in range(n_extra)] + [-1] * (8 - n_extra) if n_extra else [])
+        head(4, "depth_activation_4", S[3], dS[3], 128 + n_extra, hmap)
+        stage(4, "depth_upsample.4", CB[4], dCB[4], S[3], dS[3], ("ds", id(dS[3]), 0, 136), S[4].sl(0, 128), dS[4].sl(0, 128), dmask())
+        # the raw 7-channel input is the skip of the last stage (CamRaDepth.py:149,152)
+        up_p, sk_p = lay[4]
+        self.fwd.insert(1, Op(self.lib.crd_slice_copy, [X8.t, 8, 0, CB[4].t, CB[4].ld, up_p, B * H * W, 8, 0], "crd_slice_copy"))
+        if seg:
+            CBs1, dCBs1 = self.act(CB[4].ld, *hs[5]), self.act(CB[4].ld, *hs[5])
+            self.fwd.insert(2, Op(self.lib.crd_slice_copy, [X8.t, 8, 0, CBs1.t, CBs1.ld, up_p, B * H * W, 8, 0], "crd_slice_copy"))
+            SF1, dSF1 = self.act(128, *hs[5]), self.act(128, *hs[5])
+            stage_seg(4, "seg_upsample.1", CBs1, dCBs1, SF0, dSF0, ("ds", id(dSF0), 0, 136), SF1, dSF1, dmask())
+            ch = 136
+            if cfg.supervised_seg:
+                cw, logits = seg_head("seg_conv_final", SF1, cfg.num_classes, [(S[4], ch)], True)
+                ch += 1
+                self.seg_logits = logits
+                self.seg_out = torch.zeros((B, cfg.num_classes, H, W), dtype=F32, device=self.dev)
+                self._emit(self.fwd, "crd_pm_to_nchw", [logits.t, 1, logits.ld, 0, B, cfg.num_classes, H, W, self.seg_out])
+                self.seg_grad_in = torch.zeros((B, cfg.num_classes, H, W), dtype=F32, device=self.dev)
+                DL = self.act(rup(cfg.num_classes), H, W)
+                grp = []
+                self._emit(grp, "crd_nchw_to_pm", [self.seg_grad_in, B, cfg.num_classes, H, W, DL.t, DL.ld, 0, DL.ld])
+                self.wgrad(grp, SF1, DL, cw, 3, 1, 1, H, W, dbias=self.g("seg_conv_final.bias"))
+                self.conv(grp, self.conv_desc(DL, ("dgrad", cw), 128, 3, 1, 1, H, W, dSF1, gather=1, cin=DL.ld),
+                          region=("ds", id(dSF1), 0, 128))
+                self.bwd_groups.append(grp)
+            if cfg.unsupervised_seg:
+                self.unsup_map = torch.zeros((B, 1, H, W), dtype=F32, device=self.dev)
+                seg_head("unsup_final", SF1, UNSUP_CLASSES, [(S[4], ch), (self.unsup_map, None)], False)
+        head(5, "depth_activation_5", S[4], dS[4], 128 + n_extra, hmap)
+        self._finalise()
+
+    def _stage_fwd_only(self, stage):
+        """Run a decoder stage builder but drop its backward groups (branches without any loss)."""
+        def run(*a, **k):
+            n = len(self.bwd_groups)
+            stage(*a, **k)
+            del self.bwd_groups[n:]
+        return run
+
+    # ------------------------------------------------------------------ encoder block
+    def block(self, name, X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc):
+        """Block.forward (simplified_attention.py:141-145) with the rank-one form of the max-pool attention
+        (SURVEY.md Q2 / Appendix B3).  X: fp32 residual stream in; returns the fp32 stream out.  DX is the stage's
+        running fp32 gradient buffer (the same buffer flows through every block of the stage)."""
+        B, N, hid, dh = self.B, Hs * Ws, Cs * ratio, Cs // heads
+        scale = dh ** -0.5
+        a, ml = name + ".attn", name + ".mlp1"
+        dp = self.dp_masks[bi] if self.training else None
+        M = (Hs // sr) * (Ws // sr)
+        F_ = self.fwd
+        # ---- attention branch ----
+        st1, ch1 = self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)
+        self._emit(F_, "crd_gn_stats", [X.t, 1, Cs, 0, B, N, Cs, st1, ch1])
+        XN = self.act(Cs, Hs, Ws)
+        self.gn_fwd(X, st1, 1, name + ".norm1", 0, None, XN)
+        cq, ck, cp = self.new_conv(a + ".q"), self.new_conv(a + ".k"), self.new_conv(a + ".proj")
+        Q = self.act(Cs, Hs, Ws)
+        self.conv(F_, self.conv_desc(XN, cq, Cs, 1, 1, 0, Hs, Ws, Q, bias=cq.bias))
+        K = self.act(Cs, Hs // sr, Ws // sr)
+        if sr > 1:
+            csr = self.new_conv(a + ".sr", scatter=True)
+            KR = self.act(Cs, Hs // sr, Ws // sr)
+            stk = self.zf(B, Cs // 16, 2)
+            self.conv(F_, self.conv_desc(XN, csr, Cs, sr, sr, 0, Hs // sr, Ws // sr, KR, bias=csr.bias, stats=stk))
+            KRN = self.act(Cs, Hs // sr, Ws // sr)
+            self.gn_fwd(KR, stk, 1, a + ".norm", 0, None, KRN)
+            self.conv(F_, self.conv_desc(KRN, ck, Cs, 1, 1, 0, Hs // sr, Ws // sr, K, bias=ck.bias))
+        else:
+            self.conv(F_, self.conv_desc(XN, ck, Cs, 1, 1, 0, Hs, Ws, K, bias=ck.bias))
+        xbar = PM(self.new((B, 1, Cs)), Cs, 1, 1)
+        self._emit(F_, "crd_attn_xbar", [ch1, st1, self.p(name + ".norm1.weight"), self.p(name + ".norm1.bias"), B, N, Cs, xbar.t])
+        U = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
+        self.conv(F_, self.conv_desc(xbar, cp, Cs, 1, 1, 0, 1, 1, U))
+        Ssum = self.new((B, N), F32)
+        idx = self.new((B, N, heads), torch.int16)
+        self.keep.append(("idx", name, idx, M))
+        self._emit(F_, "crd_attn_scores", [Q.t, K.t, B, N, M, heads, dh, scale, Ssum, idx])
+        X1 = self.act(Cs, Hs, Ws, F32)
+        self._emit(F_, "crd_attn_out_residual", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t])
+        # ---- MLP branch ----
+        st2 = self.zf(B, Cs // 16, 2)
+        self._emit(F_, "crd_gn_stats", [X1.t, 1, Cs, 0, B, N, Cs, st2, None])
+        XN2 = self.act(Cs, Hs, Ws)
+        self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
+        c1, c2 = self.new_conv(ml + ".fc1"), self.new_conv(ml + ".fc2")
+        H1, H1N, H2, H3 = (self.act(hid, Hs, Ws) for _ in range(4))
+        sth1, sth2 = self.zf(B, hid // 16, 2), self.zf(B, hid // 16, 2)
+        self.conv(F_, self.conv_desc(XN2, c1, hid, 1, 1, 0, Hs, Ws, H1, bias=c1.bias, stats=sth1))
+        self.gn_fwd(H1, sth1, 1, ml + ".norm1", 0, None, H1N)
+        w9 = self.new((9, hid), F32)
+        self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9))
+        self._emit(F_, "crd_dwconv3x3", [H1N.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2])
+        self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
+        X2 = self.act(Cs, Hs, Ws, F32)
+        self.conv(F_, self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp))
+
+        # ---- backward (executed after the later blocks'; DX holds d(X2) on entry, d(X) on exit) ----
+        g = []
+        gen = ("blk", bi)
+        DH, DHID, DHID2, DXN, DQ = sc["DH"], sc["DHID"], sc["DHID2"], sc["DXN"], sc["DQ"]
+        self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
+        self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc2.bias"))
+        self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1))
+        self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID)                 # in place: d(H2)
+        dw9 = self.zb(9, hid)
+        self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw9))
+        self._emit(g, "crd_dwconv3x3_wgrad", [H1N.t, DHID.t, B, Hs, Ws, hid, dw9, self.g(ml + ".dwconv.dwconv.bias")])
+        self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None])  # d(H1N)
+        self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2)                    # in place: d(H1)
+        self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc1.bias"))
+        self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1))
+        self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1)              # DX = d(X1)
+        # attention branch
+        T, dSv = self.zb(B, Cs), self.new((B, N), F32)
+        self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, self.g(a + ".proj.bias"), dSv])
+        Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
+        self._emit(g, "crd_f32_to_bf16_rows", [T, Cs, Tb.t, Cs, 0, B, Cs, None, 1, None, 0, 0])
+        self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
+        E = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)                                           # d(xbar)
+        self.conv(g, self.conv_desc(Tb, ("dgrad", cp), Cs, 1, 1, 0, 1, 1, E, gather=1))
+        dK = self.zb(B, M, Cs)
+        self._emit(g, "crd_attn_scores_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK])
+        self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".q.bias"))
+        Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
+        self._emit(g, "crd_scale_f32", [E.t, Es.t, B * Cs, 1.0 / N])
+        self.conv(g, self.conv_desc(DQ, ("dgrad", cq), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, bias=Es.t, bias_bstride=Cs))
+        DKb = self.act(Cs, Hs // sr, Ws // sr)
+        self._emit(g, "crd_f32_to_bf16_rows", [dK, Cs, DKb.t, Cs, 0, B * M, Cs, None, 1, None, 0, 0])
+        if sr > 1:
+            self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=self.g(a + ".k.bias"))
+            DKR = self.act(Cs, Hs // sr, Ws // sr)
+            self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs // sr, Ws // sr, DKR, gather=1))
+            self.gn_bwd(g, KR, stk, 1, a + ".norm", 0, None, DKR, DKR)
+            self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=self.g(a + ".sr.bias"))
+            self.conv(g, self.conv_desc(DKR, ("scatter", csr), sr * sr * Cs, 1, 1, 0, Hs // sr, Ws // sr, DXN, out_mode=1,
+                                        patch_k=sr, patch_c=Cs, accumulate=1))
+        else:
+            self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".k.bias"))
+            self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=1))
+        self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1)               # DX = d(X)
+        self.bwd_groups.append(g)
+        return X2
+
+    # ------------------------------------------------------------------ finalisation
+    def _finalise(self):
+        dev = self.dev
+        # packed weight arena (bf16) + pack table
+        n_bf16 = 0
+        for cw in self.convs:
+            n_bf16 += cw.cout * cw.taps * cw.cin_pad
+            if cw.need_dgrad and not cw.scatter:
+                n_bf16 += cw.cin_pad * cw.taps * cw.cout_pad
+            if cw.scatter:
+                n_bf16 += cw.taps * cw.cin_pad * cw.cout_pad
+        self.w_arena = torch.zeros(n_bf16 + 8, dtype=BF16, device=dev)
+        off = 0
+
+        def take(n):
+            nonlocal off
+            t = self.w_arena[off:off + n]
+            off += rup(n)
+            return t
+        entries, max_elems = [], 1
+        unpack, max_unpack = [], 1
+        for cw in self.convs:
+            cw.w_fwd = take(cw.cout * cw.taps * cw.cin_pad)
+            if cw.need_dgrad and not cw.scatter:
+                cw.w_dgrad = take(cw.cin_pad * cw.taps * cw.cout_pad)
+            if cw.scatter:
+                cw.w_scatter = take(cw.taps * cw.cin_pad * cw.cout_pad)
+            if cw.cmap is not None:
+                cw.cmap_dev = torch.tensor(cw.cmap, dtype=torch.int32, device=dev)
+            e = L.PackEntry()
+            e.src = self.p(cw.name + ".weight").data_ptr()
+            e.dst_fwd = cw.w_fwd.data_ptr()
+            e.dst_dgrad = cw.w_dgrad.data_ptr() if cw.w_dgrad is not None else None
+            e.dst_scatter = cw.w_scatter.data_ptr() if cw.w_scatter is not None else None
+            e.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
+            e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad, cw.cout_pad, 0
+            entries.append(e)
+            max_elems = max(max_elems, cw.cout * cw.taps * cw.cin_pad, cw.cin_pad * cw.taps * cw.cout_pad)
+            # weight-gradient destination: direct into the flat gradient for identity layouts, else scratch + unpack
+            if cw.identity:
+                cw.dw = self.g(cw.name + ".weight")
+            else:
+                cw.dw = self.zb(cw.cout, cw.taps, cw.cin_pad)
+                unpack.append(cw)
+        for (name, hid, w9) in self.dw_entries:
+            e = L.PackEntry()
+            e.src, e.dst_fwd = self.p(name + ".weight").data_ptr(), w9.data_ptr()
+            e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = 1, hid, 9, hid, 8, 1
+            entries.append(e)
+            max_elems = max(max_elems, 9 * hid)
+        self.pack_table = _struct_table(entries, dev)
+        self.n_pack, self.max_pack = len(entries), max_elems
+        # zero arenas
+        self.zf_arena = self._materialise(self._zf_views)
+        self.zb_arena = self._materialise(self._zb_views)
+        uentries = []
+        for cw in unpack:
+            u = L.UnpackEntry()
+            u.src, u.dst = cw.dw.t.data_ptr(), self.g(cw.name + ".weight").data_ptr()
+            u.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
+            u.Cout, u.Cin_ref, u.taps, u.Cin_pad = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad
+            uentries.append(u)
+            max_unpack = max(max_unpack, cw.cout * cw.taps * cw.cin_pad)
+        for (name, hid, dw9) in self.dw_grads:
+            u = L.UnpackEntry()
+            u.src, u.dst, u.cmap = dw9.t.data_ptr(), self.g(name + ".weight").data_ptr(), None
+            u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, 9, hid
+            uentries.append(u)
+            max_unpack = max(max_unpack, 9 * hid)
+        self.unpack_table = _struct_table(uentries, dev)
+        self.n_unpack, self.max_unpack = len(uentries), max_unpack
+        # backward op order + accumulate flags
+        written = {}
+        self.bwd = []
+        for grp in reversed(self.bwd_groups):
+            for op in grp:
+                if op.region is not None:
+                    key, c0, c1 = op.region[:-2], op.region[-2], op.region[-1]
+                    prev = written.setdefault(key, [])
+                    overlap = [r for r in prev if r[0] < c1 and c0 < r[1]]
+                    if overlap:
+                        lo, hi = min(r[0] for r in overlap), max(r[1] for r in overlap)
+                        assert lo <= c0 and hi >= c1, f"partial gradient overlap at {op.name} {op.region}: {overlap}"
+                        acc = 1
+                    else:
+                        prev.append((c0, c1))
+                        acc = 0
+                    if op.acc_slot is not None:
+                        if isinstance(op.acc_slot, tuple):
+                            op.acc_slot[1]["accumulate"] = acc
+                        else:
+                            op.args[op.acc_slot] = acc
+                self.bwd.append(op)
+        # resolve lazy arguments to raw pointers / ctypes
+        for op in self.fwd + self.bwd:
+            op.args = [self._resolve(a) for a in op.args]
+        self.bwd_groups = None
+
+    def _resolve(self, a):
+        if isinstance(a, dict):
+            return self._make_desc(a)
+        if isinstance(a, (_Lazy, torch.Tensor)):
+            return a.data_ptr()
+        return a
+
+    # ------------------------------------------------------------------ execution
+    def run_ops(self, ops):
+        st = L.stream()
+        lib = self.lib
+        if os.environ.get("CRD_DEBUG_SYNC"):      # developer aid: name the faulting kernel
+            for i, op in enumerate(ops):
+                print(f"[crd] op {i} {op.name}", flush=True)
+                rc = op.fn(*op.args, st)
+                torch.cuda.synchronize()
+                if rc != 0:
+                    raise L.CrdError(f"{op.name} failed ({rc}): {lib.crd_last_error().decode()}")
+                if os.environ.get("CRD_DEBUG_NAN") and self.model.flat_grad is not None:
+                    bad = ~torch.isfinite(self.model.flat_grad)
+                    if bool(bad.any()) or not bool(torch.isfinite(self.zb_arena).all()):
+                        where = int(bad.nonzero()[0]) if bool(bad.any()) else -1
+                        pname = "zb_arena"
+                        for n_, o_ in zip(self.model._names, self.model._offsets):
+                            if o_ <= where:
+                                pname = n_
+                        for k in self.keep:
+                            if isinstance(k, tuple) and k[0] == "buf" and k[5].is_floating_point() \
+                                    and not bool(torch.isfinite(k[5].float()).all()):
+                                print("[crd] non-finite buffer", k[1:5], flush=True)
+                        raise L.CrdError(f"non-finite gradient after op {i} {op.name} (first bad param {pname})")
+                if os.environ.get("CRD_DEBUG_IDX"):
+                    for k in self.keep:
+                        if isinstance(k, tuple) and k[0] == "idx" and (int(k[2].min()) < 0 or int(k[2].max()) >= k[3]):
+                            raise L.CrdError(f"argmax table of {k[1]} corrupted after op {i} {op.name}")
+            return
+        for op in ops:
+            rc = op.fn(*op.args, st)
+            if rc != 0:
+                raise L.CrdError(f"{op.name} failed ({rc}): {lib.crd_last_error().decode()}")
+
+    def forward(self, masks=None):
+        """x must already be in self.x_in.  masks: optional injected {'drop_path': [...], 'dropout2d': [...]}."""
+        st = L.stream()
+        self.zf_arena.zero_()
+        L.check(self.lib.crd_weight_pack(self.pack_table.data_ptr(), self.n_pack, self.max_pack, st), "crd_weight_pack")
+        if self.training:
+            if masks is not None:
+                self.dp_masks.copy_(torch.stack([t.to(self.dev, F32) for t in masks["drop_path"]]))
+                self.d2_masks.copy_(torch.stack([t.to(self.dev, F32) for t in masks["dropout2d"]]))
+            else:
+                nblk, n_drop = self.dp_masks.shape[0], self.d2_masks.shape[0]
+                L.check(self.lib.crd_dropout_masks(self.dp_masks.data_ptr(), self.dp_keep.data_ptr(), nblk, self.B,
+                                                   self.model.seed, self.rng_counter.data_ptr(), st), "crd_dropout_masks")
+                L.check(self.lib.crd_dropout_masks(self.d2_masks.data_ptr(), self.d2_keep.data_ptr(), n_drop * self.B,
+                                                   MID_CHANNELS, self.model.seed + 1, self.rng_counter.data_ptr(), st),
+                        "crd_dropout_masks")
+        self.run_ops(self.fwd)
+
+    def backward(self):
+        """Loss gradients must already be in out_depth[('grad', j)] (and seg_grad_in).  Adds into the flat gradient."""
+        self.zb_arena.zero_()
+        self.run_ops(self.bwd)
+        if self.n_unpack:
+            L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr(), self.n_unpack, self.max_unpack, 1, L.stream()),
+                    "crd_wgrad_unpack")
+
+
+class _Lazy:
+    """Placeholder for a slice of a zero-arena, materialised in Plan._finalise."""
+    __slots__ = ("shape", "numel", "t")
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+        n = 1
+        for s in shape:
+            n *= s
+        self.numel, self.t = n, None
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+
+def _struct_table(entries, dev):
+    if not entries:
+        return torch.zeros(8, dtype=torch.uint8, device=dev)
+    raw = b"".join(bytes(e) for e in entries)
+    return torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+
+

@@ -47,7 +47,7 @@ class PackEntry(C.Structure):
         ("src", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p), ("dst_scatter", C.c_void_p),
         ("cmap", C.c_void_p),
         ("Cout", C.c_int32), ("Cin_ref", C.c_int32), ("taps", C.c_int32), ("Cin_pad", C.c_int32),
-        ("Cout_pad", C.c_int32),
+        ("Cout_pad", C.c_int32), ("dst_f32", C.c_int32),
     ]
 
 
@@ -93,14 +93,14 @@ _SIGS = {
     "crd_attn_scores": "ppiiiiifppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_out_residual": "pppppiiipp",
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifppp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
-    "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiip",
-    "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiilipLp".replace("L", "l"), "crd_sigmoid_bwd": "pplp",
+    "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiiip", "crd_scale_f32": "pplfp",
+    "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp",
     "crd_weight_pack": "pilp", "crd_wgrad_unpack": "pilip",
     "crd_masked_l1_fwd": "pplpp", "crd_masked_l1_bwd": "pplppfpp", "crd_ce_fwd": "ppiilpp",
     "crd_ce_focal_bwd": "ppiilppfpp",
     "crd_diffgradnorm_step": "pppppppppppiipfffffip",
 }
-_CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "f": C.c_float}
+_CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "L": C.c_uint64, "f": C.c_float}
 EXPORTS = list(_SIGS)
 
 

@@ -1,0 +1,248 @@
+"""Drop-in `CamRaDepth` nn.Module whose forward/backward run on hand-written HIP kernels (gfx950).
+
+Surface kept from the reference (src/models/CamRaDepth.py:20-176): constructor keywords, parameter
+names / shapes / registration order (so reference checkpoints and positional optimizer state load),
+`.forward(x: float[B,C,H,W]) -> dict` with the same nested keys, `.train()/.eval()/.to()/.state_dict()`.
+The reference reads `supervised_seg`, `unsupervised_seg`, `num_classes`, `input_channels` from a
+global argparse namespace (src/utils/args.py); here they are explicit keyword arguments.
+
+There is no CPU path: constructing the plan on a non-GPU device or without the built HIP library
+raises (camradepth_amd.lib.CrdError).
+"""
+import math
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import lib as L
+from .config import ModelConfig
+from .engine import Plan
+from .params import param_specs
+
+
+def cast_tuple(val, depth):
+    return val if isinstance(val, tuple) else (val,) * depth
+
+
+class _Holder(nn.Module):
+    """Parameter container mirroring one node of the reference's module tree (no compute)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("camradepth_amd modules are parameter containers; call the top-level CamRaDepth")
+
+
+class _Bridge(torch.autograd.Function):
+    """Connects the HIP plan to torch.autograd: outputs are plain tensors, parameter gradients are
+    accumulated by the kernels straight into `param.grad` (views of one flat buffer)."""
+
+    @staticmethod
+    def forward(ctx, anchor, x, model, masks):
+        plan = model._plan_for(x)
+        plan.x_in.copy_(x)
+        plan.forward(masks)
+        ctx.plan, ctx.model = plan, model
+        B, H, W = plan.B, plan.H, plan.W
+        outs = [plan.out_depth[5].t.view(B, 1, H, W).clone(), plan.out_depth[4].t.view(B, 1, H // 2, W // 2).clone(),
+                plan.out_depth[3].t.view(B, 1, H // 4, W // 4).clone()]
+        if plan.seg_logits is not None:
+            outs.append(plan.seg_out.clone())
+        ctx.n_out = len(outs)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        plan, model = ctx.plan, ctx.model
+        model._ensure_grad_views()
+        for j, g in zip((5, 4, 3), gouts[:3]):
+            buf = plan.out_depth[("grad", j)].t
+            if g is None:
+                buf.zero_()
+            else:
+                buf.copy_(g.reshape(buf.shape))
+        if plan.seg_logits is not None:
+            if gouts[3] is None:
+                plan.seg_grad_in.zero_()
+            else:
+                plan.seg_grad_in.copy_(gouts[3])
+        plan.backward()
+        if model._grad_sync is not None:
+            model._grad_sync.after_backward()
+        return torch.zeros_like(model._anchor), None, None, None
+
+
+class CamRaDepth(nn.Module):
+    def __init__(self, img_size=(416, 800), heads=(1, 2, 4, 8), ff_expansion=(8, 8, 4, 4), reduction_ratio=(8, 4, 2, 1),
+                 depths=(3, 10, 16, 5), dims=(64, 128, 160, 256), input_channels=None, supervised_seg=False,
+                 unsupervised_seg=False, num_classes=21, seed=0, **kwargs):
+        super().__init__()
+        dims, heads, ff_expansion, reduction_ratio, depths = (cast_tuple(v, 4) for v in
+                                                              (dims, heads, ff_expansion, reduction_ratio, depths))
+        assert all(len(t) == 4 for t in (dims, heads, ff_expansion, reduction_ratio, depths)), \
+            "only four stages are allowed, all keyword arguments must be either a single value or a tuple of 4 values"
+        input_channels = 7 if input_channels is None else input_channels
+        assert input_channels > 0, "input_channels must be > 0"
+        for dm, hd in zip(dims, heads):
+            assert dm % hd == 0, f"dim {dm} should be divided by num_heads {hd}."
+            assert dm % 16 == 0 and (dm // hd) % 8 == 0, "HIP path needs dims % 16 == 0 and head_dim % 8 == 0"
+        self.cfg = ModelConfig(input_channels=input_channels, heads=tuple(heads), ff_expansion=tuple(ff_expansion),
+                               reduction_ratio=tuple(reduction_ratio), depths=tuple(depths), dims=tuple(dims),
+                               supervised_seg=bool(supervised_seg), unsupervised_seg=bool(unsupervised_seg),
+                               num_classes=num_classes)
+        self.img_size = tuple(img_size)
+        self.supervised_seg, self.unsupervised_seg = bool(supervised_seg), bool(unsupervised_seg)
+        self.seed = int(seed)
+        self._specs = param_specs(self.cfg)
+        self._names = [n for n, _ in self._specs]
+        self._index = {n: i for i, n in enumerate(self._names)}
+        for name, shape in self._specs:
+            self._register(name, nn.Parameter(torch.empty(shape)))
+        self._plans = {}
+        self._grad_sync = None
+        self.__dict__["flat"] = None
+        self.__dict__["flat_grad"] = None
+        self.__dict__["_anchor"] = None
+        self.reset_parameters()
+        self._reflatten()
+
+    # ------------------------------------------------------------------ parameters
+    def _register(self, name, p):
+        mod = self
+        parts = name.split(".")
+        for part in parts[:-1]:
+            if part not in mod._modules:
+                mod.add_module(part, _Holder())
+            mod = mod._modules[part]
+        mod.register_parameter(parts[-1], p)
+
+    def _param(self, name):
+        mod = self
+        parts = name.split(".")
+        for part in parts[:-1]:
+            mod = mod._modules[part]
+        return mod._parameters[parts[-1]]
+
+    def has_param(self, name):
+        return name in self._index
+
+    def reset_parameters(self):
+        """Initialisation of the reference: Conv1d trunc_normal(std .02); encoder/ConvLayer Conv2d
+        N(0, sqrt(2/fan_out)); GroupNorm 1/0; Depth_Activation and seg head convs keep torch's Conv2d default."""
+        g = torch.Generator().manual_seed(self.seed)
+        with torch.no_grad():
+            for name, shape in self._specs:
+                p = self._param(name)
+                head = name.startswith(("depth_activation", "seg_conv", "unsup_"))
+                if name.endswith(".weight") and len(shape) == 3:
+                    nn.init.trunc_normal_(p, std=0.02, generator=g)
+                elif name.endswith(".weight") and len(shape) == 4 and not head:
+                    fan_out = shape[0] * shape[2] * shape[3]
+                    if "dwconv" in name:
+                        fan_out //= shape[0]
+                    p.normal_(0, math.sqrt(2.0 / fan_out), generator=g)
+                elif name.endswith(".weight") and len(shape) == 4:
+                    bound = 1.0 / math.sqrt(shape[1] * shape[2] * shape[3])
+                    p.uniform_(-bound, bound, generator=g)
+                elif name.endswith(".weight"):
+                    p.fill_(1.0)
+                elif head:
+                    w = self._param(name[:-5] + ".weight")
+                    bound = 1.0 / math.sqrt(w.shape[1] * w.shape[2] * w.shape[3])
+                    p.uniform_(-bound, bound, generator=g)
+                else:
+                    p.zero_()
+
+    def _reflatten(self):
+        """(Re)build the flat fp32 parameter buffer; every nn.Parameter becomes a view into it."""
+        ps = [self._param(n) for n in self._names]
+        dev = ps[0].device
+        offs, n = [], 0
+        for p in ps:
+            offs.append(n)
+            n += (p.numel() + 7) // 8 * 8      # 32-byte alignment for vector loads
+        flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.detach().reshape(-1).to(torch.float32))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+            p._crd_owner = weakref.ref(self)
+        self.__dict__["flat"] = flat
+        self.__dict__["_offsets"] = offs
+        self.__dict__["flat_grad"] = None
+        self.__dict__["_anchor"] = torch.zeros(1, device=dev, requires_grad=True)
+        self._plans.clear()
+
+    def _apply(self, fn, *a, **k):
+        super()._apply(fn, *a, **k)
+        self._reflatten()
+        return self
+
+    def _flat_ok(self):
+        p0, pl = self._param(self._names[0]), self._param(self._names[-1])
+        return (self.flat is not None and p0.data_ptr() == self.flat.data_ptr()
+                and pl.data_ptr() == self.flat.data_ptr() + 4 * self._offsets[-1])
+
+    def _ensure_grad_views(self):
+        if self.flat_grad is None:
+            self.__dict__["flat_grad"] = torch.zeros_like(self.flat)
+        fg = self.flat_grad
+        for name, o in zip(self._names, self._offsets):
+            p = self._param(name)
+            if p.grad is None or p.grad.data_ptr() != fg.data_ptr() + 4 * o:
+                if p.grad is None:
+                    fg[o:o + p.numel()].zero_()
+                else:
+                    fg[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = fg[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self, set_to_none=False):
+        """Zero the flat gradient buffer in one fill (views stay attached; see optim.diffGradNorm.zero_grad)."""
+        if self.flat_grad is not None:
+            self.flat_grad.zero_()
+        self._ensure_grad_views()
+
+    def param_view(self, name):
+        o = self._offsets[self._index[name]]
+        p = self._param(name)
+        return self.flat[o:o + p.numel()].view(p.shape)
+
+    def grad_view(self, name):
+        if self.flat_grad is None:
+            self.__dict__["flat_grad"] = torch.zeros_like(self.flat)
+        o = self._offsets[self._index[name]]
+        p = self._param(name)
+        return self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        if not self._flat_ok():
+            self._reflatten()
+        return out
+
+    # ------------------------------------------------------------------ forward
+    def _plan_for(self, x):
+        if x.dim() != 4 or x.shape[1] != self.cfg.input_channels:
+            raise ValueError(f"expected input [B,{self.cfg.input_channels},H,W], got {tuple(x.shape)}")
+        if not x.is_cuda or self.flat.device != x.device:
+            raise L.CrdError("camradepth_amd runs on an MI355X only: move the model and the input to cuda "
+                             "(there is no CPU fallback; see oracle/ for the test-only CPU restatement)")
+        if not self._flat_ok():
+            self._reflatten()
+        key = (x.shape[0], x.shape[2], x.shape[3], self.training)
+        plan = self._plans.get(key)
+        if plan is None:
+            self._ensure_grad_views()
+            plan = Plan(self, x.shape[0], x.shape[2], x.shape[3], self.training)
+            self._plans[key] = plan
+        return plan
+
+    def forward(self, x, masks=None):
+        """Returns the reference's nested dict (CamRaDepth.py:169-170).  `masks` optionally injects the
+        DropPath / Dropout2d masks in train mode (camradepth_amd.synth.make_masks) for parity tests."""
+        x = x.to(torch.float32)
+        outs = _Bridge.apply(self._anchor, x, self, masks)
+        final, half, quarter = outs[0], outs[1], outs[2]
+        seg = outs[3] if len(outs) > 3 else None
+        plan = self._plans[(x.shape[0], x.shape[2], x.shape[3], self.training)]
+        unsup = plan.unsup_map.clone() if plan.unsup_map is not None else None
+        return {"depth": {"intermediate_depths": (None, None, quarter, half), "final_depth": final},
+                "seg": {"final_seg": seg, "intermediate_seg": None, "unsup_map": unsup}}

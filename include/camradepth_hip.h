@@ -168,15 +168,20 @@ int crd_nchw_to_pm(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, v
 /* pixel-major (bf16 or fp32) -> NCHW fp32 */
 int crd_pm_to_nchw(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t C, int32_t H,
                    int32_t W, float* y, crd_stream_t stream);
-/* Seg_Block (utils.py:95-100): y[row][y_coff] = argmax_c logits[row][c] / num_classes (first max wins) */
+/* Seg_Block (utils.py:95-100): y[row*y_ld + y_coff] = argmax_c logits[row][c] / num_classes (first max wins);
+ * y is bf16 (y_f32=0, a channel of a pixel-major buffer) or fp32 (y_f32=1, the module output) */
 int crd_seg_argmax(const void* logits, int32_t ld, int32_t B, int32_t P, int32_t C, int32_t num_classes, void* y,
-                   int32_t y_ld, int32_t y_coff, crd_stream_t stream);
+                   int32_t y_f32, int32_t y_ld, int32_t y_coff, crd_stream_t stream);
+/* dst[i] = scale * src[i]  (fp32) */
+int crd_scale_f32(const float* src, float* dst, int64_t n, float scale, crd_stream_t stream);
 /* dst[row][d_coff+c] (+)= src[row][s_coff+c]   (bf16 slices) */
 int crd_slice_copy(const void* src, int32_t s_ld, int32_t s_coff, void* dst, int32_t d_ld, int32_t d_coff,
                    int64_t rows, int32_t C, int32_t accumulate, crd_stream_t stream);
-/* dst[row][d_coff+c] = bf16(scale[row / rows_per_sample] * src[row*s_ld + c]), c < C (scale may be NULL) */
+/* dst[row][d_coff+c] = bf16(scale[row / rows_per_sample] * src[row*s_ld + c] + add[row][add_coff+c]), c < C
+ * (scale and add may be NULL; add is a bf16 slice) */
 int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, int32_t d_ld, int32_t d_coff, int64_t rows,
-                         int32_t C, const float* scale, int64_t rows_per_sample, crd_stream_t stream);
+                         int32_t C, const float* scale, int64_t rows_per_sample, const void* add, int32_t add_ld,
+                         int32_t add_coff, crd_stream_t stream);
 /* da <- da * a * (1-a)   (bf16, n elements, n % 8 == 0): backward of the sigmoid in Depth_Activation */
 int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream);
 
@@ -191,6 +196,7 @@ typedef struct {
   void* dst_scatter;   /* bf16 [taps][Cin_pad][Cout_pad]  or NULL   (out_mode 1)    */
   const int32_t* cmap; /* [Cin_pad]: reference input channel of each packed channel, -1 = zero; NULL = identity */
   int32_t Cout, Cin_ref, taps, Cin_pad, Cout_pad;
+  int32_t dst_f32;     /* 1: dst_fwd is written as fp32 (depthwise weights [9][C]) */
 } crd_pack_entry;
 int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int64_t max_elems, crd_stream_t stream);
 /* grad_ref[co][ci_ref][tap] (+)= dw_packed[co][tap][ci_pad] */
@@ -202,6 +208,12 @@ typedef struct {
 } crd_unpack_entry;
 int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int64_t max_elems, int32_t accumulate,
                      crd_stream_t stream);
+
+/* Train-mode masks of timm DropPath (simplified_attention.py:123,143-144) and nn.Dropout2d
+ * (CamRaDepth.py:96): out[r][c] = Bernoulli(keep[r]) / keep[r].  *counter (device) is advanced by
+ * the call so that a replayed HIP graph draws new masks. */
+int crd_dropout_masks(float* out, const float* keep, int32_t rows, int32_t cols, uint64_t seed, uint64_t* counter,
+                      crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses (src/utils/loss_funcs.py:14-46,77-91; combination src/main/runner.py:197-218).
@@ -221,7 +233,7 @@ int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int3
 
 /* ---------------------------------------------------------------------------------------------
  * diffGradNorm.step (src/models/diffGradNorm.py:41-113) over flat fp32 buffers.
- * Tensor t occupies [seg_off[t], seg_off[t+1]) of every flat buffer.  Workgroup w processes chunk
+ * Tensor t occupies [seg_off[2t], seg_off[2t+1]) of every flat buffer (int64 pairs; gaps allowed).  Workgroup w processes chunk
  * blk2chunk[w] (4096 elements) of tensor blk2seg[w].  exp_grad_norm / norm_sq / factor are
  * float[n_tensors] (norm_sq must be zero on entry and is left zero).  active[t]=0 skips tensor t
  * (`p.grad is None`, :54-55).  `step` is the 1-based step count used for the bias corrections.

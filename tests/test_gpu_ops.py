@@ -272,7 +272,7 @@ def test_layout_and_small_ops():
     assert torch.equal(out.cpu(), lg[..., :21].reshape(B, H, W, 21).permute(0, 3, 1, 2))
     # seg argmax
     sm = torch.zeros(B, H * W, 8, dtype=torch.bfloat16, device="cuda")
-    ok(lb.crd_seg_argmax(P(lgc), 24, B, H * W, 21, 21, P(sm), 8, 3, lib.stream()), "seg_argmax")
+    ok(lb.crd_seg_argmax(P(lgc), 24, B, H * W, 21, 21, P(sm), 0, 8, 3, lib.stream()), "seg_argmax")
     ref = (lg[..., :21].argmax(-1) / 21)
     assert torch.equal(sm[..., 3].float().cpu(), bf(ref))
     # slice copy + accumulate
@@ -287,7 +287,7 @@ def test_layout_and_small_ops():
     sc = torch.tensor([0.5, 2.0])
     d2 = torch.zeros(30, 8, dtype=torch.bfloat16, device="cuda")
     srcc, scc = src.cuda(), sc.cuda()
-    ok(lb.crd_f32_to_bf16_rows(P(srcc), 1, P(d2), 8, 0, 30, 1, P(scc), 15, lib.stream()), "f32_to_bf16_rows")
+    ok(lb.crd_f32_to_bf16_rows(P(srcc), 1, P(d2), 8, 0, 30, 1, P(scc), 15, None, 0, 0, lib.stream()), "f32_to_bf16_rows")
     assert torch.equal(d2[:, 0].float().cpu(), bf(src[:, 0] * sc.repeat_interleave(15)))
     # sigmoid backward
     av = bf(torch.rand(64, generator=g))
@@ -358,7 +358,7 @@ def test_diffgradnorm_matches_golden_trajectory():
         for c in range((sz + 4095) // 4096):
             b2s.append(t)
             b2c.append(c)
-    seg = torch.from_numpy(off).cuda()
+    seg = torch.from_numpy(np.stack([off[:-1], off[1:]], 1).copy()).cuda()
     b2s_d, b2c_d = torch.tensor(b2s, dtype=torch.int32).cuda(), torch.tensor(b2c, dtype=torch.int32).cuda()
     for it in range(40):
         lr, b1, b2 = (float(z) for z in gd["hp"][it])

@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: CamRaDepth training images/s at 256x416, bf16, on N MI355X (one process per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one full optimizer step (zero grads, forward, masked losses, backward, RCCL gradient
+all-reduce, diffGradNorm) of BASELINE.json's config C2 per GPU: base model, batch 8, 7x256x416
+synthetic image + sparse-radar batch, random-init weights.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+FWD_GFLOP = {"base": 201.54, "supervised_seg": 364.74}   # SURVEY.md section 8(d), per image at 256x416
+MFMA_BF16_PEAK_TFLOPS = 2500.0                             # MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def per_kernel_timing(ts, reps=3):
+    """Times every kernel launch of one step with HIP events on the launch stream and aggregates the MFMA kernels
+    by template instance: {kernel: (launches, total ms, algorithmic flops)} per step."""
+    plan = ts.plan
+    import camradepth_amd.lib as L
+    agg = {}
+    st = L.stream()
+    for _ in range(reps):
+        ts._forward_and_loss_partials()           # leaves valid activations / loss partials for the backward ops
+        ts._loss_backward()
+        plan.zb_arena.zero_()
+        for ops in (plan.fwd, plan.bwd):
+            if ops is plan.fwd:
+                plan.zf_arena.zero_()
+            evs = []
+            for op in ops:
+                if op.meta is None:
+                    op.fn(*op.args, st)
+                    continue
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                op.fn(*op.args, st)
+                e1.record()
+                evs.append((op.meta, e0, e1))
+            torch.cuda.synchronize()
+            for meta, e0, e1 in evs:
+                a = agg.setdefault(meta["kernel"], [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1)
+                a[2] += meta["flops"]
+    return {k: (v[0] / reps, v[1] / reps, v[2] / reps) for k, v in agg.items()}
+
+
+def cpu_baseline(variant, seconds_budget=25.0):
+    """The CPU oracle (oracle/, a port of the reference verified against it) timed on this box's host cores."""
+    import numpy as np  # noqa: F401
+    from camradepth_amd import synth
+    from camradepth_amd.config import ModelConfig
+    from camradepth_amd.params import param_specs
+    from oracle import losses as ol
+    from oracle import model as om
+    from oracle import optim as oo
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    cfg = ModelConfig.variant(variant)
+    sd = {k: v.clone().requires_grad_(True) for k, v in synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0).items()}
+    states = {k: oo.new_state(v.detach()) for k, v in sd.items()}
+    B = 2
+    batch = synth.make_batch(B, 256, 416, seed=1234)
+    masks = synth.make_masks(cfg, B, seed=4321)
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        out = om.forward(sd, batch["image"], cfg, masks=masks)
+        loss, _ = ol.total_loss(out, batch, cfg.supervised_seg)
+        loss.backward()
+        with torch.no_grad():
+            for k, v in sd.items():
+                if v.grad is not None:
+                    oo.step_tensor(v, v.grad, states[k], 6e-5, 0.9, 0.999)
+    step()
+    t0, n = time.time(), 0
+    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return {"value": round(B / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} fp32 train steps (fwd+loss+bwd+diffGradNorm) of the CPU oracle, batch {B}, 7x256x416, "
+                      f"{threads} torch threads of {cores} host cores"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (config C2: 8)")
+    ap.add_argument("--variant", default="base", choices=["base", "supervised_seg"])
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    from camradepth_amd import synth
+    from camradepth_amd.model import CamRaDepth
+    from camradepth_amd.trainer import TrainStep, one_cycle
+
+    sup = a.variant == "supervised_seg"
+    model = CamRaDepth(input_channels=7, supervised_seg=sup, seed=0).cuda()      # same init on every rank
+    model.train()
+    total_sched = max(a.steps + a.warmup + 8, 64)
+    ts = TrainStep(model, a.batch, a.height, a.width, lr=6e-5, schedule=one_cycle(total_sched, 6e-5),
+                   use_graph=not a.no_graph)
+    batch = synth.make_batch(a.batch, a.height, a.width, seed=1234 + rank)
+    ts.set_batch({k: v.cuda() for k, v in batch.items()})
+
+    for _ in range(a.warmup):
+        ts.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        ts.step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    losses = ts.losses()
+    ms = 1e3 * dt / a.steps
+    value = a.batch * world * a.steps / dt
+
+    out = {"metric": "training images/sec at 256x416 bf16", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+           "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": f"CamRaDepth {a.variant} (image+radar) train step, {a.batch}x7x{a.height}x{a.width} per GPU, "
+                                  f"bf16 MFMA / fp32 accumulate, diffGradNorm + OneCycleLR, Dropout2d/DropPath on",
+                      "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
+           "loss": round(losses["loss"], 6), "rmse_norm": round(losses["rmse"], 6)}
+    scale = (a.height * a.width) / (256 * 416)
+    train_tflop_per_img = 3 * FWD_GFLOP[a.variant] * scale / 1e3
+    out["mfma_frac_train_step"] = round(value / world * train_tflop_per_img / MFMA_BF16_PEAK_TFLOPS, 4)
+
+    if rank == 0 and not a.no_roofline:
+        agg = per_kernel_timing(ts)
+        dom = max(agg, key=lambda k: agg[k][1])
+        n, ms_tot, fl = agg[dom]
+        ach = fl / (ms_tot * 1e-3) / 1e12
+        out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                           "launches_per_step": n, "avg_launch_us": round(1e3 * ms_tot / n, 2),
+                           "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
+        out["kernels"] = {k: {"launches": v[0], "ms_per_step": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    if world > 1:
+        dist.barrier()
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.variant)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

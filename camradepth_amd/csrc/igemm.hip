@@ -22,13 +22,15 @@ struct ConvK {
   int accumulate; float* stats; int G16;
 };
 
-constexpr int BK = 32;
+constexpr int BK = 64;                 // K elements per LDS stage (8 granules of 8 bf16 per row)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-template <int WM, int WN, int TM, int TN>
+// MODE 0: forward gather (any stride); 1: data-gradient gather, stride 1; 2: data-gradient gather, strided
+template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int A_IT = BM / 64, B_IT = (BN + 63) / 64;
+  constexpr int A_IT = BM / 32, B_IT = (BN + 31) / 32;   // 32 rows x 8 granules per pass of 256 threads
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BM + BN) * BK];
   bf16_t* sA = lds;
   bf16_t* sB = lds + 2 * BM * BK;
@@ -36,66 +38,66 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   const int t = threadIdx.x, l = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const bf16_t* xb = a.x + (long long)b * a.x_bstride;
-  const int g = t & 3, r0 = t >> 2;
-  const int swz = (r0 >> 2) & 3;  // same for r0 + 64*i
+  // hardware-bounds-checked buffer loads: an out-of-range offset returns zeros, which implements the conv padding,
+  // the K tail and the partial M/N tiles without a single branch in the load path
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + (long long)b * a.x_bstride), 0, (int)(a.x_bstride * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot * 2, 0x00020000);
+  const unsigned OOB = 0x80000000u;
+  const int g = t & 7, r0 = t >> 3;          // granule column, row within a 32-row pass
+  const int swz = (r0 >> 1) & 7;             // (row >> 1) & 7 is the same for row = r0 + 32*i
 
   int py[A_IT], px[A_IT];
-  bool mv[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    int m = m0 + r0 + 64 * i;
-    mv[i] = m < a.OHW;
-    int oy = m / a.OW, ox = m - oy * a.OW;
-    if (a.gather_mode == 0) { py[i] = oy * a.stride - a.pad; px[i] = ox * a.stride - a.pad; }
+    const int m = m0 + r0 + 32 * i;
+    const int oy = m / a.OW, ox = m - oy * a.OW;
+    if (MODE == 0) { py[i] = oy * a.stride - a.pad; px[i] = ox * a.stride - a.pad; }
     else { py[i] = oy + a.pad; px[i] = ox + a.pad; }
+    if (m >= a.OHW) py[i] = -(1 << 28);      // rows past the image: every tap lands out of range
+  }
+  unsigned woff[B_IT];
+#pragma unroll
+  for (int j = 0; j < B_IT; ++j) {
+    const int n = r0 + 32 * j, ng = n0 + n;
+    woff[j] = (n < BN && ng < a.Cout) ? (unsigned)(ng * a.Ktot * 2) : OOB;
   }
   int kf = g * 8, kc = g * 8, ky = 0, kx = 0;
   while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
 
-  uint4 ra[A_IT], rb[B_IT];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
-
+  u32x4 ra[A_IT], rb[B_IT];
   auto gload = [&]() {
     const bool kok = kf < a.Ktot;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
       int iy, ix;
-      bool ok = kok && mv[i];
-      if (a.gather_mode == 0) { iy = py[i] + ky; ix = px[i] + kx; }
+      bool ok = kok;
+      if (MODE == 0) { iy = py[i] + ky; ix = px[i] + kx; }
+      else if (MODE == 1) { iy = py[i] - ky; ix = px[i] - kx; }
       else {
-        int ty = py[i] - ky, tx = px[i] - kx;
-        if (a.stride == 1) { iy = ty; ix = tx; }
-        else {
-          iy = ty / a.stride; ix = tx / a.stride;
-          ok = ok && ty >= 0 && tx >= 0 && iy * a.stride == ty && ix * a.stride == tx;
-        }
+        const int ty = py[i] - ky, tx = px[i] - kx;
+        iy = ty / a.stride; ix = tx / a.stride;
+        ok = ok && ty >= 0 && tx >= 0 && iy * a.stride == ty && ix * a.stride == tx;
       }
       ok = ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-      ra[i] = zero4;
-      if (ok) ra[i] = *reinterpret_cast<const uint4*>(xb + (long long)(iy * a.IW + ix) * a.x_ld + kc);
+      const unsigned off = ok ? (unsigned)(((iy * a.IW + ix) * a.x_ld + kc) * 2) : OOB;
+      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-      int n = r0 + 64 * j, ng = n0 + n;
-      bool ok = kok && n < BN && ng < a.Cout;
-      rb[j] = zero4;
-      if (ok) rb[j] = *reinterpret_cast<const uint4*>(a.w + (long long)ng * a.Ktot + kf);
+      const unsigned off = kok ? woff[j] + (unsigned)(kf * 2) : OOB;
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, off | (woff[j] & OOB), 0, 0);
     }
-  };
-  auto advance = [&]() {
     kf += BK; kc += BK;
     while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
-      *reinterpret_cast<uint4*>(&sA[buf * BM * BK + (r0 + 64 * i) * BK + ((g ^ swz) << 3)]) = ra[i];
+      *reinterpret_cast<u32x4*>(&sA[buf * BM * BK + (r0 + 32 * i) * BK + ((g ^ swz) << 3)]) = ra[i];
 #pragma unroll
-    for (int j = 0; j < B_IT; ++j) {
-      int n = r0 + 64 * j;
-      if (n < BN) *reinterpret_cast<uint4*>(&sB[buf * BN * BK + n * BK + ((g ^ swz) << 3)]) = rb[j];
-    }
+    for (int j = 0; j < B_IT; ++j)
+      if (r0 + 32 * j < BN) *reinterpret_cast<u32x4*>(&sB[buf * BN * BK + (r0 + 32 * j) * BK + ((g ^ swz) << 3)]) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -109,24 +111,23 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   const int nK = (a.Ktot + BK - 1) / BK;
   gload();
   lstore(0);
-  advance();
   __syncthreads();
   for (int kt = 0; kt < nK; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nK) gload();
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[TM], bfr[TN];
       const int gi = ks * 2 + (l >> 5);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        int row = (wm * TM + i) * 32 + (l & 31);
-        af[i] = *reinterpret_cast<const bf16x8*>(&sA[cur * BM * BK + row * BK + ((gi ^ ((row >> 2) & 3)) << 3)]);
+        const int row = (wm * TM + i) * 32 + (l & 31);
+        af[i] = *reinterpret_cast<const bf16x8*>(&sA[cur * BM * BK + row * BK + ((gi ^ ((row >> 1) & 7)) << 3)]);
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        int row = (wn * TN + j) * 32 + (l & 31);
-        bfr[j] = *reinterpret_cast<const bf16x8*>(&sB[cur * BN * BK + row * BK + ((gi ^ ((row >> 2) & 3)) << 3)]);
+        const int row = (wn * TN + j) * 32 + (l & 31);
+        bfr[j] = *reinterpret_cast<const bf16x8*>(&sB[cur * BN * BK + row * BK + ((gi ^ ((row >> 1) & 7)) << 3)]);
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nK) { lstore(cur ^ 1); advance(); }
+    if (kt + 1 < nK) lstore(cur ^ 1);
     __syncthreads();
   }
 
@@ -202,7 +203,9 @@ template <int WM, int WN, int TM, int TN>
 int launch(const ConvK& k, int B, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   dim3 grid(cdiv(k.OHW, BM), cdiv(k.Cout, BN), B);
-  hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN>), grid, dim3(256), 0, st, k);
+  if (k.gather_mode == 0) hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 0>), grid, dim3(256), 0, st, k);
+  else if (k.stride == 1) hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, k);
+  else hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, k);
   CRD_LAUNCH_CHECK("crd_conv_igemm");
   return CRD_OK;
 }
@@ -219,7 +222,8 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   CRD_CHECK_ARG(!d->stats || d->Cout % 16 == 0, "crd_conv_igemm: stats need Cout %% 16 == 0");
   CRD_CHECK_ARG(d->out_mode == 0 || (d->patch_k > 0 && d->patch_c > 0 && d->Cout == d->patch_k * d->patch_k * d->patch_c),
                 "crd_conv_igemm: bad patch-scatter dims");
-  CRD_UNSUPPORTED((long long)d->IH * d->IW * d->x_ld < (1ll << 31), "crd_conv_igemm: image too large for 32-bit offsets");
+  CRD_UNSUPPORTED((long long)d->IH * d->IW * d->x_ld < (1ll << 30) && (long long)d->Cout * d->KH * d->KW * d->Cin < (1ll << 30),
+                  "crd_conv_igemm: image or weight tensor too large for 32-bit byte offsets");
   ConvK k;
   k.x = reinterpret_cast<const bf16_t*>(d->x) + d->x_coff; k.x_ld = d->x_ld;
   k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.x_bstride = (long long)d->IH * d->IW * d->x_ld;

@@ -101,8 +101,11 @@ __global__ __launch_bounds__(TPB) void k_ce_focal_bwd(const float* logits, const
 // ---- diffGradNorm (src/models/diffGradNorm.py:73-110) -------------------------------------------
 constexpr int OPT_CHUNK = 4096;  // elements per workgroup
 
+// hp (device, optional): [beta1, beta2, eps, weight_decay, step_size] -- lets a captured HIP graph follow the
+// per-iteration OneCycleLR schedule without re-capture
 __global__ __launch_bounds__(TPB) void k_dgn_norm(const float* p, const float* g, const long long* seg_off, const int* blk2seg,
-                                                  const int* blk2chunk, float wd, float* norm_sq) {
+                                                  const int* blk2chunk, float wd, const float* hp, float* norm_sq) {
+  if (hp) wd = hp[3];
   const int t = blk2seg[blockIdx.x];
   const long long beg = seg_off[2 * t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
   long long end = beg + OPT_CHUNK;
@@ -135,7 +138,8 @@ __global__ void k_dgn_scalar(float* exp_grad_norm, float* norm_sq, float* factor
 __global__ __launch_bounds__(TPB) void k_dgn_update(float* p, const float* g, float* m, float* v, float* pg, const float* factor,
                                                     const long long* seg_off, const int* blk2seg, const int* blk2chunk,
                                                     const unsigned char* active, float beta1, float beta2, float eps, float wd,
-                                                    float step_size) {
+                                                    float step_size, const float* hp) {
+  if (hp) { beta1 = hp[0]; beta2 = hp[1]; eps = hp[2]; wd = hp[3]; step_size = hp[4]; }
   const int t = blk2seg[blockIdx.x];
   if (active && !active[t]) return;
   const long long beg = seg_off[2 * t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
@@ -270,18 +274,18 @@ extern "C" int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, f
                                      float* exp_grad_norm, float* norm_sq, float* factor, const int64_t* seg_off,
                                      const int32_t* blk2seg, const int32_t* blk2chunk, int32_t n_tensors, int32_t n_blocks,
                                      const uint8_t* active, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                     int32_t step, crd_stream_t stream) {
+                                     int32_t step, const float* hp_dev, crd_stream_t stream) {
   CRD_CHECK_ARG(p && g && exp_avg && exp_avg_sq && prev_grad && exp_grad_norm && norm_sq && factor && seg_off && blk2seg &&
                     blk2chunk && n_tensors > 0 && n_blocks > 0 && step >= 1,
                 "crd_diffgradnorm_step: bad argument");
   hipStream_t st = as_stream(stream);
   const long long* so = reinterpret_cast<const long long*>(seg_off);
-  hipLaunchKernelGGL(k_dgn_norm, dim3(n_blocks), dim3(TPB), 0, st, p, g, so, blk2seg, blk2chunk, weight_decay, norm_sq);
+  hipLaunchKernelGGL(k_dgn_norm, dim3(n_blocks), dim3(TPB), 0, st, p, g, so, blk2seg, blk2chunk, weight_decay, hp_dev, norm_sq);
   hipLaunchKernelGGL(k_dgn_scalar, dim3(cdiv(n_tensors, 256)), dim3(256), 0, st, exp_grad_norm, norm_sq, factor, active, n_tensors);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr * sqrt(bc2) / (bc1 + 1e-8));
   hipLaunchKernelGGL(k_dgn_update, dim3(n_blocks), dim3(TPB), 0, st, p, g, exp_avg, exp_avg_sq, prev_grad, factor, so, blk2seg,
-                     blk2chunk, active, beta1, beta2, eps, weight_decay, step_size);
+                     blk2chunk, active, beta1, beta2, eps, weight_decay, step_size, hp_dev);
   CRD_LAUNCH_CHECK("crd_diffgradnorm_step");
   return CRD_OK;
 }

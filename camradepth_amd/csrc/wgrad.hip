@@ -17,6 +17,7 @@ struct WgK {
   const bf16_t* dy; int dy_ld; int OH, OW, Cout;
   int KW, stride, pad, Ktot;
   long long P;           // B*OH*OW
+  long long x_bytes, dy_bytes;
   int chunk;             // pixels per split (multiple of 32)
   float* dw;
 };
@@ -48,6 +49,12 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
   if (p_begin >= p_end) return;
   const int nK = (int)((p_end - p_begin + PK - 1) / PK);
 
+  // hardware-bounds-checked buffer loads (out-of-range offset -> zeros): padding, K tail and partial tiles
+  // need no branch in the load path
+  typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rxs = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rys = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
   // ---- X gather state: fixed kf granule per thread, two pixel rows ----
   const int xg = t & 15, xr0 = t >> 4;
   const int kf = n0 + xg * 8;
@@ -63,50 +70,49 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
     int rem = (int)(p - (long long)b * OHW);
     xb[i] = b; xoy[i] = rem / a.OW; xox[i] = rem - xoy[i] * a.OW;
   }
-  auto x_advance = [&]() {
+  // dy tile: thread -> (row, granule) fixed for the whole loop
+  int yr[Y_IT], yc[Y_IT];
+  bool yok[Y_IT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      xox[i] += PK;
-      while (xox[i] >= a.OW) { xox[i] -= a.OW; if (++xoy[i] == a.OH) { xoy[i] = 0; ++xb[i]; } }
-    }
-  };
+  for (int i = 0; i < Y_IT; ++i) {
+    const int idx = t + 256 * i;
+    yr[i] = idx / GY;
+    yc[i] = idx - yr[i] * GY;
+    yok[i] = idx < PK * GY && (m0 + yc[i] * 8) < a.Cout;
+  }
 
-  uint4 rx[2], ry[Y_IT];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+  u32x4 rx[2], ry[Y_IT];
   int kt_load = 0;
   auto gload = [&]() {
     const long long pbase = p_begin + (long long)kt_load * PK;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      long long p = pbase + xr0 + 16 * i;
-      int iy = xoy[i] * a.stride - a.pad + ky, ix = xox[i] * a.stride - a.pad + kx;
-      bool ok = kok && p < p_end && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
-      rx[i] = zero4;
-      if (ok) rx[i] = *reinterpret_cast<const uint4*>(a.x + ((long long)(xb[i] * a.IH + iy) * a.IW + ix) * a.x_ld + kc);
+      const long long p = pbase + xr0 + 16 * i;
+      const int iy = xoy[i] * a.stride - a.pad + ky, ix = xox[i] * a.stride - a.pad + kx;
+      const bool ok = kok && p < p_end && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
+      const unsigned off = ok ? (unsigned)((((xb[i] * a.IH + iy) * a.IW + ix) * a.x_ld + kc) * 2) : OOB;
+      rx[i] = __builtin_amdgcn_raw_buffer_load_b128(rxs, off, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i) {
-      int idx = t + 256 * i;
-      int r = idx / GY, gcol = idx - r * GY;
-      long long p = pbase + r;
-      int co = m0 + gcol * 8;
-      bool ok = idx < PK * GY && p < p_end && co < a.Cout;   // Cout multiple of 8 or handled by host padding
-      ry[i] = zero4;
-      if (ok) ry[i] = *reinterpret_cast<const uint4*>(a.dy + p * a.dy_ld + co);
+      const long long p = pbase + yr[i];
+      const unsigned off = (yok[i] && p < p_end) ? (unsigned)((p * a.dy_ld + m0 + yc[i] * 8) * 2) : OOB;
+      ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rys, off, 0, 0);
     }
-    x_advance();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      xox[i] += PK;
+      while (xox[i] >= a.OW) { xox[i] -= a.OW; if (++xoy[i] == a.OH) { xoy[i] = 0; ++xb[i]; } }
+    }
     ++kt_load;
   };
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<uint4*>(&sX[buf * PK * LDX + (xr0 + 16 * i) * LDX + xg * 8]) = rx[i];
+      *reinterpret_cast<u32x4*>(&sX[buf * PK * LDX + (xr0 + 16 * i) * LDX + xg * 8]) = rx[i];
 #pragma unroll
-    for (int i = 0; i < Y_IT; ++i) {
-      int idx = t + 256 * i;
-      int r = idx / GY, gcol = idx - r * GY;
-      if (idx < PK * GY) *reinterpret_cast<uint4*>(&sY[buf * PK * LDY + r * LDY + gcol * 8]) = ry[i];
-    }
+    for (int i = 0; i < Y_IT; ++i)
+      if (t + 256 * i < PK * GY) *reinterpret_cast<u32x4*>(&sY[buf * PK * LDY + yr[i] * LDY + yc[i] * 8]) = ry[i];
   };
 
   f32x4 acc[TMc][TNc];
@@ -210,6 +216,9 @@ extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
   k.dy = reinterpret_cast<const bf16_t*>(d->dy) + d->dy_coff; k.dy_ld = d->dy_ld; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
   k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.Ktot = d->KH * d->KW * d->Cin;
   k.P = (long long)d->B * d->OH * d->OW; k.chunk = 0; k.dw = d->dw;
+  k.x_bytes = (long long)d->B * d->IH * d->IW * d->x_ld * 2;
+  k.dy_bytes = k.P * d->dy_ld * 2;
+  CRD_UNSUPPORTED(k.x_bytes < (1ll << 31) && k.dy_bytes < (1ll << 31), "crd_conv_wgrad: tensor too large for 32-bit byte offsets");
   hipStream_t st = as_stream(stream);
   if (d->dbias) {
     dim3 grid(cdiv(d->Cout, 64), (unsigned)(k.P >= 4096 ? 64 : (k.P >= 256 ? 8 : 1)));

@@ -50,10 +50,33 @@ class PM:
 
 
 class Op:
-    __slots__ = ("fn", "args", "name", "region", "acc_slot", "zero")
+    __slots__ = ("fn", "args", "name", "region", "acc_slot", "meta")
 
-    def __init__(self, fn, args, name, region=None, acc_slot=None, zero=None):
-        self.fn, self.args, self.name, self.region, self.acc_slot, self.zero = fn, args, name, region, acc_slot, zero
+    def __init__(self, fn, args, name, region=None, acc_slot=None, meta=None):
+        self.fn, self.args, self.name, self.region, self.acc_slot, self.meta = fn, args, name, region, acc_slot, meta
+
+
+def igemm_tile(cout):
+    """Tile configuration crd_conv_igemm dispatches to (csrc/igemm.hip), as the kernel's template arguments."""
+    if cout <= 32:
+        return "k_igemm<4,1,1,1>"
+    if cout <= 64:
+        return "k_igemm<2,2,2,1>"
+    if cout <= 96:
+        return "k_igemm<4,1,1,3>"
+    if 128 < cout <= 160:
+        return "k_igemm<4,1,1,5>"
+    return "k_igemm<2,2,2,2>"
+
+
+def wgrad_tile(cout):
+    if cout <= 32:
+        return "k_wgrad<1,4,2,2>"
+    if cout <= 64:
+        return "k_wgrad<1,4,4,2>"
+    if cout <= 96:
+        return "k_wgrad<2,2,3,4>"
+    return "k_wgrad<2,2,4,4>"
 
 
 class ConvW:
@@ -78,7 +101,8 @@ class Plan:
         self.model, self.cfg, self.B, self.H, self.W, self.training = model, cfg, B, H, W, training
         self.dev = model.flat.device
         self.lib = L.load()
-        self.fwd, self.bwd_groups = [], []
+        self.fwd, self.bwd_groups, self.bwd_tags = [], [], []
+        self._tag = "enc0"
         self.zero_fwd, self.zero_bwd = [], []       # (numel) requests into the two zero arenas
         self._zf_views, self._zb_views = [], []
         self.convs = []
@@ -127,6 +151,11 @@ class Plan:
         lst.append(op)
         return op
 
+    def _push(self, grp):
+        """Register the backward ops of one forward unit; units are replayed in reverse order."""
+        self.bwd_groups.append(grp)
+        self.bwd_tags.append(self._tag)
+
     def conv_desc(self, x, w_t, cout, k, stride, pad, OH, OW, y, cin=None, gather=0, out_mode=0, patch_k=0, patch_c=0,
                   bias=None, bias_bstride=0, act=0, res=None, res_scale=None, stats=None, accumulate=0):
         """Specification of one crd_conv_igemm call; turned into a ctypes ConvDesc in _finalise."""
@@ -135,14 +164,26 @@ class Plan:
                     act=act, res=res, res_scale=res_scale, stats=stats, accumulate=accumulate)
 
     def conv(self, lst, spec, region=None):
-        op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None)
+        w, x = spec["w"], spec["x"]
+        if isinstance(w, tuple):     # data gradient of convolution w[1]: algorithmic work of that layer's forward
+            cw = w[1]
+            flops = 2.0 * self.B * x.H * x.W * cw.cout * cw.taps * min(spec["cout"] // (cw.taps if w[0] == "scatter" else 1),
+                                                                         cw.cin_ref)
+        else:
+            flops = 2.0 * self.B * spec["OH"] * spec["OW"] * spec["cout"] * w.cin_ref * w.taps
+        meta = {"kernel": igemm_tile(spec["cout"]), "flops": flops,
+                "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
+                         f"out{spec['OH']}x{spec['OW']}"}
+        op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None, meta)
         lst.append(op)
         return op
 
     def wgrad(self, lst, x, dy, cw, k, stride, pad, OH, OW, dbias=None, cin=None):
         spec = dict(wg=True, x=x, dy=dy, cw=cw, k=k, stride=stride, pad=pad, OH=OH, OW=OW, dbias=dbias,
                     cin=cin if cin is not None else x.C)
-        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad"))
+        meta = {"kernel": wgrad_tile(cw.cout), "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps,
+                "shape": f"wgrad Cin{spec['cin']} Cout{cw.cout} k{k} s{stride} out{OH}x{OW}"}
+        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta))
 
     def _make_desc(self, sp):
         def P(v):
@@ -191,6 +232,7 @@ class Plan:
         k = w.shape[2] if w.dim() == 4 else 1
         bias = self.p(name + ".bias") if self.model.has_param(name + ".bias") else None
         cw = ConvW(name, cout, cin_ref, k, cmap, bias, need_dgrad, scatter)
+        cw.tag = self._tag
         self.convs.append(cw)
         return cw
 
@@ -225,7 +267,7 @@ class Plan:
         self.wgrad(grp, x, draw, cw, k, 1, k // 2, H, W)
         if dx is not None:
             self.conv(grp, self.conv_desc(draw, ("dgrad", cw), dx.C, k, 1, k // 2, H, W, dx, gather=1), region=dx_region)
-        self.bwd_groups.append(grp)
+        self._push(grp)
 
     # ------------------------------------------------------------------ the model
     def _build(self):
@@ -260,6 +302,7 @@ class Plan:
         d_enc_out = []          # fp32 gradients of the four stage outputs
         src, bi = X8, 0
         for s in range(4):
+            self._tag = f"enc{s}"
             Cs, heads, ratio, sr = cfg.dims[s], cfg.heads[s], cfg.ff_expansion[s], cfg.reduction_ratio[s]
             k, stride = (7, 4) if s == 0 else (3, 2)
             Hs, Ws = src.H // stride, src.W // stride
@@ -280,7 +323,7 @@ class Plan:
             if s > 0:
                 self.conv(grp, self.conv_desc(draw, ("dgrad", cw), src.C, k, stride, k // 2, src.H, src.W, d_enc_out[s - 1],
                                               gather=1), region=("dxs", s - 1, 0, src.C))
-            self.bwd_groups.append(grp)
+            self._push(grp)
             # per-stage scratch shared by all blocks of the stage
             hid = Cs * ratio
             sc = {"DH": self.act(Cs, Hs, Ws), "DHID": self.act(hid, Hs, Ws), "DHID2": self.act(hid, Hs, Ws),
@@ -295,6 +338,7 @@ class Plan:
             src = Xb
 
         # ---- decoder ----
+        self._tag = "dec"
         d = cfg.dims
         hs = [(H // 32, W // 32), (H // 16, W // 16), (H // 8, W // 8), (H // 4, W // 4), (H // 2, W // 2), (H, W)]
         # from_encoder_1 -> own buffer E1 (bicubic source of stage 0); from_encoder_2..4 write into skip slices
@@ -338,7 +382,7 @@ class Plan:
             grp = []
             args = [dcb.t, dcb.ld, 0, B, up_src.H, up_src.W, up_p, d_up_src.t, d_up_src.ld, d_up_src.coff, 0]
             self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
-            self.bwd_groups.append(grp)
+            self._push(grp)
             self._cmap = cat_map(j, 0)
             self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, cb.sl(o0, o0 + 96), dout=dcb.sl(o0, o0 + 96),
                             dx=dcb.sl(0, o0), dx_region=("dcb", id(dcb), 0, o0))
@@ -390,7 +434,7 @@ class Plan:
             self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_1.bias"))
             self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
                       region=("ds", id(dsrc), 0, 128))
-            self.bwd_groups.append(grp)
+            self._push(grp)
 
         stage(0, "depth_upsample.0", CB[0], dCB[0], E1, dE1, ("de1", 0, 0, d[3]), S[0].sl(0, 128), dS[0].sl(0, 128), dmask())
         stage(1, "depth_upsample.1", CB[1], dCB[1], S[0], dS[0], ("ds", id(dS[0]), 0, 128), S[1].sl(0, 128), dS[1].sl(0, 128), dmask())
@@ -452,7 +496,7 @@ class Plan:
                 self.wgrad(grp, SF1, DL, cw, 3, 1, 1, H, W, dbias=self.g("seg_conv_final.bias"))
                 self.conv(grp, self.conv_desc(DL, ("dgrad", cw), 128, 3, 1, 1, H, W, dSF1, gather=1, cin=DL.ld),
                           region=("ds", id(dSF1), 0, 128))
-                self.bwd_groups.append(grp)
+                self._push(grp)
             if cfg.unsupervised_seg:
                 self.unsup_map = torch.zeros((B, 1, H, W), dtype=F32, device=self.dev)
                 seg_head("unsup_final", SF1, UNSUP_CLASSES, [(S[4], ch), (self.unsup_map, None)], False)
@@ -465,6 +509,7 @@ class Plan:
             n = len(self.bwd_groups)
             stage(*a, **k)
             del self.bwd_groups[n:]
+            del self.bwd_tags[n:]
         return run
 
     # ------------------------------------------------------------------ encoder block
@@ -533,7 +578,7 @@ class Plan:
         self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1))
         self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID)                 # in place: d(H2)
         dw9 = self.zb(9, hid)
-        self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw9))
+        self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw9, self._tag))
         self._emit(g, "crd_dwconv3x3_wgrad", [H1N.t, DHID.t, B, Hs, Ws, hid, dw9, self.g(ml + ".dwconv.dwconv.bias")])
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None])  # d(H1N)
         self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2)                    # in place: d(H1)
@@ -568,7 +613,7 @@ class Plan:
             self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".k.bias"))
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=1))
         self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1)               # DX = d(X)
-        self.bwd_groups.append(g)
+        self._push(g)
         return X2
 
     # ------------------------------------------------------------------ finalisation
@@ -626,26 +671,37 @@ class Plan:
         # zero arenas
         self.zf_arena = self._materialise(self._zf_views)
         self.zb_arena = self._materialise(self._zb_views)
-        uentries = []
-        for cw in unpack:
+        order = ["dec", "enc3", "enc2", "enc1", "enc0"]
+        items = [(order.index(cw.tag), cw, None) for cw in unpack] + [(order.index(t[3]), None, t) for t in self.dw_grads]
+        items.sort(key=lambda it: it[0])
+        uentries, self.unpack_ranges = [], {}
+        for seg_i, cw, dwt in items:
             u = L.UnpackEntry()
-            u.src, u.dst = cw.dw.t.data_ptr(), self.g(cw.name + ".weight").data_ptr()
-            u.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
-            u.Cout, u.Cin_ref, u.taps, u.Cin_pad = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad
+            if cw is not None:
+                u.src, u.dst = cw.dw.t.data_ptr(), self.g(cw.name + ".weight").data_ptr()
+                u.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
+                u.Cout, u.Cin_ref, u.taps, u.Cin_pad = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad
+                nel = cw.cout * cw.taps * cw.cin_pad
+            else:
+                name, hid, dw9, _ = dwt
+                u.src, u.dst, u.cmap = dw9.t.data_ptr(), self.g(name + ".weight").data_ptr(), None
+                u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, 9, hid
+                nel = 9 * hid
+            lo, hi, mx = self.unpack_ranges.get(order[seg_i], (len(uentries), len(uentries), 1))
+            self.unpack_ranges[order[seg_i]] = (lo, len(uentries) + 1, max(mx, nel))
             uentries.append(u)
-            max_unpack = max(max_unpack, cw.cout * cw.taps * cw.cin_pad)
-        for (name, hid, dw9) in self.dw_grads:
-            u = L.UnpackEntry()
-            u.src, u.dst, u.cmap = dw9.t.data_ptr(), self.g(name + ".weight").data_ptr(), None
-            u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, 9, hid
-            uentries.append(u)
-            max_unpack = max(max_unpack, 9 * hid)
+            max_unpack = max(max_unpack, nel)
         self.unpack_table = _struct_table(uentries, dev)
+        self.unpack_stride = C.sizeof(L.UnpackEntry)
         self.n_unpack, self.max_unpack = len(uentries), max_unpack
         # backward op order + accumulate flags
         written = {}
-        self.bwd = []
-        for grp in reversed(self.bwd_groups):
+        self.bwd, self.bwd_segments = [], []       # segments: (tag, first op, one-past-last op) in execution order
+        for grp, tag in zip(reversed(self.bwd_groups), reversed(self.bwd_tags)):
+            if self.bwd_segments and self.bwd_segments[-1][0] == tag:
+                self.bwd_segments[-1][2] = len(self.bwd) + len(grp)
+            else:
+                self.bwd_segments.append([tag, len(self.bwd), len(self.bwd) + len(grp)])
             for op in grp:
                 if op.region is not None:
                     key, c0, c1 = op.region[:-2], op.region[-2], op.region[-1]
@@ -715,7 +771,7 @@ class Plan:
         st = L.stream()
         self.zf_arena.zero_()
         L.check(self.lib.crd_weight_pack(self.pack_table.data_ptr(), self.n_pack, self.max_pack, st), "crd_weight_pack")
-        if self.training:
+        if self.training and not getattr(self, "training_masks_fixed", False):
             if masks is not None:
                 self.dp_masks.copy_(torch.stack([t.to(self.dev, F32) for t in masks["drop_path"]]))
                 self.d2_masks.copy_(torch.stack([t.to(self.dev, F32) for t in masks["dropout2d"]]))
@@ -728,13 +784,20 @@ class Plan:
                         "crd_dropout_masks")
         self.run_ops(self.fwd)
 
-    def backward(self):
-        """Loss gradients must already be in out_depth[('grad', j)] (and seg_grad_in).  Adds into the flat gradient."""
-        self.zb_arena.zero_()
-        self.run_ops(self.bwd)
-        if self.n_unpack:
-            L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr(), self.n_unpack, self.max_unpack, 1, L.stream()),
-                    "crd_wgrad_unpack")
+    def backward(self, tags=None):
+        """Loss gradients must already be in out_depth[('grad', j)] (and seg_grad_in).  Adds into the flat gradient.
+        tags=None runs the whole pass; otherwise only the segments with those tags (in execution order: 'dec',
+        'enc3', 'enc2', 'enc1', 'enc0'), which lets the caller start a gradient all-reduce between segments."""
+        if tags is None or "dec" in tags:
+            self.zb_arena.zero_()
+        for tag, a, b in self.bwd_segments:
+            if tags is not None and tag not in tags:
+                continue
+            self.run_ops(self.bwd[a:b])
+            if tag in self.unpack_ranges:
+                lo, hi, mx = self.unpack_ranges[tag]
+                L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1,
+                                                  L.stream()), "crd_wgrad_unpack")
 
 
 class _Lazy:

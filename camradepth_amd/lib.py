@@ -98,7 +98,7 @@ _SIGS = {
     "crd_weight_pack": "pilp", "crd_wgrad_unpack": "pilip",
     "crd_masked_l1_fwd": "pplpp", "crd_masked_l1_bwd": "pplppfpp", "crd_ce_fwd": "ppiilpp",
     "crd_ce_focal_bwd": "ppiilppfpp",
-    "crd_diffgradnorm_step": "pppppppppppiipfffffip",
+    "crd_diffgradnorm_step": "pppppppppppiipfffffipp",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "L": C.c_uint64, "f": C.c_float}
 EXPORTS = list(_SIGS)

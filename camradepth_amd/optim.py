@@ -113,7 +113,7 @@ class diffGradNorm(Optimizer):
                                              st["seg"].data_ptr(), st["b2s"].data_ptr(), st["b2c"].data_ptr(), len(ps),
                                              st["nblk"], None if parallel else st["active"].data_ptr(), float(group["lr"]),
                                              float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
-                                             st["step"], L.stream()), "crd_diffgradnorm_step")
+                                             st["step"], None, L.stream()), "crd_diffgradnorm_step")
             for p in ps:
                 self.state[p]["step"] = st["step"]
         return loss

@@ -1,0 +1,237 @@
+"""Training-step driver: the counterpart of `Trainer.train_one_epoch`'s inner iteration
+(reference: src/main/runner.py:179-270) for one process per GPU.
+
+One step = zero grads -> forward -> masked losses -> backward -> (gradient all-reduce) -> diffGradNorm,
+entirely as HIP kernels enqueued on one stream with static buffers, so the step is captured once
+into HIP graphs and replayed; the host only updates five hyper-parameter floats per step
+(OneCycleLR drives lr and beta1 every iteration, runner.py:151-152,270).
+
+Data parallelism replaces nn.DataParallel (runner.py:135-136): batch-sharded replicas, gradients
+SUM-all-reduced with RCCL in four buckets that become ready in backward order (decoder, stages 4+3,
+stage 2, stage 1 + patch embeds), each launched as soon as its backward segment is enqueued so the
+transfer overlaps the remaining backward.  The masked-mean denominators are made global first
+(one 16-float all-reduce), which reproduces the reference's loss over the gathered batch exactly.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import lib as L
+from .optim import _CHUNK
+
+LOSS_W = (1.0, 1.0, 1.0, 0.2, 0.2)   # runner.py:213
+
+
+def one_cycle(total_steps, max_lr, div_factor=2.0, pct_start=0.15, final_div_factor=1e4, base_m=0.85, max_m=0.95):
+    """(lr, beta1) schedule of torch OneCycleLR(anneal='cos', cycle_momentum=True) as configured in runner.py:151-152."""
+    initial, up_end = max_lr / div_factor, float(pct_start * total_steps) - 1
+    min_lr = initial / final_div_factor
+
+    def cos(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1)
+    out = []
+    for s in range(total_steps):
+        if s <= up_end:
+            pct = s / up_end if up_end > 0 else 1.0
+            out.append((cos(initial, max_lr, pct), cos(max_m, base_m, pct)))
+        else:
+            pct = (s - up_end) / (total_steps - 1 - up_end)
+            out.append((cos(max_lr, min_lr, pct), cos(base_m, max_m, pct)))
+    return out
+
+
+class GradSync:
+    """Bucketed gradient all-reduce (SUM) over the flat gradient buffer, RCCL over xGMI."""
+
+    ORDER = (("dec",), ("enc3", "enc2"), ("enc1",), ("enc0",))
+
+    def __init__(self, model, group=None):
+        self.model, self.group = model, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        names, offs = model._names, model._offsets
+        total = model.flat.numel()
+
+        def first(prefix):
+            return offs[next(i for i, n in enumerate(names) if n.startswith(prefix))]
+        b2, b3, dec = first("dest_encoder.block2."), first("dest_encoder.block3."), first("from_encoder_1.")
+        # flat layout: [patch embeds | block1 | block2 | block3 | block4 | decoder, heads, seg]
+        self.ranges = {("dec",): (dec, total), ("enc3", "enc2"): (b3, dec), ("enc1",): (b2, b3), ("enc0",): (0, b2)}
+        self.pending = []
+
+    def bucket(self, key):
+        lo, hi = self.ranges[key]
+        return self.model.flat_grad[lo:hi]
+
+    def launch(self, key):
+        if self.world > 1:
+            self.pending.append(dist.all_reduce(self.bucket(key), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+
+    def after_backward(self):
+        """Eager-autograd path (model._grad_sync): reduce everything once the whole backward is enqueued."""
+        for key in self.ORDER:
+            self.launch(key)
+        self.wait()
+
+
+class TrainStep:
+    def __init__(self, model, B, H, W, lr=6e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, update_interval=1,
+                 use_graph=True, schedule=None, group=None):
+        assert model.training, "TrainStep drives the training path: call model.train() first"
+        self.model, self.B, self.H, self.W = model, B, H, W
+        self.dev = model.flat.device
+        self.lib = L.load()
+        x = torch.zeros((B, model.cfg.input_channels, H, W), device=self.dev)
+        self.plan = model._plan_for(x)
+        model._ensure_grad_views()
+        self.sup = model.cfg.supervised_seg
+        self.gt = {"full": torch.zeros((B, 1, H, W), device=self.dev), "half": torch.zeros((B, 1, H // 2, W // 2), device=self.dev),
+                   "quarter": torch.zeros((B, 1, H // 4, W // 4), device=self.dev),
+                   "seg": torch.zeros((B, H, W), dtype=torch.int64, device=self.dev)}
+        self.acc = torch.zeros(16, device=self.dev)     # 4 x (sum, count, sum sq, -) for full/half/quarter/ce
+        self.update_interval = update_interval
+        self.sync = GradSync(model, group)
+        self.world = self.sync.world
+        # optimizer state over the flat buffers
+        n = model.flat.numel()
+        self.m, self.v, self.pg = (torch.zeros(n, device=self.dev) for _ in range(3))
+        nt = len(model._names)
+        self.egn, self.nsq, self.fac = (torch.zeros(nt, device=self.dev) for _ in range(3))
+        seg, b2s, b2c = [], [], []
+        for t, (name, o) in enumerate(zip(model._names, model._offsets)):
+            numel = model._param(name).numel()
+            seg.append([o, o + numel])
+            for c in range((numel + _CHUNK - 1) // _CHUNK):
+                b2s.append(t)
+                b2c.append(c)
+        self.seg = torch.tensor(seg, dtype=torch.int64, device=self.dev)
+        self.b2s = torch.tensor(b2s, dtype=torch.int32, device=self.dev)
+        self.b2c = torch.tensor(b2c, dtype=torch.int32, device=self.dev)
+        self.nt, self.nblk = nt, len(b2s)
+        self.hp = torch.zeros(8, device=self.dev)
+        self.hp_ring = [torch.zeros(8).pin_memory() for _ in range(64)]
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.schedule, self.step_count = schedule, 0
+        self.use_graph = use_graph
+        self.graphs = None
+
+    # ------------------------------------------------------------------ pieces of one step
+    def _forward_and_loss_partials(self):
+        p, st = self.plan, L.stream
+        self.model.flat_grad.zero_()
+        self.acc.zero_()
+        p.forward()
+        for i, (j, key) in enumerate(((5, "full"), (4, "half"), (3, "quarter"))):
+            pred, tgt = p.out_depth[j].t, self.gt[key]
+            L.check(self.lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), pred.numel(), self.acc.data_ptr() + 16 * i, st()),
+                    "crd_masked_l1_fwd")
+        if self.sup:
+            L.check(self.lib.crd_ce_fwd(p.seg_out.data_ptr(), self.gt["seg"].data_ptr(), self.B, self.model.cfg.num_classes,
+                                        self.H * self.W, self.acc.data_ptr() + 48, st()), "crd_ce_fwd")
+
+    def _loss_backward(self):
+        p, st = self.plan, L.stream
+        scale = 1.0 / sum(LOSS_W) / self.update_interval
+        for i, (j, key) in enumerate(((5, "full"), (4, "half"), (3, "quarter"))):
+            pred, tgt, d = p.out_depth[j].t, self.gt[key], p.out_depth[("grad", j)].t
+            L.check(self.lib.crd_masked_l1_bwd(pred.data_ptr(), tgt.data_ptr(), pred.numel(), self.acc.data_ptr() + 16 * i, None,
+                                               LOSS_W[i] * scale, d.data_ptr(), st()), "crd_masked_l1_bwd")
+        if self.sup:
+            L.check(self.lib.crd_ce_focal_bwd(p.seg_out.data_ptr(), self.gt["seg"].data_ptr(), self.B, self.model.cfg.num_classes,
+                                              self.H * self.W, self.acc.data_ptr() + 48, None, LOSS_W[3] * scale,
+                                              p.seg_grad_in.data_ptr(), st()), "crd_ce_focal_bwd")
+
+    def _optimizer(self):
+        m = self.model
+        L.check(self.lib.crd_diffgradnorm_step(m.flat.data_ptr(), m.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
+                                               self.pg.data_ptr(), self.egn.data_ptr(), self.nsq.data_ptr(), self.fac.data_ptr(),
+                                               self.seg.data_ptr(), self.b2s.data_ptr(), self.b2c.data_ptr(), self.nt, self.nblk,
+                                               None, 0.0, 0.0, 0.0, 0.0, 0.0, 1, self.hp.data_ptr(), L.stream()),
+                "crd_diffgradnorm_step")
+
+    def _segments(self):
+        """The step as a list of (callable, bucket-to-launch-after | None | 'loss')."""
+        segs = [(self._forward_and_loss_partials, "loss")]
+        first = True
+        for key in GradSync.ORDER:
+            def run(key=key, first=first):
+                if first:
+                    self._loss_backward()
+                self.plan.backward(tags=key)
+            segs.append((run, key))
+            first = False
+        segs.append((self._optimizer, None))
+        return segs
+
+    def _capture(self):
+        self.graphs = []
+        # warm up eagerly once on a side stream (allocator, lazy module loading) before capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for fn, _ in self._segments():
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        # undo the warm-up's parameter update side effects on the optimizer state
+        for t in (self.m, self.v, self.pg, self.egn, self.nsq, self.fac):
+            t.zero_()
+        for fn, after in self._segments():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                fn()
+            self.graphs.append((g, after))
+
+    def set_batch(self, batch):
+        self.plan.x_in.copy_(batch["image"], non_blocking=True)
+        self.gt["full"].copy_(batch["gt_full"], non_blocking=True)
+        self.gt["half"].copy_(batch["gt_half"], non_blocking=True)
+        self.gt["quarter"].copy_(batch["gt_quarter"], non_blocking=True)
+        if "seg" in batch:
+            self.gt["seg"].copy_(batch["seg"], non_blocking=True)
+
+    def step(self):
+        """One optimizer step on the batch currently in the static input buffers (set_batch)."""
+        self.step_count += 1
+        lr, b1 = (self.schedule[min(self.step_count - 1, len(self.schedule) - 1)] if self.schedule else (self.lr, self.betas[0]))
+        b2 = self.betas[1]
+        bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+        hp_host = self.hp_ring[self.step_count % len(self.hp_ring)]   # ring: the async copy may still be pending
+        hp_host[0], hp_host[1], hp_host[2], hp_host[3] = b1, b2, self.eps, self.wd
+        hp_host[4] = lr * math.sqrt(bc2) / (bc1 + 1e-8)
+        self.hp.copy_(hp_host, non_blocking=True)
+        if self.use_graph and self.graphs is None:
+            params = self.model.flat.clone()
+            self._capture()
+            self.model.flat.copy_(params)          # capture warm-up must not count as a training step
+        runs = self.graphs if self.use_graph else [(None, a) for _, a in self._segments()]
+        fns = None if self.use_graph else [f for f, _ in self._segments()]
+        for i, (g, after) in enumerate(runs):
+            if g is not None:
+                g.replay()
+            else:
+                fns[i]()
+            if after == "loss":
+                if self.world > 1:
+                    dist.all_reduce(self.acc, group=self.sync.group)
+            elif after is not None:
+                self.sync.launch(after)
+                if i == len(runs) - 2:
+                    self.sync.wait()
+
+    def losses(self):
+        """Host view of the last step's loss terms (synchronises)."""
+        a = self.acc.cpu()
+        full, half, quarter = (float(a[4 * i] / a[4 * i + 1]) for i in range(3))
+        rmse = math.sqrt(float(a[2] / a[1]))
+        seg = 0.0
+        if self.sup:
+            ce = float(a[12] / a[13])
+            seg = (1 - math.exp(-ce)) ** 2 * ce
+        total = (LOSS_W[0] * full + LOSS_W[1] * half + LOSS_W[2] * quarter + LOSS_W[3] * seg) / sum(LOSS_W) / self.update_interval
+        return {"loss": total, "full": full, "half": half, "quarter": quarter, "seg": seg, "rmse": rmse}

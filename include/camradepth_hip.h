@@ -237,12 +237,14 @@ int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int3
  * blk2chunk[w] (4096 elements) of tensor blk2seg[w].  exp_grad_norm / norm_sq / factor are
  * float[n_tensors] (norm_sq must be zero on entry and is left zero).  active[t]=0 skips tensor t
  * (`p.grad is None`, :54-55).  `step` is the 1-based step count used for the bias corrections.
+ * hp_dev (optional, device float[5] = beta1, beta2, eps, weight_decay, lr*sqrt(1-beta2^t)/(1-beta1^t+1e-8))
+ * overrides the scalar arguments so that a captured HIP graph can follow a per-iteration schedule.
  * ------------------------------------------------------------------------------------------- */
 int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, float* prev_grad,
                           float* exp_grad_norm, float* norm_sq, float* factor, const int64_t* seg_off,
                           const int32_t* blk2seg, const int32_t* blk2chunk, int32_t n_tensors, int32_t n_blocks,
                           const uint8_t* active, float lr, float beta1, float beta2, float eps, float weight_decay,
-                          int32_t step, crd_stream_t stream);
+                          int32_t step, const float* hp_dev, crd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,80 @@
+"""Data-parallel plumbing on CPU with the gloo backend (world_size 2): bucket layout of the flat gradient buffer,
+SUM all-reduce semantics, and the global masked-mean bookkeeping of the losses.
+No HIP kernel runs here; the GPU path is exercised by bench.py under torchrun."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from camradepth_amd.model import CamRaDepth
+        from camradepth_amd.trainer import GradSync
+        from camradepth_amd.losses import _allreduce_acc
+        torch.manual_seed(0)
+        m = CamRaDepth(input_channels=7, depths=(1, 1, 1, 1))      # parameters live in one flat CPU buffer
+        m._ensure_grad_views()
+        sync = GradSync(m)
+        assert sync.world == world
+        # buckets tile the flat buffer exactly, in backward order
+        spans = sorted(sync.ranges.values())
+        assert spans[0][0] == 0 and spans[-1][1] == m.flat.numel()
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        lo, hi = sync.ranges[("dec",)]
+        assert m._offsets[m._index["from_encoder_1.model.0.weight"]] == lo
+        assert m._offsets[m._index["dest_encoder.block4.0.mlp1.norm2.bias"]] < lo
+        # rank-dependent gradients -> SUM over ranks, identical on every rank
+        m.flat_grad.copy_(torch.arange(m.flat.numel(), dtype=torch.float32) * (rank + 1) * 1e-6)
+        sync.after_backward()
+        expect = torch.arange(m.flat.numel(), dtype=torch.float32) * 1e-6 * sum(r + 1 for r in range(world))
+        ok = torch.allclose(m.flat_grad, expect, rtol=1e-6)
+        g = m._param("depth_activation_5.conv_2.bias").grad          # param.grad is a view of the reduced buffer
+        ok = ok and torch.allclose(g, expect[m._offsets[m._index["depth_activation_5.conv_2.bias"]]:][:1])
+        # global masked mean: (sum, count) partials are summed across ranks before the division
+        acc = torch.tensor([2.0 * (rank + 1), 3.0 + rank, 0.0, 0.0])
+        _allreduce_acc(acc)
+        ok = ok and float(acc[0] / acc[1]) == pytest.approx((2.0 + 4.0) / (3.0 + 4.0))
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradsync_and_global_loss_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_one_cycle_schedule_matches_torch():
+    from camradepth_amd.trainer import one_cycle
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=6e-5, betas=(0.9, 0.999))
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=6e-5, total_steps=50, div_factor=2, pct_start=0.15)
+    mine = one_cycle(50, 6e-5)
+    for i in range(49):
+        assert opt.param_groups[0]["lr"] == pytest.approx(mine[i][0], rel=1e-9)
+        assert opt.param_groups[0]["betas"][0] == pytest.approx(mine[i][1], rel=1e-9)
+        opt.step()
+        sched.step()

@@ -365,7 +365,7 @@ def test_diffgradnorm_matches_golden_trajectory():
         gb = torch.randn(10000, generator=g) * (0.02 if 10 <= it < 14 else 1.0)
         grads = torch.cat([torch.from_numpy(gd[f"p{j}_grads"][it]).reshape(-1) for j in range(3)] + [gb]).cuda()
         ok(lb.crd_diffgradnorm_step(P(flat), P(grads), P(m), P(v), P(pg), P(egn), P(nsq), P(fac), P(seg), P(b2s_d), P(b2c_d),
-                                    4, len(b2s), None, lr, b1, b2, 1e-8, 0.0, it + 1, lib.stream()), "dgn")
+                                    4, len(b2s), None, lr, b1, b2, 1e-8, 0.0, it + 1, None, lib.stream()), "dgn")
         ooptim.step_tensor(big_ref, gb, big_state, lr, b1, b2)
         fc = flat.cpu()
         for j in range(3):

@@ -1,0 +1,43 @@
+"""Developer tool: per-launch HIP-event timing of one training step (eager), grouped by C-ABI entry point and by op."""
+import sys, collections
+sys.path.insert(0, ".")
+import torch
+from camradepth_amd import synth, lib as L
+from camradepth_amd.model import CamRaDepth
+from camradepth_amd.trainer import TrainStep
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+variant = sys.argv[2] if len(sys.argv) > 2 else "base"
+model = CamRaDepth(input_channels=7, supervised_seg=(variant == "supervised_seg")).cuda().train()
+ts = TrainStep(model, B, 256, 416, use_graph=False)
+batch = synth.make_batch(B, 256, 416, seed=1234)
+ts.set_batch({k: v.cuda() for k, v in batch.items()})
+for _ in range(2):
+    ts.step()
+torch.cuda.synchronize()
+plan, st = ts.plan, L.stream()
+rec = []
+for rep in range(3):
+    ts._forward_and_loss_partials(); ts._loss_backward(); plan.zb_arena.zero_(); plan.zf_arena.zero_()
+    for phase, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
+        evs = []
+        for i, op in enumerate(ops):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); op.fn(*op.args, st); e1.record()
+            evs.append((phase, i, op, e0, e1))
+        torch.cuda.synchronize()
+        if rep == 2:
+            rec += [(ph, i, op, e0.elapsed_time(e1)) for ph, i, op, e0, e1 in evs]
+tot = sum(r[3] for r in rec)
+print(f"total per-op time {tot:.2f} ms over {len(rec)} launches (fwd {sum(r[3] for r in rec if r[0]=='fwd'):.2f}, bwd {sum(r[3] for r in rec if r[0]=='bwd'):.2f})")
+by = collections.defaultdict(lambda: [0, 0.0])
+for ph, i, op, ms in rec:
+    k = op.name + (" " + op.meta["kernel"] if op.meta else "")
+    by[k][0] += 1; by[k][1] += ms
+for k, v in sorted(by.items(), key=lambda kv: -kv[1][1]):
+    print(f"  {v[1]:8.3f} ms {v[0]:5d}x  {k}")
+print("top ops:")
+for ph, i, op, ms in sorted(rec, key=lambda r: -r[3])[:45]:
+    extra = ""
+    if op.meta:
+        extra = f"{op.meta['shape']}  {op.meta['flops'] / ms / 1e9:.0f} TF/s"
+    print(f"  {ms:7.3f} ms {ph} #{i:4d} {op.name} {extra}")

@@ -252,6 +252,131 @@ __global__ __launch_bounds__(TPB) void k_sigmoid_bwd(const bf16_t* a, bf16_t* da
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Depth_Activation.conv_2 (utils.py:283,288): 3x3, 32 -> 1 channel.  A GEMM tile would be 1/32 full, so this is a
+// stencil-reduce: 4 lanes per pixel (8 channels each), weights in registers, HBM-bound on the 32-channel input.
+// w is the reference layout fp32 [1][32][3][3] (index c*9 + tap), rounded to bf16 on load like autocast does.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void k_head2_fwd(const bf16_t* a, const float* w, const float* bias, int H, int W,
+                                                   float* depth, bf16_t* copy, int copy_ld) {
+  const int b = blockIdx.y, q = threadIdx.x & 3;
+  float wv[9][8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[t][j] = bf_round(w[(q * 8 + j) * 9 + t]);
+  const long long pix = ((long long)blockIdx.x * TPB + threadIdx.x) >> 2;
+  const bool ok = pix < (long long)H * W;
+  const int py = ok ? (int)(pix / W) : 0, px = ok ? (int)(pix - (long long)py * W) : 0;
+  const bf16_t* ab = a + (long long)b * H * W * 32 + q * 8;
+  float acc = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = py + ky - 1;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = px + kx - 1;
+      if (ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+        float v[8];
+        load8(ab, ((long long)iy * W + ix) * 32, 0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += v[j] * wv[ky * 3 + kx][j];
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 1);
+  acc += __shfl_xor(acc, 2);
+  if (ok && q == 0) {
+    const float r = bf_round(acc + bias[0]);
+    depth[(long long)b * H * W + pix] = r;
+    if (copy) copy[((long long)b * H * W + pix) * copy_ld] = f2bf(r);
+  }
+}
+
+// dz[p][c] = a(1-a) * sum_tap dy[p - off(tap)] * w[c][tap],  dy = gd (+ add)
+__global__ __launch_bounds__(TPB) void k_head2_bwd_data(const float* gd, const bf16_t* add, int add_ld, const bf16_t* a,
+                                                        const float* w, int H, int W, bf16_t* dz) {
+  const int b = blockIdx.y, q = threadIdx.x & 3;
+  const long long pix = ((long long)blockIdx.x * TPB + threadIdx.x) >> 2;
+  if (pix >= (long long)H * W) return;
+  const int py = (int)(pix / W), px = (int)(pix - (long long)py * W);
+  const float* gb = gd + (long long)b * H * W;
+  const bf16_t* addb = add ? add + (long long)b * H * W * add_ld : nullptr;
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int oy = py + 1 - ky;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ox = px + 1 - kx;
+      if ((unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W) {
+        const long long o = (long long)oy * W + ox;
+        float dyv = gb[o];
+        if (addb) dyv += bf2f(addb[o * add_ld]);
+        dyv = bf_round(dyv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += dyv * bf_round(w[(q * 8 + j) * 9 + ky * 3 + kx]);
+      }
+    }
+  }
+  float av[8];
+  const long long off = ((long long)b * H * W + pix) * 32 + q * 8;
+  load8(a, off, 0, av);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] *= av[j] * (1.f - av[j]);
+  store8_bf16(dz, off, acc);
+}
+
+// dw[c*9 + tap] += sum_p dy[p] * a[p + off(tap)][c] ; db += sum_p dy[p]
+__global__ __launch_bounds__(TPB) void k_head2_wgrad(const float* gd, const bf16_t* add, int add_ld, const bf16_t* a, int H, int W,
+                                                     int chunk, float* dw, float* db) {
+  __shared__ float sm[9 * 32 + 1];
+  for (int i = threadIdx.x; i < 9 * 32 + 1; i += TPB) sm[i] = 0.f;
+  __syncthreads();
+  const int b = blockIdx.y, q = threadIdx.x & 3, pl = threadIdx.x >> 2;
+  const float* gb = gd + (long long)b * H * W;
+  const bf16_t* addb = add ? add + (long long)b * H * W * add_ld : nullptr;
+  const bf16_t* ab = a + (long long)b * H * W * 32 + q * 8;
+  float acc[9][8], bs = 0.f;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  int p0 = blockIdx.x * chunk, p1 = p0 + chunk;
+  if (p1 > H * W) p1 = H * W;
+  for (int pix = p0 + pl; pix < p1; pix += TPB / 4) {
+    const int py = pix / W, px = pix - py * W;
+    float dyv = gb[pix];
+    if (addb) dyv += bf2f(addb[(long long)pix * add_ld]);
+    dyv = bf_round(dyv);
+    if (q == 0) bs += dyv;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = py + ky - 1;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = px + kx - 1;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        float v[8];
+        load8(ab, ((long long)iy * W + ix) * 32, 0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += dyv * v[j];
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) atomicAdd(&sm[t * 32 + q * 8 + j], acc[t][j]);
+  if (q == 0) atomicAdd(&sm[288], bs);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 288; i += TPB) atomicAdd(&dw[(i & 31) * 9 + (i >> 5)], sm[i]);
+  if (threadIdx.x == 0) atomicAdd(db, sm[288]);
+}
+
 inline int blocks_for(long long total) {
   long long n = (total + TPB - 1) / TPB;
   if (n > 4096) n = 4096;
@@ -344,6 +469,35 @@ extern "C" int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, i
                      s_ld, reinterpret_cast<bf16_t*>(dst) + d_coff, d_ld, (long long)rows, C, scale, (long long)rows_per_sample,
                      add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr, add_ld, vec);
   CRD_LAUNCH_CHECK("crd_f32_to_bf16_rows");
+  return CRD_OK;
+}
+
+extern "C" int crd_head_conv2_fwd(const void* a, const float* w, const float* bias, int32_t B, int32_t H, int32_t W, float* depth,
+                                  void* copy, int32_t copy_ld, int32_t copy_coff, crd_stream_t stream) {
+  CRD_CHECK_ARG(a && w && bias && depth, "crd_head_conv2_fwd: null pointer");
+  hipLaunchKernelGGL(k_head2_fwd, dim3((unsigned)cdiv(4ll * H * W, TPB), B), dim3(TPB), 0, as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(a), w, bias, H, W, depth,
+                     copy ? reinterpret_cast<bf16_t*>(copy) + copy_coff : nullptr, copy_ld);
+  CRD_LAUNCH_CHECK("crd_head_conv2_fwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
+                                  int32_t B, int32_t H, int32_t W, void* dz, float* dw, float* dbias, crd_stream_t stream) {
+  CRD_CHECK_ARG(gd && a && w && dz && dw && dbias, "crd_head_conv2_bwd: null pointer");
+  const bf16_t* addp = add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(k_head2_bwd_data, dim3((unsigned)cdiv(4ll * H * W, TPB), B), dim3(TPB), 0, st, gd, addp, add_ld,
+                     reinterpret_cast<const bf16_t*>(a), w, H, W, reinterpret_cast<bf16_t*>(dz));
+  const int P = H * W;
+  int nblk = cdiv(P, 64 * 4);
+  int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  if (nblk > cap) nblk = cap;
+  const int chunk = cdiv(P, nblk);
+  nblk = cdiv(P, chunk);
+  hipLaunchKernelGGL(k_head2_wgrad, dim3(nblk, B), dim3(TPB), 0, st, gd, addp, add_ld, reinterpret_cast<const bf16_t*>(a), H, W, chunk,
+                     dw, dbias);
+  CRD_LAUNCH_CHECK("crd_head_conv2_bwd");
   return CRD_OK;
 }
 

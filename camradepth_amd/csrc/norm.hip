@@ -137,6 +137,15 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(&r[(long long)b * C * 2 + i], sm[i]);
+  // per-group sums S1 = sum_c gamma_c r0, S2 = sum_c gamma_c r1 (stored after the [B][C][2] block of r)
+  const int cpg = 16 * gmul, G = C / cpg;
+  float* rg = r + (long long)gridDim.y * C * 2 + (long long)b * G * 2;
+  for (int gi = threadIdx.x; gi < 2 * G; gi += TPB) {
+    const int grp = gi >> 1, which = gi & 1;
+    float acc = 0.f;
+    for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) acc += gamma[c] * sm[c * 2 + which];
+    atomicAdd(&rg[grp * 2 + which], acc);
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, int x_ld, const void* dy, int dy_f32,
@@ -161,13 +170,8 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
   const int cpg = 16 * gmul;
   const float inv_m = 1.f / ((float)P * cpg);
   gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, inv_m, mean, rstd);
-  float S1 = 0.f, S2 = 0.f;
-  for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) {
-    float gm = gamma[c];
-    S1 += gm * r[((long long)b * C + c) * 2];
-    S2 += gm * r[((long long)b * C + c) * 2 + 1];
-  }
-  S1 *= inv_m; S2 *= inv_m;
+  const float* rg = r + (long long)B * C * 2 + ((long long)b * (C / cpg) + grp) * 2;
+  const float S1 = rg[0] * inv_m, S2 = rg[1] * inv_m;
   float ga[8], be[8], mk[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -212,9 +216,9 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
 inline void grid_for(long long P, int C, int B, dim3& grid, int& chunk) {
   int CG = C >> 3;
   int PL = TPB / CG; if (PL < 1) PL = 1;
-  long long per_block = (long long)PL * 16;        // >= 16 pixels per pixel-lane
+  long long per_block = (long long)PL * 4;         // >= 4 pixels per pixel-lane: short dependent-load chains
   long long nblk = (P + per_block - 1) / per_block;
-  long long cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  long long cap = 4096 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   chunk = (int)((P + nblk - 1) / nblk);

@@ -20,6 +20,7 @@ struct WgK {
   long long x_bytes, dy_bytes;
   int chunk;             // pixels per split (multiple of 32)
   float* dw;
+  float* dbias;          // or nullptr; accumulated by the workgroups of the first kf tile
 };
 
 constexpr int PK = 32;  // pixels per K-step
@@ -121,6 +122,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
 #pragma unroll
     for (int j = 0; j < TNc; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0 && t < BMc;
+  float bsum = 0.f;
   gload();
   lstore(0);
   __syncthreads();
@@ -152,9 +155,14 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
 #pragma unroll
       for (int j = 0; j < TNc; ++j)
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    if (do_bias) {       // column sums of the dy tile (rows beyond p_end were loaded as zeros)
+#pragma unroll 8
+      for (int r = 0; r < PK; ++r) bsum += bf2f(sY[cur * PK * LDY + r * LDY + t]);
+    }
     if (kt + 1 < nK) lstore(cur ^ 1);
     __syncthreads();
   }
+  if (do_bias && m0 + t < a.Cout) atomicAdd(a.dbias + m0 + t, bsum);
 
   // D layout (16x16): col = lane&15 -> kf, row = (lane>>4)*4 + r -> co
 #pragma unroll
@@ -220,11 +228,7 @@ extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
   k.dy_bytes = k.P * d->dy_ld * 2;
   CRD_UNSUPPORTED(k.x_bytes < (1ll << 31) && k.dy_bytes < (1ll << 31), "crd_conv_wgrad: tensor too large for 32-bit byte offsets");
   hipStream_t st = as_stream(stream);
-  if (d->dbias) {
-    dim3 grid(cdiv(d->Cout, 64), (unsigned)(k.P >= 4096 ? 64 : (k.P >= 256 ? 8 : 1)));
-    hipLaunchKernelGGL(k_colsum_bf16, grid, dim3(256), 0, st, k.dy, k.dy_ld, k.P, d->Cout, d->dbias);
-    CRD_LAUNCH_CHECK("crd_conv_wgrad(dbias)");
-  }
+  k.dbias = d->dbias;
   if (d->Cout <= 32) return launch<1, 4, 2, 2>(k, st);
   if (d->Cout <= 64) return launch<1, 4, 4, 2>(k, st);
   if (d->Cout <= 96) return launch<2, 2, 3, 4>(k, st);

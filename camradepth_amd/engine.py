@@ -242,7 +242,7 @@ class Plan:
                                               self.p(gname + ".bias"), act, mask, y.t, y.f32, y.ld, y.coff])
 
     def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0):
-        r = self.zb(self.B, x.C, 2)
+        r = self.zb(self.B * x.C * 2 + self.B * (x.C // (16 * gmul)) * 2)
         common = [x.t, x.f32, x.ld, x.coff, dy.t, dy.f32, dy.ld, dy.coff, self.B, x.P, x.C, stats, gmul,
                   self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask]
         self._emit(grp, "crd_gn_bwd_reduce", common + [r])
@@ -411,26 +411,22 @@ class Plan:
             self._cmap = cmap
             c1 = self.new_conv(name + ".conv_1", cmap=cmap)
             self._cmap = None
-            c2 = self.new_conv(name + ".conv_2")
             A = self.act(32, Hj, Wj)
             xin = src.sl(0, len(cmap))
             self.conv(self.fwd, self.conv_desc(xin, c1, 32, 3, 1, 1, Hj, Wj, A, bias=c1.bias, act=1))
             depth = PM(self.new((B, Hj * Wj, 1), F32), 1, Hj, Wj)
-            self.conv(self.fwd, self.conv_desc(A, c2, 1, 3, 1, 1, Hj, Wj, depth, bias=c2.bias))
-            if j < 5:
-                self._emit(self.fwd, "crd_f32_to_bf16_rows", [depth.t, 1, src.t, src.ld, 128, B * Hj * Wj, 1, None, 1, None, 0, 0])
+            w2, b2 = self.p(name + ".conv_2.weight"), self.p(name + ".conv_2.bias")
+            cp = (src.t, src.ld, 128) if j < 5 else (None, 0, 0)
+            self._emit(self.fwd, "crd_head_conv2_fwd", [A.t, w2, b2, B, Hj, Wj, depth.t, cp[0], cp[1], cp[2]])
             self.out_depth[j] = depth
             # backward: dy = loss gradient (fp32 [B,P,1]) [+ d(src[128]) from the next stage]
             gd = PM(self.new((B, Hj * Wj, 1), F32), 1, Hj, Wj)
             self.out_depth[("grad", j)] = gd
-            DY8 = self.act(8, Hj, Wj)
             grp = []
             add = (dsrc.t, dsrc.ld, 128) if j < 5 else (None, 0, 0)
-            self._emit(grp, "crd_f32_to_bf16_rows", [gd.t, 1, DY8.t, 8, 0, B * Hj * Wj, 1, None, 1, add[0], add[1], add[2]])
-            self.wgrad(grp, A, DY8, c2, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_2.bias"))
             dA = self.act(32, Hj, Wj)
-            self.conv(grp, self.conv_desc(DY8, ("dgrad", c2), 32, 3, 1, 1, Hj, Wj, dA, gather=1))
-            self._emit(grp, "crd_sigmoid_bwd", [A.t, dA.t, B * Hj * Wj * 32])
+            self._emit(grp, "crd_head_conv2_bwd", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t,
+                                                   self.g(name + ".conv_2.weight"), self.g(name + ".conv_2.bias")])
             self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_1.bias"))
             self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
                       region=("ds", id(dsrc), 0, 128))

@@ -103,7 +103,8 @@ int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int
                  const float* mask, void* y, int32_t y_f32, int32_t y_ld, int32_t y_coff, crd_stream_t stream);
 
 /* Backward, phase 1: per (b, c) sums  r[b][c] = (sum g, sum g*xhat), g = dy*mask*act'(u),
- * u = xhat*gamma+beta.  dy is bf16 or fp32 pixel-major.  r must be zeroed by the caller. */
+ * u = xhat*gamma+beta, followed by the per-group sums rg[b][grp] = (sum_c gamma_c r[b][c][0], sum_c gamma_c r[b][c][1]).
+ * r is float[B*C*2 + B*(C/(16*gmul))*2], zeroed by the caller.  dy is bf16 or fp32 pixel-major. */
 int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
                       int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
                       int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
@@ -182,6 +183,15 @@ int crd_slice_copy(const void* src, int32_t s_ld, int32_t s_coff, void* dst, int
 int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, int32_t d_ld, int32_t d_coff, int64_t rows,
                          int32_t C, const float* scale, int64_t rows_per_sample, const void* add, int32_t add_ld,
                          int32_t add_coff, crd_stream_t stream);
+/* Depth_Activation.conv_2 (utils.py:283,288): 3x3 conv 32 -> 1 (+bias) as a stencil-reduce.  a: bf16 [B][H][W][32]
+ * (the sigmoid output), w: fp32 reference layout [1][32][3][3], depth: fp32 [B][H][W]; `copy` (optional) receives
+ * the bf16 depth as one channel of a pixel-major buffer (the reference's torch.cat([stage, depth]), CamRaDepth.py:120,146). */
+int crd_head_conv2_fwd(const void* a, const float* w, const float* bias, int32_t B, int32_t H, int32_t W, float* depth,
+                       void* copy, int32_t copy_ld, int32_t copy_coff, crd_stream_t stream);
+/* Backward of the above fused with the sigmoid backward: dy = gd (+ add, a bf16 channel);
+ * dz = a(1-a) * conv2^T(dy) (bf16 [B][H][W][32]); dw[1][32][3][3] += ..., dbias[0] += sum dy (fp32 atomics). */
+int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
+                       int32_t B, int32_t H, int32_t W, void* dz, float* dw, float* dbias, crd_stream_t stream);
 /* da <- da * a * (1-a)   (bf16, n elements, n % 8 == 0): backward of the sigmoid in Depth_Activation */
 int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream);
 

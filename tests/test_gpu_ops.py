@@ -112,7 +112,7 @@ def test_groupnorm_forward_backward(C_, gmul, xf32, act):
     assert_close(yf.cpu().permute(0, 2, 1), yref.detach(), "gn_apply f32", rel=1e-4, elem=1e-4)
     # backward
     dyd = dy.permute(0, 2, 1).contiguous().to(torch.bfloat16).cuda()
-    r = torch.zeros(B, C_, 2, device="cuda")
+    r = torch.zeros(B * C_ * 2 + B * groups * 2, device="cuda")
     ok(lb.crd_gn_bwd_reduce(P(xd), xf32, C_, 0, P(dyd), 0, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(r),
                             lib.stream()), "gn_bwd_reduce")
     dgam, dbet = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")

@@ -318,8 +318,8 @@ extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int
   const int CG = C / 8;
   int PL = TPB / CG; if (PL < 1) PL = 1;
   const int P = H * W;
-  int nblk = cdiv(P, PL * 4);
-  int cap = 4096 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  int nblk = cdiv(P, PL * 8);
+  int cap = 512 / (B > 0 ? B : 1); if (cap < 1) cap = 1;    // every workgroup ends with 10*C global atomics
   if (nblk > cap) nblk = cap;
   int chunk = cdiv(P, nblk);
   nblk = cdiv(P, chunk);

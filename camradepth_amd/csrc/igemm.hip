@@ -30,7 +30,7 @@ template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int A_IT = BM / 32, B_IT = (BN + 31) / 32;   // 32 rows x 8 granules per pass of 256 threads
+  constexpr int A_IT = BM / 32, B_IT = (BN + 31) / 32;   // each wave DMAs 8 rows per instruction, 4 waves -> 32 rows per pass
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BM + BN) * BK];
   bf16_t* sA = lds;
   bf16_t* sB = lds + 2 * BM * BK;
@@ -44,8 +44,13 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
       (void*)(a.x + (long long)b * a.x_bstride), 0, (int)(a.x_bstride * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot * 2, 0x00020000);
   const unsigned OOB = 0x80000000u;
-  const int g = t & 7, r0 = t >> 3;          // granule column, row within a 32-row pass
-  const int swz = (r0 >> 1) & 7;             // (row >> 1) & 7 is the same for row = r0 + 32*i
+  // LDS-DMA staging (buffer_load ... lds): one wave instruction fills 8 consecutive tile rows (8 x 128 B, lane-linear:
+  // lane -> row l>>3, 16-byte slot l&7).  The XOR swizzle that makes the ds_read_b128 fragment reads conflict-free is
+  // applied on the SOURCE side: slot s of row r receives K-granule s ^ ((r>>1)&7).  A thread's rows are 32 apart, so
+  // its swizzle -- and therefore its K-granule and (tap, channel) walk -- is the same for all of them.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const int r0 = 8 * wv + (l >> 3);
+  const int g = (l & 7) ^ ((r0 >> 1) & 7);
 
   int py[A_IT], px[A_IT];
 #pragma unroll
@@ -65,8 +70,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   int kf = g * 8, kc = g * 8, ky = 0, kx = 0;
   while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
 
-  u32x4 ra[A_IT], rb[B_IT];
-  auto gload = [&]() {
+  typedef __attribute__((address_space(3))) void* lds_ptr;
+  auto stage = [&](int buf) {
     const bool kok = kf < a.Ktot;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -81,23 +86,26 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
       }
       ok = ok && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
       const unsigned off = ok ? (unsigned)(((iy * a.IW + ix) * a.x_ld + kc) * 2) : OOB;
-      ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+#if defined(__HIP_DEVICE_COMPILE__)   // (the host pass of hipcc only needs the kernel's signature)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sA + buf * BM * BK + (8 * wv + 32 * i) * BK), 16, off, 0, 0, 0);
+#else
+      (void)off;
+#endif
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) {
-      const unsigned off = kok ? woff[j] + (unsigned)(kf * 2) : OOB;
-      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, off | (woff[j] & OOB), 0, 0);
+      if (8 * wv + 32 * j < BN) {          // wave-uniform
+        const unsigned off = kok ? woff[j] + (unsigned)(kf * 2) : OOB;
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sB + buf * BN * BK + (8 * wv + 32 * j) * BK), 16,
+                                                 off | (woff[j] & OOB), 0, 0, 0);
+#else
+        (void)off;
+#endif
+      }
     }
     kf += BK; kc += BK;
     while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i)
-      *reinterpret_cast<u32x4*>(&sA[buf * BM * BK + (r0 + 32 * i) * BK + ((g ^ swz) << 3)]) = ra[i];
-#pragma unroll
-    for (int j = 0; j < B_IT; ++j)
-      if (r0 + 32 * j < BN) *reinterpret_cast<u32x4*>(&sB[buf * BN * BK + (r0 + 32 * j) * BK + ((g ^ swz) << 3)]) = rb[j];
   };
 
   f32x16 acc[TM][TN];
@@ -109,12 +117,12 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nK = (a.Ktot + BK - 1) / BK;
-  gload();
-  lstore(0);
+  stage(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   for (int kt = 0; kt < nK; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nK) gload();
+    if (kt + 1 < nK) stage(cur ^ 1);        // DMA of the next K-slab runs under this slab's MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[TM], bfr[TN];
@@ -135,7 +143,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (kt + 1 < nK) lstore(cur ^ 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
 
@@ -241,6 +249,11 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   k.res = d->res; k.res_ld = d->res_ld; k.res_bstride = (long long)YH * YW * d->res_ld; k.res_scale = d->res_scale;
   k.accumulate = d->accumulate; k.stats = d->stats; k.G16 = d->Cout / 16;
   hipStream_t st = as_stream(stream);
+  // small problems: 64x64 tiles so that the launch still covers the 256 CUs
+  {
+    const long long big_tiles = (long long)cdiv(k.OHW, 128) * cdiv(d->Cout, 128) * d->B;
+    if (d->Cout > 32 && big_tiles < 192) return launch<2, 2, 1, 1>(k, d->B, st);
+  }
   if (d->Cout <= 32) return launch<4, 1, 1, 1>(k, d->B, st);
   if (d->Cout <= 64) return launch<2, 2, 2, 1>(k, d->B, st);
   if (d->Cout <= 96) return launch<4, 1, 1, 3>(k, d->B, st);

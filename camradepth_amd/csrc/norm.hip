@@ -213,12 +213,14 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
   }
 }
 
-inline void grid_for(long long P, int C, int B, dim3& grid, int& chunk) {
+// reduce=true: kernels that end in per-workgroup global atomics (stats / backward sums) get fewer, longer
+// workgroups on large tensors so that the atomic traffic stays negligible
+inline void grid_for(long long P, int C, int B, dim3& grid, int& chunk, bool reduce = false) {
   int CG = C >> 3;
   int PL = TPB / CG; if (PL < 1) PL = 1;
   long long per_block = (long long)PL * 4;         // >= 4 pixels per pixel-lane: short dependent-load chains
   long long nblk = (P + per_block - 1) / per_block;
-  long long cap = 4096 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  long long cap = (reduce ? 1024 : 4096) / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   chunk = (int)((P + nblk - 1) / nblk);
@@ -245,7 +247,7 @@ extern "C" int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   int rc = check_common("crd_gn_stats", x_ld, x_coff, C, x_f32);
   if (rc) return rc;
   dim3 grid; int chunk;
-  grid_for(P, C, B, grid, chunk);
+  grid_for(P, C, B, grid, chunk, true);
   hipLaunchKernelGGL(k_gn_stats, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream), off_ptr(x, x_f32, x_coff),
                      x_f32, x_ld, (long long)P, C, chunk, stats, chan_sums);
   CRD_LAUNCH_CHECK("crd_gn_stats");
@@ -279,7 +281,7 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
   int rc = check_common("crd_gn_bwd_reduce", x_ld, x_coff, C, x_f32);
   if (rc) return rc;
   dim3 grid; int chunk;
-  grid_for(P, C, B, grid, chunk);
+  grid_for(P, C, B, grid, chunk, true);
   hipLaunchKernelGGL(k_gn_bwd_reduce, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream),
                      off_ptr(x, x_f32, x_coff), x_f32, x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C,
                      chunk, stats, gmul, gamma, beta, act, mask, r);

@@ -56,8 +56,10 @@ class Op:
         self.fn, self.args, self.name, self.region, self.acc_slot, self.meta = fn, args, name, region, acc_slot, meta
 
 
-def igemm_tile(cout):
+def igemm_tile(cout, ohw=1 << 30, batch=1):
     """Tile configuration crd_conv_igemm dispatches to (csrc/igemm.hip), as the kernel's template arguments."""
+    if cout > 32 and -(-ohw // 128) * -(-cout // 128) * batch < 192:
+        return "k_igemm<2,2,1,1>"
     if cout <= 32:
         return "k_igemm<4,1,1,1>"
     if cout <= 64:
@@ -171,7 +173,7 @@ class Plan:
                                                                          cw.cin_ref)
         else:
             flops = 2.0 * self.B * spec["OH"] * spec["OW"] * spec["cout"] * w.cin_ref * w.taps
-        meta = {"kernel": igemm_tile(spec["cout"]), "flops": flops,
+        meta = {"kernel": igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B), "flops": flops,
                 "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
                          f"out{spec['OH']}x{spec['OW']}"}
         op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None, meta)

@@ -1,0 +1,229 @@
+// Halo-tile 3x3 convolution (stride 1, pad 1) on MFMA for gfx950 -- the decoder's ShortResBlock convs, which are
+// ~85 % of the model's FLOPs (src/utils/utils.py:114-124,211), forward and data gradient.
+//
+// The generic implicit-GEMM kernel (igemm.hip) re-gathers every input pixel once per tap and re-reads the weight
+// tensor for every 128-pixel tile; on the big layers that is ~10 GB of L2->LDS traffic per launch and the kernel is
+// bound by it.  Here a workgroup owns an 8 x 32 = 256-pixel 2-D output tile and walks K as (channel chunk of 64) x
+// (9 taps):
+//   * the (8+2) x (32+2) input halo of the chunk is brought into LDS ONCE (LDS-DMA, double buffered, the next
+//     chunk's halo is prefetched in small pieces during taps 1..8) and serves all nine taps -- a tap is just a
+//     different row offset into the halo image;
+//   * the [Cout tile][64] weight slab of each (chunk, tap) is streamed by LDS-DMA, double buffered;
+//   * 8 waves, each a (TM x TN) grid of 32x32 v_mfma_f32_32x32x16_bf16 tiles; one barrier per (chunk, tap).
+// Out-of-image halo pixels, the channel tail and partial tiles are zero-filled by the buffer bounds check, so the
+// hot loop has no branches.  MODE 0: forward (weights [Cout][tap][Cin]); MODE 1: data gradient (weights
+// [Cin][tap][Cout], taps mirrored).  Same argument block and fused epilogue as igemm.hip.
+#include "conv_common.h"
+
+using namespace crdk;
+
+namespace {
+
+constexpr int TH = 8, TW = 32;            // output tile (pixels)
+constexpr int HW_ = TW + 2;               // halo width
+constexpr int HROWS = (TH + 2) * HW_;     // 340 halo pixels
+constexpr int HGROUPS = (HROWS + 7) / 8;  // 43 DMA groups of 8 rows
+constexpr int HPAD = HGROUPS * 8;         // 344 rows allocated
+constexpr int CK = 64;                    // channels per chunk (8 granules, 128-byte LDS rows)
+constexpr int NW = 8;                     // waves per workgroup
+constexpr int HPT = 6;                    // halo groups prefetched per tap (taps 1..8 -> 48 >= 43)
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int WM, int WN, int TM, int TN, int MODE>
+__global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
+  static_assert(WM * WN == NW && WM * TM == TH, "8 waves cover the 8 tile rows");
+  constexpr int BN = WN * TN * 32;
+  constexpr int WGROUPS = BN / 8;         // weight-slab DMA groups
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  bf16_t* sH = lds;                       // [2][HPAD][CK]
+  bf16_t* sW = lds + 2 * HPAD * CK;       // [2][BN][CK]
+
+  const int t = threadIdx.x, l = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wv / WN, wn = wv % WN;
+  const int b = blockIdx.z, n0 = blockIdx.y * BN;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int ty0 = tyi * TH, tx0 = txi * TW;
+  const int H = a.IH, W = a.IW;           // stride 1, pad 1: output grid == input grid
+
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.x + (long long)b * a.x_bstride), 0, (int)(a.x_bstride * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot * 2, 0x00020000);
+  const unsigned OOB = 0x80000000u;
+
+  // ---- per-thread DMA descriptors -------------------------------------------------------------------------
+  // Wave roles for staging: waves 0..5 stream the NEXT chunk's halo (HBM latency, ~2 us) and never wait for it until
+  // the chunk boundary; waves 6..7 stream the next tap's weight slab (L2 resident) and wait for it every step.
+  // vmcnt is per wave and in order, so mixing both streams in one wave would make every step pay the HBM latency.
+  // halo: at tap slot s (0..7) wave w < 6 stages group G = 6 s + w: rows 8G + (l>>3), 16-byte slot l&7, which receives
+  // channel granule (l&7) ^ ((row>>1)&7) (source-side swizzle).
+  const bool halo_wave = wv < HPT;
+  unsigned hoff[8];   // byte offset of the pixel (channel 0 of the chunk) or OOB
+  int hch[8];         // channel offset of this lane's granule inside a chunk
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int G = HPT * s + wv;
+    const int hr = 8 * G + (l >> 3);
+    const int hy = hr / HW_, hx = hr - hy * HW_;
+    const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+    const bool ok = halo_wave && G < HGROUPS && hr < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    hch[s] = ((l & 7) ^ ((hr >> 1) & 7)) * 8;
+    hoff[s] = ok ? (unsigned)((iy * W + ix) * a.x_ld * 2) : OOB;
+  }
+  // weight slab: wave 6 stages the even 8-row groups, wave 7 the odd ones: rows n = 8 (2j + wsel) + (l>>3);
+  // (n>>1)&7 = (4 wsel + (l>>4)) & 7 does not depend on j
+  const int wsel = wv - HPT;
+  const int wch = ((l & 7) ^ ((4 * wsel + (l >> 4)) & 7)) * 8;
+  constexpr int WJ = BN / 16;            // groups per weight-loader wave
+  unsigned woff[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) {
+    const int n = 8 * (2 * j + wsel) + (l >> 3), ng = n0 + n;
+    woff[j] = (!halo_wave && ng < a.Cout) ? (unsigned)(ng * a.Ktot * 2) : OOB;
+  }
+  const int Cin = a.Cin;
+  const int nChunks = (Cin + CK - 1) / CK;
+
+  auto stage_halo_piece = [&](int s, int chunk, int buf) {   // s in 0..7, halo waves only
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (HPT * s + wv < HGROUPS) {
+      const int ch = chunk * CK + hch[s];
+      const unsigned off = (ch < Cin) ? hoff[s] + (unsigned)(ch * 2) : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sH + buf * HPAD * CK + (HPT * s + wv) * 8 * CK), 16,
+                                               off | (hoff[s] & OOB), 0, 0, 0);
+    }
+#else
+    (void)s; (void)chunk; (void)buf;
+#endif
+  };
+  auto stage_weights = [&](int chunk, int tap, int buf) {    // weight waves only
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int ch = chunk * CK + wch;
+    const unsigned koff = (unsigned)((tap * Cin + ch) * 2);
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const unsigned off = (ch < Cin) ? woff[j] + koff : OOB;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sW + buf * BN * CK + 8 * (2 * j + wsel) * CK), 16,
+                                               off | (woff[j] & OOB), 0, 0, 0);
+    }
+#else
+    (void)chunk; (void)tap; (void)buf;
+#endif
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: whole halo of chunk 0 + first weight slab
+  if (halo_wave) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) stage_halo_piece(s, 0, 0);
+  } else {
+    stage_weights(0, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  int step = 0;
+  for (int chunk = 0; chunk < nChunks; ++chunk) {
+    const int hb = chunk & 1;
+    int nks = (Cin - chunk * CK + 15) >> 4;
+    if (nks > 4) nks = 4;
+    for (int tap = 0; tap < 9; ++tap, ++step) {
+      const int wb = step & 1;
+      if (a.dbg & 2) {
+      } else if (halo_wave) {            // one piece of the next chunk's halo per tap; lands any time before the chunk ends
+        if (tap < 8 && chunk + 1 < nChunks) stage_halo_piece(tap, chunk + 1, hb ^ 1);
+      } else {                    // next weight slab
+        if (tap < 8) stage_weights(chunk, tap + 1, wb ^ 1);
+        else if (chunk + 1 < nChunks) stage_weights(chunk + 1, 0, wb ^ 1);
+      }
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int oy = (MODE == 0) ? ky : 2 - ky, ox = (MODE == 0) ? kx : 2 - kx;
+      const bf16_t* hbase = sH + hb * HPAD * CK;
+      const bf16_t* wbase = sW + wb * BN * CK;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        if (ks < nks) {
+          bf16x8 af[TM], bfr[TN];
+          const int gi = ks * 2 + (l >> 5);
+#pragma unroll
+          for (int i = 0; i < TM; ++i) {
+            const int hr = (wm * TM + i + oy) * HW_ + (l & 31) + ox;
+            af[i] = *reinterpret_cast<const bf16x8*>(hbase + hr * CK + ((gi ^ ((hr >> 1) & 7)) << 3));
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int row = (wn * TN + j) * 32 + (l & 31);
+            bfr[j] = *reinterpret_cast<const bf16x8*>(wbase + row * CK + ((gi ^ ((row >> 1) & 7)) << 3));
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      // weight waves wait for their (L2-resident) slab every step; halo waves only at the chunk boundary.
+      // Raw s_barrier: __syncthreads() would make every wave drain its DMA queue (vmcnt(0)) here.
+      if ((!halo_wave && !(a.dbg & 1)) || tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  }
+
+  if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(a.y)[0] = 1.f; return; }
+  conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
+                                [&](int i, int rr, bool& valid, int& row) {
+    const int y = ty0 + wm * TM + i, x = tx0 + rr;
+    valid = y < H && x < W;
+    row = y * W + x;
+  }, [&](int rl, bool& valid, int& row) {
+    const int y = ty0 + (rl >> 5), x = tx0 + (rl & 31);
+    valid = y < H && x < W;
+    row = y * W + x;
+  });
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch3(const ConvK& k0, int B, hipStream_t st, long long partial_cap) {
+  constexpr int BN = WN * TN * 32;
+  ConvK k = k0;
+  k.n_tiles = cdiv(k.IW, TW) * cdiv(k.IH, TH);
+  if ((long long)B * k.n_tiles * k.G16 * 2 > partial_cap) k.stats_partial = nullptr;
+  const size_t lds = (size_t)(2 * HPAD * CK + 2 * BN * CK) * sizeof(bf16_t);
+  const int tiles_x = cdiv(k.IW, TW), tiles_y = cdiv(k.IH, TH);
+  dim3 grid(tiles_x * tiles_y, cdiv(k.Cout, BN), B);
+  static bool attr_done[2] = {false, false};
+  if (k.gather_mode == 0) {
+    if (!attr_done[0]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done[0] = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 0>), grid, dim3(512), lds, st, k, tiles_x);
+  } else {
+    if (!attr_done[1]) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      attr_done[1] = true;
+    }
+    hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 1>), grid, dim3(512), lds, st, k, tiles_x);
+  }
+  if (k.stats && k.stats_partial)
+    hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, k.n_tiles, k.G16, k.stats);
+  CRD_LAUNCH_CHECK("crd_conv_igemm(3x3 halo)");
+  return CRD_OK;
+}
+
+}  // namespace
+
+// Called from crd_conv_igemm for 3x3 / stride 1 / pad 1 layers on grids large enough to fill the chip.
+int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_cap) {
+  if (k.Cout <= 32) return launch3<8, 1, 1, 1>(k, B, st, partial_cap);
+  if (k.Cout <= 64) return launch3<4, 2, 2, 1>(k, B, st, partial_cap);
+  if (k.Cout <= 96) return launch3<8, 1, 1, 3>(k, B, st, partial_cap);
+  return launch3<4, 2, 2, 2>(k, B, st, partial_cap);
+}

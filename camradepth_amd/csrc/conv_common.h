@@ -1,0 +1,175 @@
+// Shared pieces of the MFMA convolution kernels (igemm.hip, conv3x3.hip): kernel argument block and the fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace crdk {
+
+struct ConvK {
+  const bf16_t* x; int x_ld; int IH, IW, Cin; long long x_bstride;
+  const bf16_t* w; int Cout, KW, stride, pad, Ktot;
+  int OW, OHW; int gather_mode;
+  void* y; int y_ld; int y_f32; long long y_bstride;
+  int out_mode, patch_k, patch_c, YW;
+  const float* bias; int bias_bstride; int act;
+  const float* res; int res_ld; long long res_bstride; const float* res_scale;
+  int accumulate; float* stats; int G16;
+  float* stats_partial; int n_tiles;   // per-tile partial sums [B][n_tiles][G16][2] (plain stores) or nullptr -> atomics
+  int vec_ok;   // y base/offset 16-byte aligned: the vectorised epilogue may be used
+  int dbg;   // developer experiments only (CRD_DBG env): 1 no weight-DMA wait, 2 no DMA at all, 4 no epilogue
+};
+
+
+// Fused epilogue of one wave's TM x TN grid of 32x32 accumulator tiles (v_mfma_f32_32x32x16 C/D layout: lane l holds
+// column l&31 and rows (r&3) + 8*(r>>2) + 4*(l>>5)).  `pix(i, rr, valid, p)` maps accumulator row rr of row-tile i to the
+// linear output-pixel index p of the image (or valid=false).  Fuses: bias (optionally per image), sigmoid, residual add
+// with per-image scale, fp32/bf16 store or read-modify-write accumulate, patch scatter, GroupNorm partial statistics.
+// `smem` is the kernel's LDS (free after the K loop).  Statistics are reduced across the WM waves that share a column
+// range before they leave the workgroup.  `pix(i, rr, valid, p)` maps accumulator row rr of row-tile i to the output
+// pixel p; `pixrow(row_local, valid, p)` does the same for a row of the whole BM x BN tile (vector store path).
+// Vector path (bf16 output, plain layout): the tile is transposed through LDS so that every thread stores -- or
+// read-modify-writes, for gradient accumulation -- 16 contiguous bytes instead of 64 scattered 2-byte elements.
+template <int TM, int TN, int WM, int WN, typename PixFn, typename PixRowFn>
+__device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][TN], int b, int l, int wm, int wn, int n0,
+                                              int tile, void* smem, PixFn pix, PixRowFn pixrow) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64, LDT = BN + 8;
+  float* red = reinterpret_cast<float*>(smem) + (BM * LDT) / 2;     // behind the bf16 staging tile
+  const bool vec = a.out_mode == 0 && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
+  if (vec) {
+    bf16_t* T = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cl = (wn * TN + j) * 32 + (l & 31), col = n0 + cl;
+      const bool colok = col < a.Cout;
+      const float bias_v = (a.bias && colok) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+          bool valid;
+          int row;
+          pix(i, rr, valid, row);
+          float v = acc[i][j][r] + bias_v;
+          if (a.act == 1) v = sigmoidf_(v);
+          const bf16_t q = f2bf(v);
+          T[((wm * TM + i) * 32 + rr) * LDT + cl] = q;
+          if (valid && colok) { v = bf2f(q); s += v; ss += v * v; }
+        }
+      }
+      if (a.stats) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+        if ((l & 15) == 0 && l < 32) {
+          float* r = red + (((wm * WN + wn) * TN + j) * 2 + (l >> 4)) * 2;
+          r[0] = s; r[1] = ss;
+        }
+      }
+    }
+    __syncthreads();
+    bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
+    constexpr int GPR = BN / 8;
+    for (int idx = threadIdx.x; idx < BM * GPR; idx += NT) {
+      const int rl = idx / GPR, g = idx - rl * GPR;
+      bool valid;
+      int p;
+      pixrow(rl, valid, p);
+      const int col = n0 + g * 8;
+      if (valid && col < a.Cout) {
+        uint4 u = *reinterpret_cast<const uint4*>(T + rl * LDT + g * 8);
+        bf16_t* dst = yb + (long long)p * a.y_ld + col;
+        if (a.accumulate) {
+          const uint4 o = *reinterpret_cast<const uint4*>(dst);
+          u.x = pack_bf2(bf_lo(u.x) + bf_lo(o.x), bf_hi(u.x) + bf_hi(o.x));
+          u.y = pack_bf2(bf_lo(u.y) + bf_lo(o.y), bf_hi(u.y) + bf_hi(o.y));
+          u.z = pack_bf2(bf_lo(u.z) + bf_lo(o.z), bf_hi(u.z) + bf_hi(o.z));
+          u.w = pack_bf2(bf_lo(u.w) + bf_lo(o.w), bf_hi(u.w) + bf_hi(o.w));
+        }
+        *reinterpret_cast<uint4*>(dst) = u;
+      }
+    }
+  } else {
+  const int col0 = n0 + wn * TN * 32;
+  const float rscale = (a.res && a.res_scale) ? a.res_scale[b] : 1.f;
+  char* yb = reinterpret_cast<char*>(a.y) + (long long)b * a.y_bstride * (a.y_f32 ? 4 : 2);
+  const float* resb = a.res ? a.res + (long long)b * a.res_bstride : nullptr;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + j * 32 + (l & 31);
+    const bool colok = col < a.Cout;
+    const float bias_v = (a.bias && colok) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
+    int pky = 0, pkx = 0, pci = col;
+    if (a.out_mode == 1) {
+      int tap = col / a.patch_c;
+      pci = col - tap * a.patch_c;
+      pky = tap / a.patch_k;
+      pkx = tap - pky * a.patch_k;
+    }
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        bool valid;
+        int row;
+        pix(i, rr, valid, row);
+        if (valid && colok) {
+          float v = acc[i][j][r] + bias_v;
+          if (a.act == 1) v = sigmoidf_(v);
+          long long off;
+          if (a.out_mode == 0) off = (long long)row * a.y_ld + col;
+          else {
+            int oy = row / a.OW, ox = row - oy * a.OW;
+            off = ((long long)(oy * a.patch_k + pky) * a.YW + (ox * a.patch_k + pkx)) * a.y_ld + pci;
+          }
+          if (resb) v = resb[(long long)row * a.res_ld + col] + rscale * bf_round(v);
+          if (a.y_f32) {
+            float* p = reinterpret_cast<float*>(yb) + off;
+            if (a.accumulate) v += *p;
+            *p = v;
+          } else {
+            bf16_t* p = reinterpret_cast<bf16_t*>(yb) + off;
+            if (a.accumulate) v += bf2f(*p);
+            bf16_t q = f2bf(v);
+            *p = q;
+            v = bf2f(q);
+          }
+          s += v; ss += v * v;
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+      s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+      if ((l & 15) == 0 && l < 32) {            // lanes 0 and 16: the two 16-channel slabs of this 32-column tile
+        float* r = red + (((wm * WN + wn) * TN + j) * 2 + (l >> 4)) * 2;
+        r[0] = s; r[1] = ss;
+      }
+    }
+  }
+  }   // scalar path
+  if (a.stats) {
+    // one value per (slab, sum|sumsq) of the workgroup's column range: reduce over the WM waves that share it
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < WN * TN * 4) {
+      const int which = t & 1, slab = (t >> 1) % (TN * 2), wn_ = (t >> 1) / (TN * 2);
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(((w * WN + wn_) * TN) * 2 + slab) * 2 + which];
+      const int g = (n0 >> 4) + wn_ * TN * 2 + slab;
+      if (g < a.G16) {
+        if (a.stats_partial) a.stats_partial[(((long long)b * a.n_tiles + tile) * a.G16 + g) * 2 + which] = v;
+        else atomicAdd(a.stats + ((long long)b * a.G16 + g) * 2 + which, v);
+      }
+    }
+  }
+}
+
+// stats[b][g][which] += sum over tiles of the per-tile partials written by conv_epilogue
+__global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, float* stats);
+
+}  // namespace crdk

@@ -7,20 +7,26 @@
 // A-operand rows are gathered on the fly from the pixel-major activation tensor (im2col is never
 // materialised); the 3x3 re-reads are absorbed by the XCD L2.  Tiles are staged through LDS with
 // an XOR swizzle so the ds_read_b128 fragment reads of v_mfma_f32_32x32x16_bf16 are conflict-free.
-#include "common.h"
+#include <stdlib.h>
+#include "conv_common.h"
+
+using namespace crdk;
+int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_cap);   // conv3x3.hip
+
+namespace crdk {
+__global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, float* stats) {
+  const int g = blockIdx.x, b = blockIdx.y;
+  float s = 0.f, ss = 0.f;
+  for (int t = threadIdx.x; t < n_tiles; t += 64) {
+    const float* p = partial + (((long long)b * n_tiles + t) * G16 + g) * 2;
+    s += p[0]; ss += p[1];
+  }
+  s = wave_sum(s); ss = wave_sum(ss);
+  if (threadIdx.x == 0) { stats[((long long)b * G16 + g) * 2] += s; stats[((long long)b * G16 + g) * 2 + 1] += ss; }
+}
+}  // namespace crdk
 
 namespace {
-
-struct ConvK {
-  const bf16_t* x; int x_ld; int IH, IW, Cin; long long x_bstride;
-  const bf16_t* w; int Cout, KW, stride, pad, Ktot;
-  int OW, OHW; int gather_mode;
-  void* y; int y_ld; int y_f32; long long y_bstride;
-  int out_mode, patch_k, patch_c, YW;
-  const float* bias; int bias_bstride; int act;
-  const float* res; int res_ld; long long res_bstride; const float* res_scale;
-  int accumulate; float* stats; int G16;
-};
 
 constexpr int BK = 64;                 // K elements per LDS stage (8 granules of 8 bf16 per row)
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
@@ -147,73 +153,29 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
     __syncthreads();
   }
 
-  // ---- epilogue -------------------------------------------------------------------------------
-  const float rscale = (a.res && a.res_scale) ? a.res_scale[b] : 1.f;
-  char* yb = reinterpret_cast<char*>(a.y) + (long long)b * a.y_bstride * (a.y_f32 ? 4 : 2);
-  const float* resb = a.res ? a.res + (long long)b * a.res_bstride : nullptr;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + (wn * TN + j) * 32 + (l & 31);
-    const bool colok = col < a.Cout;
-    const float bias_v = (a.bias && colok) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
-    int pky = 0, pkx = 0, pci = col;
-    if (a.out_mode == 1) {
-      int tap = col / a.patch_c;
-      pci = col - tap * a.patch_c;
-      pky = tap / a.patch_k;
-      pkx = tap - pky * a.patch_k;
-    }
-    float s = 0.f, ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        if (row < a.OHW && colok) {
-          float v = acc[i][j][r] + bias_v;
-          if (a.act == 1) v = sigmoidf_(v);
-          long long off;
-          if (a.out_mode == 0) off = (long long)row * a.y_ld + col;
-          else {
-            int oy = row / a.OW, ox = row - oy * a.OW;
-            off = ((long long)(oy * a.patch_k + pky) * a.YW + (ox * a.patch_k + pkx)) * a.y_ld + pci;
-          }
-          if (resb) v = resb[(long long)row * a.res_ld + col] + rscale * bf_round(v);
-          if (a.y_f32) {
-            float* p = reinterpret_cast<float*>(yb) + off;
-            if (a.accumulate) v += *p;
-            *p = v;
-          } else {
-            bf16_t* p = reinterpret_cast<bf16_t*>(yb) + off;
-            if (a.accumulate) v += bf2f(*p);
-            bf16_t q = f2bf(v);
-            *p = q;
-            v = bf2f(q);
-          }
-          s += v; ss += v * v;
-        }
-      }
-    }
-    if (a.stats) {
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-      s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-      if ((l & 15) == 0 && l < 32 && colok) {
-        float* st = a.stats + ((long long)b * a.G16 + (col >> 4)) * 2;
-        atomicAdd(st, s);
-        atomicAdd(st + 1, ss);
-      }
-    }
-  }
+  // ---- epilogue (conv_common.h) ----
+  conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
+                                [&](int i, int rr, bool& valid, int& row) {
+    row = m0 + (wm * TM + i) * 32 + rr;
+    valid = row < a.OHW;
+  }, [&](int rl, bool& valid, int& row) {
+    row = m0 + rl;
+    valid = row < a.OHW;
+  });
 }
 
 template <int WM, int WN, int TM, int TN>
-int launch(const ConvK& k, int B, hipStream_t st) {
+int launch(const ConvK& k0, int B, hipStream_t st, long long partial_cap) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  dim3 grid(cdiv(k.OHW, BM), cdiv(k.Cout, BN), B);
+  ConvK k = k0;
+  k.n_tiles = cdiv(k.OHW, BM);
+  if ((long long)B * k.n_tiles * k.G16 * 2 > partial_cap) k.stats_partial = nullptr;
+  dim3 grid(k.n_tiles, cdiv(k.Cout, BN), B);
   if (k.gather_mode == 0) hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 0>), grid, dim3(256), 0, st, k);
   else if (k.stride == 1) hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, k);
   else hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, k);
+  if (k.stats && k.stats_partial)
+    hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, k.n_tiles, k.G16, k.stats);
   CRD_LAUNCH_CHECK("crd_conv_igemm");
   return CRD_OK;
 }
@@ -248,15 +210,23 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   k.bias = d->bias; k.bias_bstride = d->bias_bstride; k.act = d->act;
   k.res = d->res; k.res_ld = d->res_ld; k.res_bstride = (long long)YH * YW * d->res_ld; k.res_scale = d->res_scale;
   k.accumulate = d->accumulate; k.stats = d->stats; k.G16 = d->Cout / 16;
+  k.stats_partial = d->stats ? d->stats_partial : nullptr; k.n_tiles = 0;
+  k.vec_ok = (d->y_coff % 8 == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0);
+  const long long pcap = d->stats_partial ? d->stats_partial_capacity : 0;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   hipStream_t st = as_stream(stream);
+  // 3x3 / stride 1 / pad 1 on grids at least one tile wide: halo-tile kernel (conv3x3.hip)
+  if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == 0 && d->IH == d->OH && d->IW == d->OW &&
+      d->IW >= 32 && d->IH >= 8)
+    return crd_conv3x3_halo(k, d->B, st, pcap);
   // small problems: 64x64 tiles so that the launch still covers the 256 CUs
   {
     const long long big_tiles = (long long)cdiv(k.OHW, 128) * cdiv(d->Cout, 128) * d->B;
-    if (d->Cout > 32 && big_tiles < 192) return launch<2, 2, 1, 1>(k, d->B, st);
+    if (d->Cout > 32 && big_tiles < 192) return launch<2, 2, 1, 1>(k, d->B, st, pcap);
   }
-  if (d->Cout <= 32) return launch<4, 1, 1, 1>(k, d->B, st);
-  if (d->Cout <= 64) return launch<2, 2, 2, 1>(k, d->B, st);
-  if (d->Cout <= 96) return launch<4, 1, 1, 3>(k, d->B, st);
-  if (d->Cout > 128 && d->Cout <= 160) return launch<4, 1, 1, 5>(k, d->B, st);
-  return launch<2, 2, 2, 2>(k, d->B, st);
+  if (d->Cout <= 32) return launch<4, 1, 1, 1>(k, d->B, st, pcap);
+  if (d->Cout <= 64) return launch<2, 2, 2, 1>(k, d->B, st, pcap);
+  if (d->Cout <= 96) return launch<4, 1, 1, 3>(k, d->B, st, pcap);
+  if (d->Cout > 128 && d->Cout <= 160) return launch<4, 1, 1, 5>(k, d->B, st, pcap);
+  return launch<2, 2, 2, 2>(k, d->B, st, pcap);
 }

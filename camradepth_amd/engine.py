@@ -71,6 +71,17 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
     return "k_igemm<2,2,2,2>"
 
 
+def halo_tile(cout):
+    """Tile configuration of the halo-tile 3x3 kernel (csrc/conv3x3.hip)."""
+    if cout <= 32:
+        return "k_conv3x3<8,1,1,1>"
+    if cout <= 64:
+        return "k_conv3x3<4,2,2,1>"
+    if cout <= 96:
+        return "k_conv3x3<8,1,1,3>"
+    return "k_conv3x3<4,2,2,2>"
+
+
 def wgrad_tile(cout):
     if cout <= 32:
         return "k_wgrad<1,4,2,2>"
@@ -173,7 +184,9 @@ class Plan:
                                                                          cw.cin_ref)
         else:
             flops = 2.0 * self.B * spec["OH"] * spec["OW"] * spec["cout"] * w.cin_ref * w.taps
-        meta = {"kernel": igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B), "flops": flops,
+        halo = spec["k"] == 3 and spec["stride"] == 1 and spec["out_mode"] == 0 and spec["OW"] >= 32 and spec["OH"] >= 8
+        kname = halo_tile(spec["cout"]) if halo else igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B)
+        meta = {"kernel": kname, "flops": flops,
                 "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
                          f"out{spec['OH']}x{spec['OW']}"}
         op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None, meta)
@@ -218,6 +231,8 @@ class Plan:
             res = sp["res"]
             d.res, d.res_ld, d.res_scale = P(res), (res.ld if res is not None else 0), P(sp["res_scale"])
             d.accumulate, d.stats = sp["accumulate"], P(sp["stats"])
+            if sp["stats"] is not None:
+                d.stats_partial, d.stats_partial_capacity = self.stats_scratch.data_ptr(), self.stats_scratch.numel()
         self.keep.append(d)
         return C.byref(d)
 
@@ -666,6 +681,13 @@ class Plan:
             max_elems = max(max_elems, 9 * hid)
         self.pack_table = _struct_table(entries, dev)
         self.n_pack, self.max_pack = len(entries), max_elems
+        # scratch for per-tile GroupNorm partial sums of the conv epilogues (largest requirement over all convs)
+        need = 1024
+        for op in self.fwd:
+            if op.name == "crd_conv_igemm" and op.args[0].get("stats") is not None:
+                sp = op.args[0]
+                need = max(need, self.B * (-(-(sp["OH"] * sp["OW"]) // 64)) * (sp["cout"] // 16) * 2)
+        self.stats_scratch = self.new((need,), F32)
         # zero arenas
         self.zf_arena = self._materialise(self._zf_views)
         self.zb_arena = self._materialise(self._zb_views)

@@ -28,6 +28,7 @@ class ConvDesc(C.Structure):
         ("bias", C.c_void_p), ("bias_bstride", C.c_int32), ("act", C.c_int32),
         ("res", C.c_void_p), ("res_ld", C.c_int32), ("res_scale", C.c_void_p),
         ("accumulate", C.c_int32), ("stats", C.c_void_p),
+        ("stats_partial", C.c_void_p), ("stats_partial_capacity", C.c_int64),
     ]
 
 

@@ -68,6 +68,9 @@ typedef struct {
   const float* res_scale; /* [B] or NULL (=1) */
   int32_t accumulate;           /* 1: y += v (read-modify-write in y's dtype) */
   float* stats;       /* [B][Cout/16][2] += (sum, sum of squares) of the ROUNDED outputs, or NULL */
+  float* stats_partial;           /* optional scratch: per-tile partial sums are written here with plain stores and
+                                     folded into `stats` by a small second kernel (avoids contended atomics) */
+  int64_t stats_partial_capacity; /* floats available in stats_partial; needs B*ceil(OH*OW/64)*(Cout/16)*2 */
 } crd_conv_desc;
 
 int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);

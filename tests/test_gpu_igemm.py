@@ -40,7 +40,7 @@ def pack_w(w, cin_pad=None):
 
 def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, OH, OW, y, y_ld, y_coff, y_f32=0,
              gather_mode=0, out_mode=0, patch_k=0, patch_c=0, bias=None, act=0, res=None, res_ld=0, res_scale=None,
-             accumulate=0, stats=None):
+             accumulate=0, stats=None, partial=None):
     lib = _lib()
     L = lib.load()
     d = lib.ConvDesc()
@@ -56,6 +56,8 @@ def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, O
     d.res_scale = res_scale.data_ptr() if res_scale is not None else None
     d.accumulate = accumulate
     d.stats = stats.data_ptr() if stats is not None else None
+    if partial is not None:
+        d.stats_partial, d.stats_partial_capacity = partial.data_ptr(), partial.numel()
     lib.check(L.crd_conv_igemm(C.byref(d), lib.stream()), "crd_conv_igemm")
     torch.cuda.synchronize()
 
@@ -84,6 +86,13 @@ CASES = [
     (3, 256, 256, 4, 7, 256, 1, 1, 0),
     (2, 64, 64, 20, 26, 512, 1, 1, 0),
     (1, 640, 640, 6, 7, 160, 1, 1, 0),
+    # 3x3 / stride 1 on grids >= 32 wide: halo-tile kernel (conv3x3.hip), all Cout tile variants, ragged borders
+    (2, 136, 136, 19, 45, 96, 3, 1, 1),
+    (1, 232, 232, 8, 64, 64, 3, 1, 1),
+    (2, 296, 304, 33, 70, 128, 3, 1, 1),
+    (1, 129, 136, 17, 40, 32, 3, 1, 1),
+    (2, 128, 128, 9, 33, 21, 3, 1, 1),
+    (1, 48, 48, 40, 32, 128, 3, 1, 1),
 ]
 
 
@@ -101,8 +110,10 @@ def test_conv_forward(case):
     ld_y = ((Co + 7) // 8) * 8 + 8
     y = torch.zeros(B, OH, OW, ld_y, dtype=torch.bfloat16, device="cuda")
     stats = torch.zeros(B, Co // 16, 2, device="cuda") if Co % 16 == 0 else None
+    # odd-sized cases use the atomic statistics path, the others the per-tile partials + finalize path
+    partial = torch.full((B * (-(-OH * OW // 64)) * max(Co // 16, 1) * 2,), 7.0, device="cuda") if (H * W) % 2 == 0 else None
     run_conv(xpm, Cp + 16, 8, B, H, W, Cp, wp, Co, k, k, s, p, OH, OW, y, ld_y, 8 if Co % 8 == 0 else 0,
-             bias=bias.cuda(), stats=stats)
+             bias=bias.cuda(), stats=stats, partial=partial)
     coff = 8 if Co % 8 == 0 else 0
     got = y[..., coff:coff + Co].float().cpu().permute(0, 3, 1, 2)
     assert_close(got, ref, f"conv {case}")
@@ -148,6 +159,9 @@ DGRAD_CASES = [
     (1, 64, 16, 24, 128, 3, 2, 1),
     (2, 128, 9, 13, 160, 3, 2, 1),
     (2, 64, 10, 10, 64, 1, 1, 0),
+    (2, 304, 19, 45, 128, 3, 1, 1),      # halo-tile kernel, data-gradient mode (mirrored taps), 3 N tiles
+    (1, 144, 17, 40, 96, 3, 1, 1),
+    (1, 128, 9, 64, 32, 3, 1, 1),
 ]
 
 

@@ -1,0 +1,30 @@
+"""Developer microbench: one conv layer through crd_conv_igemm, N launches (for rocprofv3 --pmc runs)."""
+import sys, ctypes as C
+sys.path.insert(0, ".")
+import torch
+from camradepth_amd import lib
+B, H, W, Cin, Cout = 8, 256, 416, 304, 128
+mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+L = lib.load()
+x = (torch.randn(B, H * W, Cin, device="cuda") * 0.5).to(torch.bfloat16)
+w = (torch.randn(Cout, 9, Cin, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16)
+y = torch.zeros(B, H * W, Cout, dtype=torch.bfloat16, device="cuda")
+stats = torch.zeros(B, Cout // 16, 2, device="cuda")
+d = lib.ConvDesc()
+d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x.data_ptr(), Cin, 0, B, H, W, Cin
+d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = w.data_ptr(), Cout, 3, 3, 1, 1, H, W
+d.gather_mode = mode
+d.y, d.y_ld, d.y_coff, d.y_f32 = y.data_ptr(), Cout, 0, 0
+d.stats = stats.data_ptr() if len(sys.argv) <= 3 else None
+for _ in range(3):
+    lib.check(L.crd_conv_igemm(C.byref(d), lib.stream()), "conv")
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(reps):
+    L.crd_conv_igemm(C.byref(d), lib.stream())
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+print(f"conv {Cin}->{Cout} 3x3 @{H}x{W} B{B}: {ms:.3f} ms, {2.0 * B * H * W * Cout * Cin * 9 / ms / 1e9:.0f} TFLOP/s")

@@ -21,18 +21,17 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
     __syncthreads();
   }
   const long long total = (long long)H * W * CG;
-  const long long idx = (long long)blockIdx.x * TPB + threadIdx.x;
-  float s = 0.f, ss = 0.f;
-  int cg = 0;
-  if (idx < total) {
-    cg = (int)(idx % CG);
+  const bf16_t* xb = x + (long long)b * H * W * C;
+  // grid-stride: a workgroup keeps its statistics in LDS over all its items and flushes them once, so the number of
+  // global atomics is (#workgroups x C/8) instead of one pair per 256 items
+  for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
+    const int cg = (int)(idx % CG);
     const int pix = (int)(idx / CG);
     const int py = pix / W, px = pix - py * W;
     const int c0 = cg * 8;
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c0 + j] : 0.f;
-    const bf16_t* xb = x + (long long)b * H * W * C;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = py + ky - 1;
@@ -53,12 +52,14 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
     u.x = pack_bf2(acc[0], acc[1]); u.y = pack_bf2(acc[2], acc[3]); u.z = pack_bf2(acc[4], acc[5]); u.w = pack_bf2(acc[6], acc[7]);
     *reinterpret_cast<uint4*>(y + ((long long)b * H * W + pix) * C + c0) = u;
     if (stats) {
+      float s = 0.f, ss = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { float q = bf_round(acc[j]); s += q; ss += q * q; }
+      atomicAdd(&sm[(cg >> 1) * 2], s);
+      atomicAdd(&sm[(cg >> 1) * 2 + 1], ss);
     }
   }
   if (stats) {
-    if (idx < total) { atomicAdd(&sm[(cg >> 1) * 2], s); atomicAdd(&sm[(cg >> 1) * 2 + 1], ss); }
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * G16; i += TPB)
       if (sm[i] != 0.f) atomicAdd(&stats[(long long)b * G16 * 2 + i], sm[i]);
@@ -304,7 +305,10 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
   CRD_CHECK_ARG(x && w9 && y, "crd_dwconv3x3: null pointer");
   CRD_CHECK_ARG(C % 16 == 0, "crd_dwconv3x3: C must be a multiple of 16");
   const long long total = (long long)H * W * (C / 8);
-  dim3 grid((unsigned)cdiv(total, TPB), B);
+  long long nblk = cdiv(total, TPB);
+  const long long cap = (stats ? 2048 : 8192) / (B > 0 ? B : 1);     // with statistics: few, long workgroups (one flush each)
+  if (nblk > cap) nblk = cap > 0 ? cap : 1;
+  dim3 grid((unsigned)nblk, B);
   hipLaunchKernelGGL(k_dwconv, grid, dim3(TPB), stats ? (C / 16) * 2 * sizeof(float) : 0, as_stream(stream),
                      reinterpret_cast<const bf16_t*>(x), H, W, C, w9, bias, flip, reinterpret_cast<bf16_t*>(y), stats);
   CRD_LAUNCH_CHECK("crd_dwconv3x3");

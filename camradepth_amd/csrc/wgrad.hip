@@ -8,7 +8,10 @@
 // transposing LDS read: a 16-lane group fetches a 4x16 block and lane i receives column i),
 // which costs the same as a plain read and removes any explicit transpose.  The pixel range is
 // split across workgroups (split-K); partial tiles are combined with fp32 atomics.
+#include <stdlib.h>
 #include "common.h"
+
+int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st);   // wgrad3x3.hip
 
 namespace {
 
@@ -21,9 +24,10 @@ struct WgK {
   int chunk;             // pixels per split (multiple of 32)
   float* dw;
   float* dbias;          // or nullptr; accumulated by the workgroups of the first kf tile
+  int dbg;               // developer experiments (CRD_DBG): 1 skip output atomics, 2 skip loads
 };
 
-constexpr int PK = 32;  // pixels per K-step
+constexpr int PK = 64;  // pixels per K-step (two 32-pixel MFMA sub-steps)
 
 __device__ __forceinline__ s16x4 tr_read(const bf16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -37,6 +41,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
   constexpr int LDY = BMc + 16, LDX = BNk + 16;
   constexpr int GY = BMc / 8;                       // 16-byte granules per dy row
   constexpr int Y_IT = (PK * GY + 255) / 256;
+  constexpr int X_IT = PK / 16;                      // 16 granules per row, 16 rows per pass of 256 threads
   __shared__ __attribute__((aligned(16))) bf16_t lds[2 * PK * (LDY + LDX)];
   bf16_t* sY = lds;
   bf16_t* sX = lds + 2 * PK * LDY;
@@ -62,10 +67,10 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
   const bool kok = kf < a.Ktot;
   const int tap = kf / a.Cin, kc = kf - tap * a.Cin;
   const int ky = tap / a.KW, kx = tap - ky * a.KW;
-  int xb[2], xoy[2], xox[2];
+  int xb[X_IT], xoy[X_IT], xox[X_IT];
   const int OHW = a.OH * a.OW;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < X_IT; ++i) {
     long long p = p_begin + xr0 + 16 * i;
     int b = (int)(p / OHW);
     int rem = (int)(p - (long long)b * OHW);
@@ -82,12 +87,12 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
     yok[i] = idx < PK * GY && (m0 + yc[i] * 8) < a.Cout;
   }
 
-  u32x4 rx[2], ry[Y_IT];
+  u32x4 rx[X_IT], ry[Y_IT];
   int kt_load = 0;
   auto gload = [&]() {
     const long long pbase = p_begin + (long long)kt_load * PK;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < X_IT; ++i) {
       const long long p = pbase + xr0 + 16 * i;
       const int iy = xoy[i] * a.stride - a.pad + ky, ix = xox[i] * a.stride - a.pad + kx;
       const bool ok = kok && p < p_end && (unsigned)iy < (unsigned)a.IH && (unsigned)ix < (unsigned)a.IW;
@@ -101,7 +106,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
       ry[i] = __builtin_amdgcn_raw_buffer_load_b128(rys, off, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < X_IT; ++i) {
       xox[i] += PK;
       while (xox[i] >= a.OW) { xox[i] -= a.OW; if (++xoy[i] == a.OH) { xoy[i] = 0; ++xb[i]; } }
     }
@@ -109,7 +114,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
   };
   auto lstore = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < X_IT; ++i)
       *reinterpret_cast<u32x4*>(&sX[buf * PK * LDX + (xr0 + 16 * i) * LDX + xg * 8]) = rx[i];
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i)
@@ -132,29 +137,32 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
   const int q = l >> 4, prow = (l & 15) >> 2, pcol = (l & 3) * 4;
   for (int kt = 0; kt < nK; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nK) gload();
-    bf16x8 af[TMc], bfr[TNc];
+    if (kt + 1 < nK && !(a.dbg & 2)) gload();
 #pragma unroll
-    for (int i = 0; i < TMc; ++i) {
-      const bf16_t* base = &sY[cur * PK * LDY + (8 * q + prow) * LDY + (wm * TMc + i) * 16 + pcol];
-      s16x4 lo = tr_read(base), hi = tr_read(base + 4 * LDY);
-      union { bf16x8 v; s16x4 h[2]; } u;
-      u.h[0] = lo; u.h[1] = hi;
-      af[i] = u.v;
+    for (int sub = 0; sub < PK / 32; ++sub) {
+      bf16x8 af[TMc], bfr[TNc];
+#pragma unroll
+      for (int i = 0; i < TMc; ++i) {
+        const bf16_t* base = &sY[cur * PK * LDY + (32 * sub + 8 * q + prow) * LDY + (wm * TMc + i) * 16 + pcol];
+        s16x4 lo = tr_read(base), hi = tr_read(base + 4 * LDY);
+        union { bf16x8 v; s16x4 h[2]; } u;
+        u.h[0] = lo; u.h[1] = hi;
+        af[i] = u.v;
+      }
+#pragma unroll
+      for (int j = 0; j < TNc; ++j) {
+        const bf16_t* base = &sX[cur * PK * LDX + (32 * sub + 8 * q + prow) * LDX + (wn * TNc + j) * 16 + pcol];
+        s16x4 lo = tr_read(base), hi = tr_read(base + 4 * LDX);
+        union { bf16x8 v; s16x4 h[2]; } u;
+        u.h[0] = lo; u.h[1] = hi;
+        bfr[j] = u.v;
+      }
+#pragma unroll
+      for (int i = 0; i < TMc; ++i)
+#pragma unroll
+        for (int j = 0; j < TNc; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-#pragma unroll
-    for (int j = 0; j < TNc; ++j) {
-      const bf16_t* base = &sX[cur * PK * LDX + (8 * q + prow) * LDX + (wn * TNc + j) * 16 + pcol];
-      s16x4 lo = tr_read(base), hi = tr_read(base + 4 * LDX);
-      union { bf16x8 v; s16x4 h[2]; } u;
-      u.h[0] = lo; u.h[1] = hi;
-      bfr[j] = u.v;
-    }
-#pragma unroll
-    for (int i = 0; i < TMc; ++i)
-#pragma unroll
-      for (int j = 0; j < TNc; ++j)
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     if (do_bias) {       // column sums of the dy tile (rows beyond p_end were loaded as zeros)
 #pragma unroll 8
       for (int r = 0; r < PK; ++r) bsum += bf2f(sY[cur * PK * LDY + r * LDY + t]);
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = m0 + (wm * TMc + i) * 16 + (l >> 4) * 4 + r;
-        if (co < a.Cout && kfo < a.Ktot) atomicAdd(a.dw + (long long)co * a.Ktot + kfo, acc[i][j][r]);
+        if (co < a.Cout && kfo < a.Ktot && (!(a.dbg & 1) || acc[i][j][r] == 123.456f)) atomicAdd(a.dw + (long long)co * a.Ktot + kfo, acc[i][j][r]);
       }
     }
 }
@@ -198,7 +206,7 @@ int launch(const WgK& k0, hipStream_t st) {
   const int tn = cdiv(k.Ktot, BNk), tm = cdiv(k.Cout, BMc);
   long long steps = (k.P + PK - 1) / PK;
   long long want = (1536 + tn * tm - 1) / (tn * tm);        // aim for ~6 workgroups per CU in flight
-  long long max_splits = (steps + 7) / 8;                   // at least 8 K-steps per workgroup
+  long long max_splits = (steps + 3) / 4;                   // at least 4 K-steps per workgroup
   long long splits = want < 1 ? 1 : want;
   if (splits > max_splits) splits = max_splits;
   if (splits < 1) splits = 1;
@@ -228,7 +236,12 @@ extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
   k.dy_bytes = k.P * d->dy_ld * 2;
   CRD_UNSUPPORTED(k.x_bytes < (1ll << 31) && k.dy_bytes < (1ll << 31), "crd_conv_wgrad: tensor too large for 32-bit byte offsets");
   hipStream_t st = as_stream(stream);
+  // 3x3 / stride 1 / pad 1 on grids at least one 32-pixel strip wide: streaming halo-row kernel (wgrad3x3.hip)
+  if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IH == d->OH && d->IW == d->OW && d->IW >= 32 &&
+      d->IH >= 8 && !getenv("CRD_NO_WGRAD3"))
+    return crd_wgrad3x3_stream(d, st);
   k.dbias = d->dbias;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   if (d->Cout <= 32) return launch<1, 4, 2, 2>(k, st);
   if (d->Cout <= 64) return launch<1, 4, 4, 2>(k, st);
   if (d->Cout <= 96) return launch<2, 2, 3, 4>(k, st);

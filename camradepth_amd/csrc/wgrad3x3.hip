@@ -1,0 +1,248 @@
+// Streaming weight gradient of the 3x3 / stride-1 / pad-1 convolutions for gfx950 (the decoder's ShortResBlock convs).
+//
+//   dw[co][tap][ci] += sum_{b,y,x} dy[b,y,x,co] * x[b, y+ky-1, x+kx-1, ci]
+//
+// The generic split-K kernel (wgrad.hip) re-gathers the input once per tap and re-reads dy once per 128-wide (tap,ci)
+// tile: ~9 GB of L2 traffic per launch on the big layers, and it is bound by that.  Here a workgroup owns
+//   * one 64-channel chunk of ci, ALL nine taps and all of Cout  -> 9 x (Cout x 64) fp32 accumulators in registers
+//     (wave w: 16 output channels x 64 ci x 9 taps = 36 v_mfma_f32_16x16x32_bf16 tiles = 144 VGPRs),
+//   * a contiguous range of "strip rows": 32-pixel-wide column strips of the images, walked top to bottom.
+// Each step consumes one 32-pixel output row: its dy row and the three input rows around it come from LDS rings that
+// are filled by LDS-DMA three steps ahead (HBM latency), so every input row is fetched once per strip instead of
+// nine times, and dy once per ci chunk.  Both operands are pixel-major, so MFMA fragments are read with the
+// transposing LDS read ds_read_b64_tr_b16.  Partial results leave the workgroup once, as fp32 atomics.
+#include "common.h"
+
+namespace {
+
+struct Wg3K {
+  const bf16_t* x; int x_ld; int Cin;           // input activations (Cin padded to 8)
+  const bf16_t* dy; int dy_ld; int Cout;
+  int B, H, W;
+  int strips_x;                                  // ceil(W / 32)
+  int rows_per_wg;                               // strip rows per workgroup
+  long long total_rows;                          // B * strips_x * H
+  long long x_bytes, dy_bytes;
+  float* dw; float* dbias;
+};
+
+constexpr int XS = 6, YS = 4;                    // ring slots: input rows / dy rows
+constexpr int XPX = 40;                          // pixels per staged input row (34 used, 5 DMA groups of 8)
+constexpr int XLD = 64;                          // channels per chunk (128-byte LDS rows)
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+// Source-side swizzle of the lane-linear LDS images so that the transposing reads are bank-conflict free: a 16-lane
+// group of ds_read_b64_tr_b16 fetches 4 pixel rows x 32 bytes, a half-wave two such groups 8 rows apart.  The 32-byte
+// unit u of row r is stored at unit u ^ f(r)  (found by exhaustive search over the access pattern; 64 banks x 4 B).
+__device__ __forceinline__ int swz128(int r) { return (r & 3) ^ ((r >> 3) & 1); }            // 128-byte rows (4 units)
+__device__ __forceinline__ int swz256(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }     // 256-byte rows (8 units)
+template <int COT>
+__device__ __forceinline__ int swz_y(int r) { return COT == 128 ? swz256(r) : (COT == 64 ? swz128(r) : 0); }
+
+__device__ __forceinline__ s16x4 tr_read3(const bf16_t* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
+}
+
+// WCO x WCI = 8 waves; a wave owns TCO 16-channel co tiles and NT 16-channel ci tiles of the 64-channel chunk
+// (2 x 2 tiles per wave halve the LDS fragment reads per MFMA compared with 1 x 4)
+template <int WCO, int WCI, int TCO>
+__global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
+  static_assert(WCO * WCI == 8, "8 waves");
+  constexpr int NT = 4 / WCI;
+  constexpr int COT = WCO * TCO * 16;            // channels of dy staged per row (>= Cout)
+  constexpr int YGRP = 32 * COT * 2 / 1024;      // DMA wave-instructions per dy row (1 KiB each)
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  bf16_t* sX = lds;                              // [XS][XPX][XLD]
+  bf16_t* sY = lds + XS * XPX * XLD;             // [YS][32][COT]
+
+  const int t = threadIdx.x, l = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wco = wv / WCI, wci = wv % WCI;
+  const int chunk = blockIdx.y;
+  const int c0 = chunk * XLD;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
+
+  f32x4 acc[9][TCO][NT];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[tp][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // loop-invariant (swizzled) fragment offsets
+  const int q = l >> 4, prow = (l & 15) >> 2, pcol = (l & 3) * 4;
+  int yoff[TCO][2], xoff[3][NT][2];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = 8 * q + prow + 4 * h;
+      yoff[i][h] = r * COT + (((wco * TCO + i) ^ swz_y<COT>(r)) << 4) + pcol;
+    }
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int r = 8 * q + prow + kx + 4 * h;
+        xoff[kx][j][h] = r * XLD + (((wci * NT + j) ^ swz128(r)) << 4) + pcol;
+      }
+  const bool do_bias = a.dbias != nullptr && chunk == 0 && t < a.Cout;
+  float bsum = 0.f;
+
+  long long sr = (long long)blockIdx.x * a.rows_per_wg;
+  long long sr_end = sr + a.rows_per_wg;
+  if (sr_end > a.total_rows) sr_end = a.total_rows;
+
+  // DMA lane roles: input row = 5 wave-instructions (8 pixels x 128 B), issued by waves 0..4;
+  // dy row = YGRP wave-instructions, issued by waves 0..YGRP-1.  lane -> (pixel in group, 16-byte granule)
+  const int xpix = 8 * wv + (l >> 3);            // staged pixel index 0..39 (image x = x0 - 1 + xpix)
+  const int xgr = l & 7;                         // channel granule inside the chunk
+  constexpr int YPPI = 1024 / (COT * 2);         // dy pixels per wave-instruction
+  const int ypix = YPPI * wv + l / (COT / 8);
+  const int ygr = l % (COT / 8);
+
+  while (sr < sr_end) {
+    // ---- one segment: rows [y0, y1) of strip (b, sx) ----
+    const long long strip = sr / a.H;
+    const int y0 = (int)(sr - strip * a.H);
+    long long seg_end = (strip + 1) * a.H;
+    if (seg_end > sr_end) seg_end = sr_end;
+    const int y1 = y0 + (int)(seg_end - sr);
+    const int b = (int)(strip / a.strips_x), sx = (int)(strip - (long long)b * a.strips_x);
+    const int x0 = sx * 32;
+
+    auto issue_x = [&](int h) {                  // input row h (image coords) -> ring slot (h + 1) % XS
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (wv < 5) {
+        const int ix = x0 - 1 + xpix, ch = c0 + ((((xgr >> 1) ^ swz128(xpix)) << 1) | (xgr & 1)) * 8;
+        const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && xpix < 34 && ch < a.Cin;
+        const unsigned off = ok ? (unsigned)((((long long)(b * a.H + h) * a.W + ix) * a.x_ld + ch) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sX + (((h + 1) % XS) * XPX + 8 * wv) * XLD), 16, off, 0, 0, 0);
+      }
+#else
+      (void)h;
+#endif
+    };
+    auto issue_y = [&](int r) {                  // dy row r -> ring slot r % YS (rows >= y1 are zero-filled)
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (wv < YGRP) {
+        const int ix = x0 + ypix, co = ((((ygr >> 1) ^ swz_y<COT>(ypix)) << 1) | (ygr & 1)) * 8;
+        const bool ok = r < y1 && ix < a.W && co < a.Cout;
+        const unsigned off = ok ? (unsigned)((((long long)(b * a.H + r) * a.W + ix) * a.dy_ld + co) * 2) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr)(sY + ((r % YS) * 32 + YPPI * wv) * COT), 16, off, 0, 0, 0);
+      }
+#else
+      (void)r;
+#endif
+    };
+
+    // all waves must be done with the previous segment's LDS data before it is overwritten
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // prologue: input rows y0-1, y0 first, then the three "virtual" steps y0-3 .. y0-1 (each: dy row s+3, input row s+4)
+    issue_x(y0 - 1);
+    issue_x(y0);
+#pragma unroll
+    for (int s = -3; s < 0; ++s) { issue_y(y0 + s + 3); issue_x(y0 + s + 4); }
+
+    for (int y = y0; y < y1; ++y) {
+      // dy row y and input row y+1 were issued three steps ago: at most two steps' worth of DMA may still be in flight
+      if (wv < 5 && wv < YGRP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else if (wv < 5 || wv < YGRP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      issue_y(y + 3);
+      issue_x(y + 4);
+
+      const bf16_t* yrow = sY + (y % YS) * 32 * COT;
+      bf16x8 af[TCO];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) {
+        s16x4 lo = tr_read3(yrow + yoff[i][0]), hi = tr_read3(yrow + yoff[i][1]);
+        union { bf16x8 v; s16x4 h[2]; } u;
+        u.h[0] = lo; u.h[1] = hi;
+        af[i] = u.v;
+      }
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        const bf16_t* xrow = sX + ((y + ky) % XS) * XPX * XLD;      // input row y+ky-1 lives in slot (y+ky) % XS
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            s16x4 lo = tr_read3(xrow + xoff[kx][j][0]), hi = tr_read3(xrow + xoff[kx][j][1]);
+            union { bf16x8 v; s16x4 h[2]; } u;
+            u.h[0] = lo; u.h[1] = hi;
+#pragma unroll
+            for (int i = 0; i < TCO; ++i)
+              acc[ky * 3 + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], u.v, acc[ky * 3 + kx][i][j], 0, 0, 0);
+          }
+        }
+      }
+      if (do_bias) {
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) bsum += bf2f(yrow[r * COT + ((((t >> 4) ^ swz_y<COT>(r)) << 4) | (t & 15))]);
+      }
+    }
+    sr = seg_end;
+  }
+
+  // ---- flush: dw[co][tap][ci] ; D layout: col = lane&15 -> ci, row = (lane>>4)*4 + r -> co ----
+  const int Ktot = 9 * a.Cin;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp)
+#pragma unroll
+    for (int i = 0; i < TCO; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int ci = c0 + (wci * NT + j) * 16 + (l & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int co = (wco * TCO + i) * 16 + (l >> 4) * 4 + r;
+          if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * Ktot + tp * a.Cin + ci, acc[tp][i][j][r]);
+        }
+      }
+  if (do_bias) atomicAdd(a.dbias + t, bsum);
+}
+
+template <int WCO, int WCI, int TCO>
+int launch_w3(const Wg3K& k0, hipStream_t st) {
+  Wg3K k = k0;
+  constexpr int COT = WCO * TCO * 16;
+  const size_t lds = (size_t)(XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
+  const int chunks = cdiv(k.Cin, XLD);
+  int wgs = 512 / chunks;                        // ~2 workgroups per CU in total
+  if (wgs < 1) wgs = 1;
+  if (wgs > k.total_rows / 8) wgs = (int)(k.total_rows / 8 > 0 ? k.total_rows / 8 : 1);
+  k.rows_per_wg = (int)((k.total_rows + wgs - 1) / wgs);
+  wgs = (int)((k.total_rows + k.rows_per_wg - 1) / k.rows_per_wg);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_wgrad3x3<WCO, WCI, TCO>), dim3(wgs, chunks), dim3(512), lds, st, k);
+  CRD_LAUNCH_CHECK("crd_conv_wgrad(3x3 streaming)");
+  return CRD_OK;
+}
+
+}  // namespace
+
+// Called from crd_conv_wgrad for 3x3 / stride 1 / pad 1 layers on grids at least one strip wide.
+int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st) {
+  Wg3K k;
+  k.x = reinterpret_cast<const bf16_t*>(d->x) + d->x_coff; k.x_ld = d->x_ld; k.Cin = d->Cin;
+  k.dy = reinterpret_cast<const bf16_t*>(d->dy) + d->dy_coff; k.dy_ld = d->dy_ld; k.Cout = d->Cout;
+  k.B = d->B; k.H = d->IH; k.W = d->IW;
+  k.strips_x = cdiv(d->IW, 32);
+  k.total_rows = (long long)d->B * k.strips_x * d->IH;
+  k.rows_per_wg = 0;
+  k.x_bytes = (long long)d->B * d->IH * d->IW * d->x_ld * 2;
+  k.dy_bytes = (long long)d->B * d->IH * d->IW * d->dy_ld * 2;
+  k.dw = d->dw; k.dbias = d->dbias;
+  if (d->Cout <= 32) return launch_w3<2, 4, 1>(k, st);
+  if (d->Cout <= 64) return launch_w3<2, 4, 2>(k, st);
+  return launch_w3<4, 2, 2>(k, st);
+}

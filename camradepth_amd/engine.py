@@ -121,6 +121,7 @@ class Plan:
         self.convs = []
         self.keep = []                              # keep ctypes structs / tensors alive
         self.dw_entries, self.dw_grads = [], []
+        self.shapes = {}
         self.buffers = []
         self._build()
 
@@ -196,7 +197,10 @@ class Plan:
     def wgrad(self, lst, x, dy, cw, k, stride, pad, OH, OW, dbias=None, cin=None):
         spec = dict(wg=True, x=x, dy=dy, cw=cw, k=k, stride=stride, pad=pad, OH=OH, OW=OW, dbias=dbias,
                     cin=cin if cin is not None else x.C)
-        meta = {"kernel": wgrad_tile(cw.cout), "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps,
+        stream3 = k == 3 and stride == 1 and OW >= 32 and OH >= 8
+        kname = ("k_wgrad3x3<2,4,1>" if cw.cout <= 32 else "k_wgrad3x3<2,4,2>" if cw.cout <= 64 else "k_wgrad3x3<4,2,2>") if stream3 \
+            else wgrad_tile(cw.cout)
+        meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps,
                 "shape": f"wgrad Cin{spec['cin']} Cout{cw.cout} k{k} s{stride} out{OH}x{OW}"}
         lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta))
 
@@ -255,8 +259,11 @@ class Plan:
 
     # ------------------------------------------------------------------ building blocks
     def gn_fwd(self, x, stats, gmul, gname, act, mask, y):
-        self._emit(self.fwd, "crd_gn_apply", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, gmul, self.p(gname + ".weight"),
-                                              self.p(gname + ".bias"), act, mask, y.t, y.f32, y.ld, y.coff])
+        op = self._emit(self.fwd, "crd_gn_apply", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, gmul,
+                                                   self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask, y.t, y.f32, y.ld,
+                                                   y.coff])
+        op.meta = None
+        self.shapes[id(op)] = f"P{x.P} C{x.C} xf32={x.f32}"
 
     def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0):
         r = self.zb(self.B * x.C * 2 + self.B * (x.C // (16 * gmul)) * 2)

@@ -41,6 +41,14 @@ WG_CASES = [
     (3, 256, 256, 4, 7, 256, 1, 1, 0),
     (2, 64, 64, 40, 52, 512, 1, 1, 0),
     (1, 640, 640, 6, 7, 160, 1, 1, 0),
+    # 3x3 / stride 1 on grids >= 32 wide: streaming halo-row kernel (wgrad3x3.hip); ragged widths, segments crossing
+    # strip and image boundaries, all wave layouts
+    (2, 136, 136, 19, 45, 96, 3, 1, 1),
+    (1, 232, 232, 8, 64, 64, 3, 1, 1),
+    (2, 296, 304, 33, 70, 128, 3, 1, 1),
+    (2, 129, 136, 17, 40, 32, 3, 1, 1),
+    (2, 128, 128, 9, 33, 21, 3, 1, 1),
+    (3, 48, 48, 40, 32, 128, 3, 1, 1),
 ]
 
 

@@ -1,0 +1,24 @@
+"""Developer microbench: one weight-gradient launch (D4 layer 2 shape)."""
+import sys, ctypes as C
+sys.path.insert(0, ".")
+import torch
+from camradepth_amd import lib
+B, H, W, Cin, Cout = 8, 256, 416, 304, 128
+L = lib.load()
+x = (torch.randn(B, H * W, Cin, device="cuda") * 0.5).to(torch.bfloat16)
+dy = (torch.randn(B, H * W, Cout, device="cuda") * 0.5).to(torch.bfloat16)
+dw = torch.zeros(Cout, 9, Cin, device="cuda")
+d = lib.WgradDesc()
+d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x.data_ptr(), Cin, 0, B, H, W, Cin
+d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = dy.data_ptr(), Cout, 0, H, W, Cout
+d.KH, d.KW, d.stride, d.pad, d.dw, d.dbias = 3, 3, 1, 1, dw.data_ptr(), None
+for _ in range(3):
+    lib.check(L.crd_conv_wgrad(C.byref(d), lib.stream()), "wgrad")
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    L.crd_conv_wgrad(C.byref(d), lib.stream())
+e1.record(); torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / 10
+print(f"wgrad {Cin}->{Cout}: {ms:.3f} ms, {2.0 * B * H * W * Cout * Cin * 9 / ms / 1e9:.0f} TFLOP/s")

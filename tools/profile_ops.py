@@ -41,3 +41,7 @@ for ph, i, op, ms in sorted(rec, key=lambda r: -r[3])[:45]:
     if op.meta:
         extra = f"{op.meta['shape']}  {op.meta['flops'] / ms / 1e9:.0f} TF/s"
     print(f"  {ms:7.3f} ms {ph} #{i:4d} {op.name} {extra}")
+
+import json
+with open("gpurun_out/ops_all.json", "w") as f:
+    json.dump([(ph, i, op.name, (op.meta or {}).get("shape", ""), ms) for ph, i, op, ms in rec], f)

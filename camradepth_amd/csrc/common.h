@@ -49,15 +49,39 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
-__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+// two fp32 -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even)
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  f32x2_t v = {lo, hi};
+  bf16x2_t r = __builtin_convertvector(v, bf16x2_t);
+  return *reinterpret_cast<uint32_t*>(&r);
+}
 __device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
 __device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+// Exact (erf) GELU of nn.GELU() -- the libm erff costs ~40 VALU ops and made the GroupNorm+GELU passes VALU-bound.
+// erf via Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 rounding level): one v_rcp, one v_exp, five FMAs;
+// the same exponential e^{-x^2/2} also gives the Gaussian density needed by the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& Phi, float& E) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  E = __expf(-z * z);                                   // = exp(-x^2/2)
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32 (1 ulp); __frcp_rn expands to a full IEEE divide
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * E;
+  Phi = 0.5f * (1.0f + copysignf(erf_abs, x));
 }
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_exact(float x) {
+  float Phi, E;
+  gelu_parts(x, Phi, E);
+  return x * Phi;
+}
+__device__ __forceinline__ float gelu_grad(float x) {
+  float Phi, E;
+  gelu_parts(x, Phi, E);
+  return Phi + x * 0.39894228040143267794f * E;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -68,6 +92,18 @@ __device__ __forceinline__ float wave_sum(float v) {
 // load 8 consecutive channels as floats from a bf16 or fp32 row
 __device__ __forceinline__ void load8(const void* base, int64_t elem_off, int is_f32, float (&v)[8]) {
   if (is_f32) {
+    const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
+    float4 a = p[0], b = p[1];
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
+    uint4 u = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(base) + elem_off);
+    v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
+    v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+  }
+}
+template <int F32>
+__device__ __forceinline__ void load8t(const void* base, long long elem_off, float (&v)[8]) {
+  if (F32) {
     const float4* p = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(base) + elem_off);
     float4 a = p[0], b = p[1];
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;

@@ -7,115 +7,163 @@ namespace {
 constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------------
-// Depthwise 3x3, stride 1, pad 1, pixel-major bf16 [B][H][W][C] (ld = C).  One thread = 8 channels
-// of one pixel; the 3x3 neighbourhood comes from L1/L2 (each line is reused by 9 pixels).
+// Depthwise 3x3, stride 1, pad 1, pixel-major bf16 [B][H][W][C] (ld = C).  Sliding window: one thread owns 8 channels
+// and walks TP consecutive pixels of an image row keeping the 3x3 neighbourhood in registers, so each input pixel is
+// loaded 3 times (once per row it contributes to) instead of 9; weights stay in registers; GroupNorm statistics are
+// accumulated per thread and leave the workgroup once.
 // ------------------------------------------------------------------------------------------------
+constexpr int TP = 8;   // pixels per thread along x
+
+template <bool FLIP, bool STATS>
 __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, int C, const float* w9, const float* bias,
-                                                int flip, bf16_t* y, float* stats) {
+                                                bf16_t* y, float* stats) {
   extern __shared__ float sm[];  // [C/16][2] when stats
   const int b = blockIdx.y;
-  const int CG = C >> 3;
-  const int G16 = C >> 4;
-  if (stats) {
+  const int CG = C >> 3, G16 = C >> 4;
+  if (STATS) {
     for (int i = threadIdx.x; i < 2 * G16; i += TPB) sm[i] = 0.f;
     __syncthreads();
   }
-  const long long total = (long long)H * W * CG;
+  const int segs = (W + TP - 1) / TP;
+  const long long total = (long long)H * segs * CG;
   const bf16_t* xb = x + (long long)b * H * W * C;
-  // grid-stride: a workgroup keeps its statistics in LDS over all its items and flushes them once, so the number of
-  // global atomics is (#workgroups x C/8) instead of one pair per 256 items
+  bf16_t* yb = y + (long long)b * H * W * C;
   for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
     const int cg = (int)(idx % CG);
-    const int pix = (int)(idx / CG);
-    const int py = pix / W, px = pix - py * W;
-    const int c0 = cg * 8;
-    float acc[8];
+    const int rest = (int)(idx / CG);
+    const int seg = rest % segs, py = rest / segs;
+    const int c0 = cg * 8, x0 = seg * TP;
+    float wv[9][8], bv[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = bias ? bias[c0 + j] : 0.f;
+    for (int t = 0; t < 9; ++t) load8t<1>(w9, (long long)(FLIP ? 8 - t : t) * C + c0, wv[t]);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = py + ky - 1;
-      if ((unsigned)iy >= (unsigned)H) continue;
+    for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[c0 + j] : 0.f;
+    float win[3][3][8];   // [row ky][column slot][channel]; column slot rotates with the pixel index
+    auto load_col = [&](int slot, int ix) {
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = px + kx - 1;
-        if ((unsigned)ix >= (unsigned)W) continue;
-        const int tap = flip ? (8 - (ky * 3 + kx)) : (ky * 3 + kx);
-        float v[8], wv[8];
-        load8(xb, ((long long)iy * W + ix) * C + c0, 0, v);
-        load8(w9, (long long)tap * C + c0, 1, wv);
+      for (int ky = 0; ky < 3; ++ky) {
+        const int iy = py + ky - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) load8t<0>(xb, ((long long)iy * W + ix) * C + c0, win[ky][slot]);
+        else {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += v[j] * wv[j];
+          for (int j = 0; j < 8; ++j) win[ky][slot][j] = 0.f;
+        }
+      }
+    };
+    load_col(0, x0 - 1);
+    load_col(1, x0);
+    float s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < TP; ++i) {
+      load_col((i + 2) % 3, x0 + i + 1);
+      if (x0 + i < W) {
+        float acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = bv[j];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const int slot = (i + kx) % 3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += win[ky][slot][j] * wv[ky * 3 + kx][j];
+          }
+        uint4 u;
+        u.x = pack_bf2(acc[0], acc[1]); u.y = pack_bf2(acc[2], acc[3]); u.z = pack_bf2(acc[4], acc[5]); u.w = pack_bf2(acc[6], acc[7]);
+        *reinterpret_cast<uint4*>(yb + ((long long)py * W + x0 + i) * C + c0) = u;
+        if (STATS) {
+          s += bf_lo(u.x) + bf_hi(u.x) + bf_lo(u.y) + bf_hi(u.y) + bf_lo(u.z) + bf_hi(u.z) + bf_lo(u.w) + bf_hi(u.w);
+          ss += bf_lo(u.x) * bf_lo(u.x) + bf_hi(u.x) * bf_hi(u.x) + bf_lo(u.y) * bf_lo(u.y) + bf_hi(u.y) * bf_hi(u.y) +
+                bf_lo(u.z) * bf_lo(u.z) + bf_hi(u.z) * bf_hi(u.z) + bf_lo(u.w) * bf_lo(u.w) + bf_hi(u.w) * bf_hi(u.w);
+        }
       }
     }
-    uint4 u;
-    u.x = pack_bf2(acc[0], acc[1]); u.y = pack_bf2(acc[2], acc[3]); u.z = pack_bf2(acc[4], acc[5]); u.w = pack_bf2(acc[6], acc[7]);
-    *reinterpret_cast<uint4*>(y + ((long long)b * H * W + pix) * C + c0) = u;
-    if (stats) {
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { float q = bf_round(acc[j]); s += q; ss += q * q; }
+    if (STATS) {
       atomicAdd(&sm[(cg >> 1) * 2], s);
       atomicAdd(&sm[(cg >> 1) * 2 + 1], ss);
     }
   }
-  if (stats) {
+  if (STATS) {
     __syncthreads();
     for (int i = threadIdx.x; i < 2 * G16; i += TPB)
       if (sm[i] != 0.f) atomicAdd(&stats[(long long)b * G16 * 2 + i], sm[i]);
   }
 }
 
-// dw9[tap][c] += sum_{b,p} dy[p][c]*x[p+tap][c] ; dbias[c] += sum dy
-__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, int chunk,
+// dw9[tap][c] += sum_{b,p} dy[p][c]*x[p+tap][c] ; dbias[c] += sum dy.  Same sliding window; a thread keeps its 8 channels
+// (blockIdx.y selects a 64-granule channel window, 4 row-lanes per workgroup) so the 80 partial sums stay in registers
+// across all the row segments it visits; one LDS merge and one set of global atomics per workgroup.
+__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int B, int H, int W, int C,
                                                       float* dw9, float* dbias) {
-  extern __shared__ float sm[];  // [10][C]
-  for (int i = threadIdx.x; i < 10 * C; i += TPB) sm[i] = 0.f;
-  __syncthreads();
-  const int b = blockIdx.y;
+  __shared__ float sm[10 * 512];
   const int CG = C >> 3;
-  int PL = TPB / CG; if (PL < 1) PL = 1;
-  const bool active = threadIdx.x < PL * CG;
-  const int cg = threadIdx.x % CG, pl = threadIdx.x / CG, c0 = cg * 8;
-  if (active) {
-    float acc[10][8];
+  const int cgl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  const int cg = blockIdx.y * 64 + cgl;
+  const bool cok = cg < CG;
+  for (int i = threadIdx.x; i < 10 * 512; i += TPB) sm[i] = 0.f;
+  __syncthreads();
+  const int c0 = cg * 8;
+  const int segs = (W + TP - 1) / TP;
+  const long long items = (long long)B * H * segs;
+  float acc[10][8];
 #pragma unroll
-    for (int t = 0; t < 10; ++t)
+  for (int t = 0; t < 10; ++t)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-    const bf16_t* xb = x + (long long)b * H * W * C;
-    const bf16_t* db = dy + (long long)b * H * W * C;
-    int p0 = blockIdx.x * chunk, p1 = p0 + chunk;
-    if (p1 > H * W) p1 = H * W;
-    for (int pix = p0 + pl; pix < p1; pix += PL) {
-      const int py = pix / W, px = pix - py * W;
-      float d[8];
-      load8(db, (long long)pix * C + c0, 0, d);
+    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
+  if (cok) {
+    for (long long it = (long long)blockIdx.x * 4 + lane; it < items; it += (long long)gridDim.x * 4) {
+      const int seg = (int)(it % segs);
+      const long long r2 = it / segs;
+      const int py = (int)(r2 % H), b = (int)(r2 / H);
+      const int x0 = seg * TP;
+      const bf16_t* xb = x + (long long)b * H * W * C;
+      const bf16_t* db = dy + (long long)b * H * W * C;
+      float win[3][3][8];
+      auto load_col = [&](int slot, int ix) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[9][j] += d[j];
+        for (int ky = 0; ky < 3; ++ky) {
+          const int iy = py + ky - 1;
+          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) load8t<0>(xb, ((long long)iy * W + ix) * C + c0, win[ky][slot]);
+          else {
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = py + ky - 1;
-        if ((unsigned)iy >= (unsigned)H) continue;
+            for (int j = 0; j < 8; ++j) win[ky][slot][j] = 0.f;
+          }
+        }
+      };
+      load_col(0, x0 - 1);
+      load_col(1, x0);
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          const int ix = px + kx - 1;
-          if ((unsigned)ix >= (unsigned)W) continue;
-          float v[8];
-          load8(xb, ((long long)iy * W + ix) * C + c0, 0, v);
+      for (int i = 0; i < TP; ++i) {
+        load_col((i + 2) % 3, x0 + i + 1);
+        if (x0 + i < W) {
+          float d[8];
+          load8t<0>(db, ((long long)py * W + x0 + i) * C + c0, d);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += d[j] * v[j];
+          for (int j = 0; j < 8; ++j) acc[9][j] += d[j];
+#pragma unroll
+          for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+              const int slot = (i + kx) % 3;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += d[j] * win[ky][slot][j];
+            }
         }
       }
     }
 #pragma unroll
     for (int t = 0; t < 10; ++t)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&sm[t * C + c0 + j], acc[t][j]);
+      for (int j = 0; j < 8; ++j) atomicAdd(&sm[t * 512 + cgl * 8 + j], acc[t][j]);
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < 9 * C; i += TPB) atomicAdd(&dw9[i], sm[i]);
-  for (int i = threadIdx.x; i < C; i += TPB) atomicAdd(&dbias[i], sm[9 * C + i]);
+  for (int i = threadIdx.x; i < 10 * 512; i += TPB) {
+    const int t = i / 512, cl = i - t * 512, c = blockIdx.y * 512 + cl;
+    if (c < C && sm[i] != 0.f) {
+      if (t < 9) atomicAdd(&dw9[(long long)t * C + c], sm[i]);
+      else atomicAdd(&dbias[c], sm[i]);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -304,13 +352,22 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
                              int32_t flip, void* y, float* stats, crd_stream_t stream) {
   CRD_CHECK_ARG(x && w9 && y, "crd_dwconv3x3: null pointer");
   CRD_CHECK_ARG(C % 16 == 0, "crd_dwconv3x3: C must be a multiple of 16");
-  const long long total = (long long)H * W * (C / 8);
+  const long long total = (long long)H * cdiv(W, TP) * (C / 8);
   long long nblk = cdiv(total, TPB);
-  const long long cap = (stats ? 2048 : 8192) / (B > 0 ? B : 1);     // with statistics: few, long workgroups (one flush each)
+  const long long cap = 4096 / (B > 0 ? B : 1);
   if (nblk > cap) nblk = cap > 0 ? cap : 1;
   dim3 grid((unsigned)nblk, B);
-  hipLaunchKernelGGL(k_dwconv, grid, dim3(TPB), stats ? (C / 16) * 2 * sizeof(float) : 0, as_stream(stream),
-                     reinterpret_cast<const bf16_t*>(x), H, W, C, w9, bias, flip, reinterpret_cast<bf16_t*>(y), stats);
+  const size_t lds = stats ? (C / 16) * 2 * sizeof(float) : 0;
+  const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
+  bf16_t* yp = reinterpret_cast<bf16_t*>(y);
+  hipStream_t st = as_stream(stream);
+  if (flip) {
+    if (stats) hipLaunchKernelGGL((k_dwconv<true, true>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
+    else hipLaunchKernelGGL((k_dwconv<true, false>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
+  } else {
+    if (stats) hipLaunchKernelGGL((k_dwconv<false, true>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
+    else hipLaunchKernelGGL((k_dwconv<false, false>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
+  }
   CRD_LAUNCH_CHECK("crd_dwconv3x3");
   return CRD_OK;
 }
@@ -318,17 +375,15 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
 extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw9,
                                    float* dbias, crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && dw9 && dbias, "crd_dwconv3x3_wgrad: null pointer");
-  CRD_CHECK_ARG(C % 16 == 0 && C <= 2048, "crd_dwconv3x3_wgrad: C must be a multiple of 16, <= 2048");
-  const int CG = C / 8;
-  int PL = TPB / CG; if (PL < 1) PL = 1;
-  const int P = H * W;
-  int nblk = cdiv(P, PL * 8);
-  int cap = 512 / (B > 0 ? B : 1); if (cap < 1) cap = 1;    // every workgroup ends with 10*C global atomics
+  CRD_CHECK_ARG(C % 16 == 0 && C <= 4096, "crd_dwconv3x3_wgrad: C must be a multiple of 16, <= 4096");
+  const int cwin = cdiv(C / 8, 64);                         // 512-channel windows
+  const long long items = (long long)B * H * cdiv(W, TP);
+  long long nblk = cdiv(items, 4 * 2);                     // >= 2 row segments per thread
+  const long long cap = 384 / cwin > 0 ? 384 / cwin : 1;   // each workgroup ends with up to 5120 global atomics
   if (nblk > cap) nblk = cap;
-  int chunk = cdiv(P, nblk);
-  nblk = cdiv(P, chunk);
-  hipLaunchKernelGGL(k_dwconv_wgrad, dim3(nblk, B), dim3(TPB), 10 * C * sizeof(float), as_stream(stream),
-                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), H, W, C, chunk, dw9, dbias);
+  if (nblk < 1) nblk = 1;
+  hipLaunchKernelGGL(k_dwconv_wgrad, dim3((unsigned)nblk, cwin), dim3(TPB), 0, as_stream(stream),
+                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), B, H, W, C, dw9, dbias);
   CRD_LAUNCH_CHECK("crd_dwconv3x3_wgrad");
   return CRD_OK;
 }

@@ -3,11 +3,13 @@
 // / 32-byte fp32 accesses) of a pixel and keeps its channel group fixed while striding over pixels,
 // so per-channel partial sums stay in registers; workgroup partials are merged in LDS and flushed
 // with one global atomic per value.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
 
 constexpr int TPB = 256;
+constexpr int U = 4;   // independent 16-byte loads in flight per thread in the streaming loops
 
 // thread -> (channel granule cg, pixel lane pl); CG = C/8 granules; PL = TPB/CG pixel lanes
 struct Map {
@@ -22,6 +24,7 @@ struct Map {
   }
 };
 
+template <int XF>
 __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
                                                   float* stats, float* chan) {
   extern __shared__ float sm[];  // [C][2]
@@ -35,11 +38,20 @@ __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int 
   if (m.active) {
     long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
     if (p1 > P) p1 = P;
-    for (long long p = p0 + m.pl; p < p1; p += m.PL) {
-      float v[8];
-      load8(x, ((long long)b * P + p) * x_ld + m.cg * 8, x_f32, v);
+    for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {   // U independent loads in flight per thread
+      float v[U][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { s[j] += v[j]; ss[j] += v[j] * v[j]; }
+      for (int u = 0; u < U; ++u) {
+        long long pp = p + (long long)u * m.PL;
+        if (pp >= p1) pp = p1 - 1;
+        load8t<XF>(x, ((long long)b * P + pp) * x_ld + m.cg * 8, v[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + (long long)u * m.PL < p1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { s[j] += v[u][j]; ss[j] += v[u][j] * v[u][j]; }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -60,6 +72,7 @@ __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int 
     }
 }
 
+template <int XF, int YF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
                                                   const float* stats, int gmul, const float* gamma, const float* beta,
                                                   int act, const float* mask, void* y, int y_ld, int y_f32) {
@@ -79,25 +92,37 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
   }
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > P) p1 = P;
-  for (long long p = p0 + m.pl; p < p1; p += m.PL) {
-    float v[8];
-    load8(x, ((long long)b * P + p) * x_ld + c0, x_f32, v);
+  for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
+    float v[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float u = v[j] * ga[j] + be[j];
-      if (act == 1) u = gelu_exact(u);
-      v[j] = u * mk[j];
+    for (int u = 0; u < U; ++u) {
+      long long pp = p + (long long)u * m.PL;
+      if (pp >= p1) pp = p1 - 1;
+      load8t<XF>(x, ((long long)b * P + pp) * x_ld + c0, v[u]);
     }
-    if (y_f32) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + p) * y_ld + c0, v);
-    else store8_bf16(y, ((long long)b * P + p) * y_ld + c0, v);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long pp = p + (long long)u * m.PL;
+      if (pp < p1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float w = v[u][j] * ga[j] + be[j];
+          if (ACT == 1) w = gelu_exact(w);
+          v[u][j] = w * mk[j];
+        }
+        if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, v[u]);
+        else store8_bf16(y, ((long long)b * P + pp) * y_ld + c0, v[u]);
+      }
+    }
   }
 }
 
 // r[b][c] = (sum_p g, sum_p g*xhat), g = dy*mask*act'(u)
+template <int XF, int DF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32, int x_ld, const void* dy, int dy_f32,
                                                        int dy_ld, long long P, int C, int chunk, const float* stats,
                                                        int gmul, const float* gamma, const float* beta, int act,
-                                                       const float* mask, float* r) {
+                                                       const float* mask, float* r, float* partial) {
   extern __shared__ float sm[];  // [C][2]
   const int b = blockIdx.y;
   for (int i = threadIdx.x; i < 2 * C; i += TPB) sm[i] = 0.f;
@@ -117,17 +142,26 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
     }
     long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
     if (p1 > P) p1 = P;
-    for (long long p = p0 + m.pl; p < p1; p += m.PL) {
-      float v[8], d[8];
-      load8(x, ((long long)b * P + p) * x_ld + c0, x_f32, v);
-      load8(dy, ((long long)b * P + p) * dy_ld + c0, dy_f32, d);
+    for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
+      float v[U][8], d[U][8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float xh = (v[j] - mean) * rstd;
-        float g = d[j] * mk[j];
-        if (act == 1) g *= gelu_grad(xh * ga[j] + be[j]);
-        s0[j] += g; s1[j] += g * xh;
+      for (int u = 0; u < U; ++u) {
+        long long pp = p + (long long)u * m.PL;
+        if (pp >= p1) pp = p1 - 1;
+        load8t<XF>(x, ((long long)b * P + pp) * x_ld + c0, v[u]);
+        load8t<DF>(dy, ((long long)b * P + pp) * dy_ld + c0, d[u]);
       }
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (p + (long long)u * m.PL < p1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float xh = (v[u][j] - mean) * rstd;
+            float g = d[u][j] * mk[j];
+            if (ACT == 1) g *= gelu_grad(xh * ga[j] + be[j]);
+            s0[j] += g; s1[j] += g * xh;
+          }
+        }
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -136,6 +170,11 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
     }
   }
   __syncthreads();
+  if (partial) {   // plain stores of this workgroup's sums; k_gn_bwd_finalize folds them (no contended atomics)
+    float* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 2 * C;
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) dst[i] = sm[i];
+    return;
+  }
   for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(&r[(long long)b * C * 2 + i], sm[i]);
   // per-group sums S1 = sum_c gamma_c r0, S2 = sum_c gamma_c r1 (stored after the [B][C][2] block of r)
   const int cpg = 16 * gmul, G = C / cpg;
@@ -148,6 +187,41 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
   }
 }
 
+// r[b][c][0..1] = sum over workgroup partials; rg[b][grp] += sum_c gamma_c r[b][c]  (64 channels per workgroup)
+__global__ __launch_bounds__(TPB) void k_gn_bwd_finalize(const float* partial, int nblk, int C, int gmul, const float* gamma,
+                                                         float* r, int B) {
+  __shared__ float sm[4][64][2];
+  const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C)
+    for (int k = lane; k < nblk; k += 4) {
+      const float* p = partial + ((long long)b * nblk + k) * 2 * C + c * 2;
+      s0 += p[0]; s1 += p[1];
+    }
+  sm[lane][threadIdx.x & 63][0] = s0; sm[lane][threadIdx.x & 63][1] = s1;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    s0 = sm[0][threadIdx.x][0] + sm[1][threadIdx.x][0] + sm[2][threadIdx.x][0] + sm[3][threadIdx.x][0];
+    s1 = sm[0][threadIdx.x][1] + sm[1][threadIdx.x][1] + sm[2][threadIdx.x][1] + sm[3][threadIdx.x][1];
+    r[((long long)b * C + c) * 2] = s0;
+    r[((long long)b * C + c) * 2 + 1] = s1;
+    const float g = gamma[c];
+    sm[0][threadIdx.x][0] = g * s0; sm[0][threadIdx.x][1] = g * s1;
+  }
+  __syncthreads();
+  // group sums: 16-channel slabs of this 64-channel window, added into the group's accumulator
+  if (threadIdx.x < 8) {
+    const int slab = threadIdx.x >> 1, which = threadIdx.x & 1, c0 = blockIdx.x * 64 + slab * 16;
+    if (c0 < C) {
+      float a = 0.f;
+      for (int j = 0; j < 16; ++j) a += sm[0][slab * 16 + j][which];
+      const int cpg = 16 * gmul;
+      atomicAdd(r + (long long)B * C * 2 + ((long long)b * (C / cpg) + c0 / cpg) * 2 + which, a);
+    }
+  }
+}
+
+template <int XF, int DF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, int x_ld, const void* dy, int dy_f32,
                                                       int dy_ld, long long P, int C, int chunk, const float* stats,
                                                       int gmul, const float* gamma, const float* beta, int act,
@@ -180,47 +254,58 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
   }
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > P) p1 = P;
-  for (long long p = p0 + m.pl; p < p1; p += m.PL) {
-    float v[8], d[8], o[8];
-    load8(x, ((long long)b * P + p) * x_ld + c0, x_f32, v);
-    load8(dy, ((long long)b * P + p) * dy_ld + c0, dy_f32, d);
+  for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
+    float v[U][8], d[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float xh = (v[j] - mean) * rstd;
-      float g = d[j] * mk[j];
-      if (act == 1) g *= gelu_grad(xh * ga[j] + be[j]);
-      o[j] = (ga[j] * g - S1 - xh * S2) * rstd;
+    for (int u = 0; u < U; ++u) {
+      long long pp = p + (long long)u * m.PL;
+      if (pp >= p1) pp = p1 - 1;
+      load8t<XF>(x, ((long long)b * P + pp) * x_ld + c0, v[u]);
+      load8t<DF>(dy, ((long long)b * P + pp) * dy_ld + c0, d[u]);
     }
-    const long long off = ((long long)b * P + p) * dx_ld + c0;
-    if (dx_f32) {
-      float* q = reinterpret_cast<float*>(dx);
-      if (dx_acc) {
-        float w[8];
-        load8(dx, off, 1, w);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] += w[j];
-      }
-      store8_f32(q, off, o);
-    } else {
-      if (dx_acc) {
-        float w[8];
-        load8(dx, off, 0, w);
+    for (int u = 0; u < U; ++u) {
+      const long long pp = p + (long long)u * m.PL;
+      if (pp >= p1) continue;
+      float o[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o[j] += w[j];
+      for (int j = 0; j < 8; ++j) {
+        float xh = (v[u][j] - mean) * rstd;
+        float g = d[u][j] * mk[j];
+        if (ACT == 1) g *= gelu_grad(xh * ga[j] + be[j]);
+        o[j] = (ga[j] * g - S1 - xh * S2) * rstd;
       }
-      store8_bf16(dx, off, o);
+      const long long off = ((long long)b * P + pp) * dx_ld + c0;
+      if (dx_f32) {
+        float* q = reinterpret_cast<float*>(dx);
+        if (dx_acc) {
+          float w[8];
+          load8(dx, off, 1, w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += w[j];
+        }
+        store8_f32(q, off, o);
+      } else {
+        if (dx_acc) {
+          float w[8];
+          load8(dx, off, 0, w);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] += w[j];
+        }
+        store8_bf16(dx, off, o);
+      }
     }
   }
 }
 
-// reduce=true: kernels that end in per-workgroup global atomics (stats / backward sums) get fewer, longer
-// workgroups on large tensors so that the atomic traffic stays negligible
 inline void grid_for(long long P, int C, int B, dim3& grid, int& chunk, bool reduce = false) {
   int CG = C >> 3;
   int PL = TPB / CG; if (PL < 1) PL = 1;
-  long long per_block = (long long)PL * 4;         // >= 4 pixels per pixel-lane: short dependent-load chains
+  long long per_block = (long long)PL * 8;         // >= 8 pixels per pixel-lane (two batches of U loads)
   long long nblk = (P + per_block - 1) / per_block;
-  long long cap = (reduce ? 1024 : 4096) / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  static int cap_r = -1, cap_e = -1;
+  if (cap_r < 0) { const char* e = getenv("CRD_GN_CAP_R"); cap_r = e ? atoi(e) : 1024; e = getenv("CRD_GN_CAP_E"); cap_e = e ? atoi(e) : 4096; }
+  long long cap = (reduce ? cap_r : cap_e) / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   chunk = (int)((P + nblk - 1) / nblk);
@@ -248,8 +333,10 @@ extern "C" int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   if (rc) return rc;
   dim3 grid; int chunk;
   grid_for(P, C, B, grid, chunk, true);
-  hipLaunchKernelGGL(k_gn_stats, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream), off_ptr(x, x_f32, x_coff),
-                     x_f32, x_ld, (long long)P, C, chunk, stats, chan_sums);
+  if (x_f32) hipLaunchKernelGGL(k_gn_stats<1>, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream), off_ptr(x, x_f32, x_coff),
+                                x_f32, x_ld, (long long)P, C, chunk, stats, chan_sums);
+  else hipLaunchKernelGGL(k_gn_stats<0>, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream), off_ptr(x, x_f32, x_coff),
+                          x_f32, x_ld, (long long)P, C, chunk, stats, chan_sums);
   CRD_LAUNCH_CHECK("crd_gn_stats");
   return CRD_OK;
 }
@@ -264,9 +351,18 @@ extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   if (rc) return rc;
   dim3 grid; int chunk;
   grid_for(P, C, B, grid, chunk);
-  hipLaunchKernelGGL(k_gn_apply, grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, x_ld,
-                     (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask,
-                     y_f32 ? (void*)(reinterpret_cast<float*>(y) + y_coff) : (void*)(reinterpret_cast<bf16_t*>(y) + y_coff), y_ld, y_f32);
+  void* yp = y_f32 ? (void*)(reinterpret_cast<float*>(y) + y_coff) : (void*)(reinterpret_cast<bf16_t*>(y) + y_coff);
+#define CRD_GN_APPLY(XF, YF, ACT)                                                                                        \
+  hipLaunchKernelGGL((k_gn_apply<XF, YF, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
+                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, y_f32)
+  const int key = (x_f32 ? 4 : 0) | (y_f32 ? 2 : 0) | (act ? 1 : 0);
+  switch (key) {
+    case 0: CRD_GN_APPLY(0, 0, 0); break;  case 1: CRD_GN_APPLY(0, 0, 1); break;
+    case 2: CRD_GN_APPLY(0, 1, 0); break;  case 3: CRD_GN_APPLY(0, 1, 1); break;
+    case 4: CRD_GN_APPLY(1, 0, 0); break;  case 5: CRD_GN_APPLY(1, 0, 1); break;
+    case 6: CRD_GN_APPLY(1, 1, 0); break;  default: CRD_GN_APPLY(1, 1, 1); break;
+  }
+#undef CRD_GN_APPLY
   CRD_LAUNCH_CHECK("crd_gn_apply");
   return CRD_OK;
 }
@@ -274,7 +370,7 @@ extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
 extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
                                  int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
                                  int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
-                                 float* r, crd_stream_t stream) {
+                                 float* r, float* scratch, int64_t scratch_capacity, crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && stats && gamma && beta && r, "crd_gn_bwd_reduce: null pointer");
   CRD_CHECK_ARG(gmul >= 1 && (C / 16) % gmul == 0, "crd_gn_bwd_reduce: bad gmul");
   CRD_CHECK_ARG(dy_ld % 8 == 0 && dy_coff % 8 == 0, "crd_gn_bwd_reduce: dy_ld/dy_coff must be multiples of 8");
@@ -282,9 +378,21 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
   if (rc) return rc;
   dim3 grid; int chunk;
   grid_for(P, C, B, grid, chunk, true);
-  hipLaunchKernelGGL(k_gn_bwd_reduce, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream),
-                     off_ptr(x, x_f32, x_coff), x_f32, x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C,
-                     chunk, stats, gmul, gamma, beta, act, mask, r);
+  float* part = (scratch && (long long)B * grid.x * 2 * C <= scratch_capacity && grid.x > 1) ? scratch : nullptr;
+#define CRD_GN_RED(XF, DF, ACT)                                                                                              \
+  hipLaunchKernelGGL((k_gn_bwd_reduce<XF, DF, ACT>), grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream),            \
+                     off_ptr(x, x_f32, x_coff), x_f32, x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C, \
+                     chunk, stats, gmul, gamma, beta, act, mask, r, part)
+  switch ((x_f32 ? 4 : 0) | (dy_f32 ? 2 : 0) | (act ? 1 : 0)) {
+    case 0: CRD_GN_RED(0, 0, 0); break;  case 1: CRD_GN_RED(0, 0, 1); break;
+    case 2: CRD_GN_RED(0, 1, 0); break;  case 3: CRD_GN_RED(0, 1, 1); break;
+    case 4: CRD_GN_RED(1, 0, 0); break;  case 5: CRD_GN_RED(1, 0, 1); break;
+    case 6: CRD_GN_RED(1, 1, 0); break;  default: CRD_GN_RED(1, 1, 1); break;
+  }
+#undef CRD_GN_RED
+  if (scratch && (long long)B * grid.x * 2 * C <= scratch_capacity && grid.x > 1)
+    hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(cdiv(C, 64), B), dim3(TPB), 0, as_stream(stream), scratch, (int)grid.x, C, gmul,
+                       gamma, r, B);
   CRD_LAUNCH_CHECK("crd_gn_bwd_reduce");
   return CRD_OK;
 }
@@ -304,9 +412,17 @@ extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int3
   dim3 grid; int chunk;
   grid_for(P, C, B, grid, chunk);
   void* dxp = dx_f32 ? (void*)(reinterpret_cast<float*>(dx) + dx_coff) : (void*)(reinterpret_cast<bf16_t*>(dx) + dx_coff);
-  hipLaunchKernelGGL(k_gn_bwd_apply, grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, x_ld,
-                     off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act,
-                     mask, r, dgamma, dbeta, dxp, dx_f32, dx_ld, dx_accumulate, B);
+#define CRD_GN_BAP(XF, DF, ACT)                                                                                              \
+  hipLaunchKernelGGL((k_gn_bwd_apply<XF, DF, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
+                     x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C, chunk, stats, gmul, gamma, beta,  \
+                     act, mask, r, dgamma, dbeta, dxp, dx_f32, dx_ld, dx_accumulate, B)
+  switch ((x_f32 ? 4 : 0) | (dy_f32 ? 2 : 0) | (act ? 1 : 0)) {
+    case 0: CRD_GN_BAP(0, 0, 0); break;  case 1: CRD_GN_BAP(0, 0, 1); break;
+    case 2: CRD_GN_BAP(0, 1, 0); break;  case 3: CRD_GN_BAP(0, 1, 1); break;
+    case 4: CRD_GN_BAP(1, 0, 0); break;  case 5: CRD_GN_BAP(1, 0, 1); break;
+    case 6: CRD_GN_BAP(1, 1, 0); break;  default: CRD_GN_BAP(1, 1, 1); break;
+  }
+#undef CRD_GN_BAP
   CRD_LAUNCH_CHECK("crd_gn_bwd_apply");
   return CRD_OK;
 }

@@ -209,6 +209,9 @@ int launch(const WgK& k0, hipStream_t st) {
   long long max_splits = (steps + 3) / 4;                   // at least 4 K-steps per workgroup
   long long splits = want < 1 ? 1 : want;
   if (splits > max_splits) splits = max_splits;
+  // every split adds Cout x Ktot fp32 atomics: keep the total around 2M per launch (L2 sustains ~170 G atomics/s)
+  const long long atom_cap = (2ll << 20) / ((long long)k.Cout * k.Ktot) + 1;
+  if (splits > atom_cap) splits = atom_cap;
   if (splits < 1) splits = 1;
   long long chunk_steps = (steps + splits - 1) / splits;
   k.chunk = (int)(chunk_steps * PK);

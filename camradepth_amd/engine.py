@@ -123,6 +123,7 @@ class Plan:
         self.dw_entries, self.dw_grads = [], []
         self.shapes = {}
         self.buffers = []
+        self.gn_scratch = self.new((1024 * 2 * 1024,), F32)     # per-workgroup partial sums of the GN backward reductions
         self._build()
 
     # ------------------------------------------------------------------ allocation helpers
@@ -269,7 +270,7 @@ class Plan:
         r = self.zb(self.B * x.C * 2 + self.B * (x.C // (16 * gmul)) * 2)
         common = [x.t, x.f32, x.ld, x.coff, dy.t, dy.f32, dy.ld, dy.coff, self.B, x.P, x.C, stats, gmul,
                   self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask]
-        self._emit(grp, "crd_gn_bwd_reduce", common + [r])
+        self._emit(grp, "crd_gn_bwd_reduce", common + [r, self.gn_scratch, self.gn_scratch.numel()])
         args = common + [r, self.g(gname + ".weight"), self.g(gname + ".bias"), dx.t, dx.f32, dx.ld, dx.coff, dx_acc]
         self._emit(grp, "crd_gn_bwd_apply", args, region, len(args) - 1 if region else None)
 

@@ -89,7 +89,7 @@ def load():
 _SIGS = {
     "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
-    "crd_gn_bwd_reduce": "piiipiiiiiipippippp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiip",
+    "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiip",
     "crd_dwconv3x3": "piiiippippp", "crd_dwconv3x3_wgrad": "ppiiiippp",
     "crd_attn_scores": "ppiiiiifppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_out_residual": "pppppiiipp",
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifppp",

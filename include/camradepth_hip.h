@@ -107,11 +107,13 @@ int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int
 
 /* Backward, phase 1: per (b, c) sums  r[b][c] = (sum g, sum g*xhat), g = dy*mask*act'(u),
  * u = xhat*gamma+beta, followed by the per-group sums rg[b][grp] = (sum_c gamma_c r[b][c][0], sum_c gamma_c r[b][c][1]).
- * r is float[B*C*2 + B*(C/(16*gmul))*2], zeroed by the caller.  dy is bf16 or fp32 pixel-major. */
+ * r is float[B*C*2 + B*(C/(16*gmul))*2], zeroed by the caller.  dy is bf16 or fp32 pixel-major.
+ * scratch (optional, >= B*1024*2*C floats is always enough): per-workgroup partial sums go there with plain stores and
+ * a second small kernel folds them, instead of ~1M contended atomics on large tensors. */
 int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
                       int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
                       int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
-                      float* r, crd_stream_t stream);
+                      float* r, float* scratch, int64_t scratch_capacity, crd_stream_t stream);
 /* Backward, phase 2: dgamma[c] += sum_b r[b][c][1], dbeta[c] += sum_b r[b][c][0];
  * dx = (gamma*g - mean_grp(gamma*g) - xhat*mean_grp(gamma*g*xhat)) * rstd, written as bf16
  * (dx_f32=0) or ADDED into an fp32 tensor (dx_f32=1, accumulate). */

@@ -34,7 +34,7 @@ __device__ __forceinline__ s16x4 tr_read(const bf16_t* p) {
 }
 
 template <int WMc, int WNc, int TMc, int TNc>
-__global__ __launch_bounds__(256) void k_wgrad(WgK a) {
+__device__ __forceinline__ void wgrad_tile(const WgK& a, const int bx, const int by, const int bz) {
   static_assert(WMc * WNc == 4, "4 waves");
   constexpr int BMc = WMc * TMc * 16, BNk = WNc * TNc * 16;
   static_assert(BNk == 128, "kf tile is 128 wide");
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
 
   const int t = threadIdx.x, l = t & 63, wave = t >> 6;
   const int wm = wave / WNc, wn = wave % WNc;
-  const int n0 = blockIdx.x * BNk, m0 = blockIdx.y * BMc;
-  const long long p_begin = (long long)blockIdx.z * a.chunk;
+  const int n0 = bx * BNk, m0 = by * BMc;
+  const long long p_begin = (long long)bz * a.chunk;
   long long p_end = p_begin + a.chunk;
   if (p_end > a.P) p_end = a.P;
   if (p_begin >= p_end) return;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
 #pragma unroll
     for (int j = 0; j < TNc; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const bool do_bias = a.dbias != nullptr && blockIdx.x == 0 && t < BMc;
+  const bool do_bias = a.dbias != nullptr && bx == 0 && t < BMc;
   float bsum = 0.f;
   gload();
   lstore(0);
@@ -186,6 +186,21 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
     }
 }
 
+template <int WMc, int WNc, int TMc, int TNc>
+__global__ __launch_bounds__(256) void k_wgrad(WgK a) {
+  wgrad_tile<WMc, WNc, TMc, TNc>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: many small weight-gradient problems in ONE dispatch.  items[i] = (problem, kf tile, co tile, split);
+// the problem descriptors live in device memory (built once by crd_wgrad_group_build).  The encoder's ~190 small
+// wgrads are each latency-bound on their own (a few dozen workgroups, 4 serial K-steps); together they fill the chip.
+template <int WMc, int WNc, int TMc, int TNc>
+__global__ __launch_bounds__(256) void k_wgrad_grouped(const WgK* __restrict__ probs, const int4* __restrict__ items) {
+  const int4 it = items[blockIdx.x];
+  const WgK a = probs[it.x];
+  wgrad_tile<WMc, WNc, TMc, TNc>(a, it.y, it.z, it.w);
+}
+
 // dbias[c] += sum over rows of a bf16 [rows][C] slice
 __global__ __launch_bounds__(256) void k_colsum_bf16(const bf16_t* x, int ld, long long rows, int C, float* out) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -199,14 +214,11 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const bf16_t* x, int ld, lo
   if (rl == 0 && c < C) atomicAdd(out + c, sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
 }
 
-template <int WMc, int WNc, int TMc, int TNc>
-int launch(const WgK& k0, hipStream_t st) {
-  WgK k = k0;
-  constexpr int BMc = WMc * TMc * 16, BNk = WNc * TNc * 16;
-  const int tn = cdiv(k.Ktot, BNk), tm = cdiv(k.Cout, BMc);
+// Split-K plan: sets k.chunk, returns the number of splits.  `want` = splits that would fill the chip, `min_steps` =
+// K-steps a workgroup must at least run.
+long long plan_splits(WgK& k, int tiles, long long want, int min_steps) {
   long long steps = (k.P + PK - 1) / PK;
-  long long want = (1536 + tn * tm - 1) / (tn * tm);        // aim for ~6 workgroups per CU in flight
-  long long max_splits = (steps + 3) / 4;                   // at least 4 K-steps per workgroup
+  long long max_splits = (steps + min_steps - 1) / min_steps;
   long long splits = want < 1 ? 1 : want;
   if (splits > max_splits) splits = max_splits;
   // every split adds Cout x Ktot fp32 atomics: keep the total around 2M per launch (L2 sustains ~170 G atomics/s)
@@ -215,35 +227,101 @@ int launch(const WgK& k0, hipStream_t st) {
   if (splits < 1) splits = 1;
   long long chunk_steps = (steps + splits - 1) / splits;
   k.chunk = (int)(chunk_steps * PK);
-  splits = (steps + chunk_steps - 1) / chunk_steps;
+  return (steps + chunk_steps - 1) / chunk_steps;
+}
+
+template <int WMc, int WNc, int TMc, int TNc>
+int launch(const WgK& k0, hipStream_t st) {
+  WgK k = k0;
+  constexpr int BMc = WMc * TMc * 16, BNk = WNc * TNc * 16;
+  const int tn = cdiv(k.Ktot, BNk), tm = cdiv(k.Cout, BMc);
+  const long long splits = plan_splits(k, tn * tm, (1536 + tn * tm - 1) / (tn * tm), 4);   // ~6 workgroups per CU in flight
   dim3 grid(tn, tm, (unsigned)splits);
   hipLaunchKernelGGL((k_wgrad<WMc, WNc, TMc, TNc>), grid, dim3(256), 0, st, k);
   CRD_LAUNCH_CHECK("crd_conv_wgrad");
   return CRD_OK;
 }
 
-}  // namespace
-
-extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
+int fill(const crd_wgrad_desc* d, WgK& k) {
   CRD_CHECK_ARG(d && d->x && d->dy && d->dw, "crd_conv_wgrad: null pointer");
   CRD_CHECK_ARG(d->Cin % 8 == 0 && d->x_ld % 8 == 0 && d->x_coff % 8 == 0, "crd_conv_wgrad: x channels must be multiples of 8");
   CRD_CHECK_ARG(d->dy_ld % 8 == 0 && d->dy_coff % 8 == 0, "crd_conv_wgrad: dy_ld/dy_coff must be multiples of 8");
   CRD_CHECK_ARG(d->Cout % 8 == 0 || d->dy_ld - d->dy_coff >= ((d->Cout + 7) / 8) * 8,
                 "crd_conv_wgrad: dy rows must hold Cout rounded up to 8 channels");
-  WgK k;
   k.x = reinterpret_cast<const bf16_t*>(d->x) + d->x_coff; k.x_ld = d->x_ld; k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin;
   k.dy = reinterpret_cast<const bf16_t*>(d->dy) + d->dy_coff; k.dy_ld = d->dy_ld; k.OH = d->OH; k.OW = d->OW; k.Cout = d->Cout;
   k.KW = d->KW; k.stride = d->stride; k.pad = d->pad; k.Ktot = d->KH * d->KW * d->Cin;
   k.P = (long long)d->B * d->OH * d->OW; k.chunk = 0; k.dw = d->dw;
   k.x_bytes = (long long)d->B * d->IH * d->IW * d->x_ld * 2;
   k.dy_bytes = k.P * d->dy_ld * 2;
+  k.dbias = d->dbias; k.dbg = 0;
   CRD_UNSUPPORTED(k.x_bytes < (1ll << 31) && k.dy_bytes < (1ll << 31), "crd_conv_wgrad: tensor too large for 32-bit byte offsets");
+  return CRD_OK;
+}
+
+// tile configuration of the generic kernel by output-channel count (index into the launch tables)
+int cfg_of(int cout) { return cout <= 32 ? 0 : cout <= 64 ? 1 : cout <= 96 ? 2 : 3; }
+const int CFG_BM[4] = {32, 64, 96, 128};
+
+}  // namespace
+
+extern "C" int crd_wgrad_group_build(const crd_wgrad_desc* descs, int32_t n, void* host_table, int64_t capacity,
+                                     crd_wgrad_group_info* info) {
+  CRD_CHECK_ARG(descs && info && n > 0, "crd_wgrad_group_build: null pointer / empty group");
+  // pass 1: plan every problem, count the work items of each tile configuration
+  const long long head = ((long long)n * sizeof(WgK) + 15) / 16 * 16;
+  long long count[4] = {0, 0, 0, 0};
+  WgK* probs = reinterpret_cast<WgK*>(host_table);
+  for (int pass = 0; pass < 2; ++pass) {
+    long long cursor[4];
+    if (pass == 1) {
+      long long off = 0;
+      for (int c = 0; c < 4; ++c) { info->item_offset[c] = (int32_t)off; info->n_items[c] = (int32_t)count[c]; cursor[c] = off; off += count[c]; }
+      info->n_problems = n;
+      info->bytes = head + off * (long long)sizeof(int4);
+      if (host_table == nullptr || capacity < info->bytes) return CRD_OK;      // size query
+    }
+    for (int i = 0; i < n; ++i) {
+      WgK k;
+      int rc = fill(&descs[i], k);
+      if (rc != CRD_OK) return rc;
+      const int c = cfg_of(k.Cout);
+      const int tn = cdiv(k.Ktot, 128), tm = cdiv(k.Cout, CFG_BM[c]);
+      // the group as a whole fills the chip: long K runs per workgroup (8 steps) keep the atomics per problem low
+      const long long splits = plan_splits(k, tn * tm, 1 << 20, 8);
+      if (pass == 0) { count[c] += (long long)tn * tm * splits; continue; }
+      probs[i] = k;
+      int4* items = reinterpret_cast<int4*>(reinterpret_cast<char*>(host_table) + head);
+      for (long long s = 0; s < splits; ++s)
+        for (int m = 0; m < tm; ++m)
+          for (int t = 0; t < tn; ++t) items[cursor[c]++] = make_int4(i, t, m, (int)s);
+    }
+  }
+  return CRD_OK;
+}
+
+extern "C" int crd_conv_wgrad_grouped(const void* dev_table, const crd_wgrad_group_info* info, crd_stream_t stream) {
+  CRD_CHECK_ARG(dev_table && info, "crd_conv_wgrad_grouped: null pointer");
+  const WgK* probs = reinterpret_cast<const WgK*>(dev_table);
+  const long long head = ((long long)info->n_problems * sizeof(WgK) + 15) / 16 * 16;
+  const int4* items = reinterpret_cast<const int4*>(reinterpret_cast<const char*>(dev_table) + head);
+  hipStream_t st = as_stream(stream);
+  if (info->n_items[0]) hipLaunchKernelGGL((k_wgrad_grouped<1, 4, 2, 2>), dim3(info->n_items[0]), dim3(256), 0, st, probs, items + info->item_offset[0]);
+  if (info->n_items[1]) hipLaunchKernelGGL((k_wgrad_grouped<1, 4, 4, 2>), dim3(info->n_items[1]), dim3(256), 0, st, probs, items + info->item_offset[1]);
+  if (info->n_items[2]) hipLaunchKernelGGL((k_wgrad_grouped<2, 2, 3, 4>), dim3(info->n_items[2]), dim3(256), 0, st, probs, items + info->item_offset[2]);
+  if (info->n_items[3]) hipLaunchKernelGGL((k_wgrad_grouped<2, 2, 4, 4>), dim3(info->n_items[3]), dim3(256), 0, st, probs, items + info->item_offset[3]);
+  CRD_LAUNCH_CHECK("crd_conv_wgrad_grouped");
+  return CRD_OK;
+}
+
+extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
+  WgK k;
+  { int rc = fill(d, k); if (rc != CRD_OK) return rc; }
   hipStream_t st = as_stream(stream);
   // 3x3 / stride 1 / pad 1 on grids at least one 32-pixel strip wide: streaming halo-row kernel (wgrad3x3.hip)
   if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IH == d->OH && d->IW == d->OW && d->IW >= 32 &&
       d->IH >= 8 && !getenv("CRD_NO_WGRAD3"))
     return crd_wgrad3x3_stream(d, st);
-  k.dbias = d->dbias;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   if (d->Cout <= 32) return launch<1, 4, 2, 2>(k, st);
   if (d->Cout <= 64) return launch<1, 4, 4, 2>(k, st);

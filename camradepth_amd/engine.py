@@ -22,6 +22,9 @@ from . import lib as L
 from .config import MID_CHANNELS, UNSUP_CLASSES, ModelConfig
 from .params import short_res_block_plan
 
+# developer switch: CRD_NO_GROUP_WGRAD=1 runs every small weight gradient as its own launch (A/B against the grouped launch)
+GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
+
 BF16, F32 = torch.bfloat16, torch.float32
 
 
@@ -122,6 +125,8 @@ class Plan:
         self.keep = []                              # keep ctypes structs / tensors alive
         self.dw_entries, self.dw_grads = [], []
         self.shapes = {}
+        self.fwd_marks = []
+        self._defer = None
         self.buffers = []
         self.gn_scratch = self.new((1024 * 2 * 1024,), F32)     # per-workgroup partial sums of the GN backward reductions
         self._build()
@@ -203,9 +208,34 @@ class Plan:
             else wgrad_tile(cw.cout)
         meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps,
                 "shape": f"wgrad Cin{spec['cin']} Cout{cw.cout} k{k} s{stride} out{OH}x{OW}"}
+        if self._defer is not None and not stream3:
+            self._defer.append((spec, meta))      # runs in the segment's grouped launch (see flush_deferred)
+            return
         lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta))
 
-    def _make_desc(self, sp):
+    def flush_deferred(self, lst):
+        """Emit ONE grouped weight-gradient launch for every wgrad deferred since `self._defer = []` (the small GEMMs
+        of a stage's blocks).  Their dy operands are per-block buffers, so they are all still valid here."""
+        items, self._defer = self._defer, None
+        if not items:
+            return
+        meta = {"kernel": "k_wgrad_grouped", "flops": sum(m["flops"] for _, m in items), "shape": f"{len(items)} wgrads"}
+        lst.append(Op(self.lib.crd_conv_wgrad_grouped, [{"wg_group": [sp for sp, _ in items]}], "crd_conv_wgrad_grouped", meta=meta))
+
+    def _make_group(self, specs):
+        descs = (L.WgradDesc * len(specs))()
+        for i, sp in enumerate(specs):
+            self._make_desc(sp, into=descs[i])
+        info = L.WgradGroupInfo()
+        L.check(self.lib.crd_wgrad_group_build(descs, len(specs), None, 0, C.byref(info)), "crd_wgrad_group_build")
+        host = (C.c_uint8 * info.bytes)()
+        L.check(self.lib.crd_wgrad_group_build(descs, len(specs), host, info.bytes, C.byref(info)), "crd_wgrad_group_build")
+        table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).to(self.dev)
+        self.buffers.append(table)
+        self.keep.append(info)
+        return [table.data_ptr(), C.byref(info)]
+
+    def _make_desc(self, sp, into=None):
         def P(v):
             if v is None:
                 return None
@@ -214,7 +244,7 @@ class Plan:
             return v.data_ptr()
         if sp.get("wg"):
             x, dy, cw = sp["x"], sp["dy"], sp["cw"]
-            d = L.WgradDesc()
+            d = into if into is not None else L.WgradDesc()
             d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = P(x), x.ld, x.coff, self.B, x.H, x.W, sp["cin"]
             d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = P(dy), dy.ld, dy.coff, sp["OH"], sp["OW"], cw.cout
             d.KH, d.KW, d.stride, d.pad = sp["k"], sp["k"], sp["stride"], sp["pad"]
@@ -328,6 +358,7 @@ class Plan:
         src, bi = X8, 0
         for s in range(4):
             self._tag = f"enc{s}"
+            self.fwd_marks.append((f"enc{s}", len(self.fwd)))
             Cs, heads, ratio, sr = cfg.dims[s], cfg.heads[s], cfg.ff_expansion[s], cfg.reduction_ratio[s]
             k, stride = (7, 4) if s == 0 else (3, 2)
             Hs, Ws = src.H // stride, src.W // stride
@@ -352,10 +383,12 @@ class Plan:
             # per-stage scratch shared by all blocks of the stage
             hid = Cs * ratio
             sc = {"DH": self.act(Cs, Hs, Ws), "DHID": self.act(hid, Hs, Ws), "DHID2": self.act(hid, Hs, Ws),
-                  "DXN": self.act(Cs, Hs, Ws), "DQ": self.act(Cs, Hs, Ws)}
+                  "DXN": self.act(Cs, Hs, Ws), "DQ": self.act(Cs, Hs, Ws), "hid": hid}
+            self._defer = [] if GROUP_WGRAD else None
             for i in range(cfg.depths[s]):
                 X = self.block(f"dest_encoder.block{s + 1}.{i}", X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc)
                 bi += 1
+            self.flush_deferred(grp)       # grp (patch embed) is the LAST backward unit of this stage
             Xb = self.act(Cs, Hs, Ws)
             self._emit(self.fwd, "crd_f32_to_bf16_rows", [X.t, Cs, Xb.t, Cs, 0, B * N, Cs, None, 1, None, 0, 0])
             enc_out_b.append(Xb)
@@ -364,6 +397,7 @@ class Plan:
 
         # ---- decoder ----
         self._tag = "dec"
+        self.fwd_marks.append(("dec", len(self.fwd)))
         d = cfg.dims
         hs = [(H // 32, W // 32), (H // 16, W // 16), (H // 8, W // 8), (H // 4, W // 4), (H // 2, W // 2), (H, W)]
         # from_encoder_1 -> own buffer E1 (bicubic source of stage 0); from_encoder_2..4 write into skip slices
@@ -594,6 +628,8 @@ class Plan:
         g = []
         gen = ("blk", bi)
         DH, DHID, DHID2, DXN, DQ = sc["DH"], sc["DHID"], sc["DHID2"], sc["DXN"], sc["DQ"]
+        if self._defer is not None:      # operands of deferred weight gradients must outlive the block
+            DH, DHID2, DQ = self.act(Cs, Hs, Ws), self.act(hid, Hs, Ws), self.act(Cs, Hs, Ws)
         self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
         self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc2.bias"))
         self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1))
@@ -750,7 +786,10 @@ class Plan:
                 self.bwd.append(op)
         # resolve lazy arguments to raw pointers / ctypes
         for op in self.fwd + self.bwd:
-            op.args = [self._resolve(a) for a in op.args]
+            if op.args and isinstance(op.args[0], dict) and "wg_group" in op.args[0]:
+                op.args = self._make_group(op.args[0]["wg_group"])
+            else:
+                op.args = [self._resolve(a) for a in op.args]
         self.bwd_groups = None
 
     def _resolve(self, a):

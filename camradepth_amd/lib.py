@@ -43,6 +43,10 @@ class WgradDesc(C.Structure):
     ]
 
 
+class WgradGroupInfo(C.Structure):
+    _fields_ = [("n_problems", C.c_int32), ("n_items", C.c_int32 * 4), ("item_offset", C.c_int32 * 4), ("bytes", C.c_int64)]
+
+
 class PackEntry(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("dst_fwd", C.c_void_p), ("dst_dgrad", C.c_void_p), ("dst_scatter", C.c_void_p),
@@ -87,7 +91,7 @@ def load():
 
 # Signatures of include/camradepth_hip.h (all return int status). p = pointer, i = int32, l = int64, f = float
 _SIGS = {
-    "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp",
+    "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiip",
     "crd_dwconv3x3": "piiiippippp", "crd_dwconv3x3_wgrad": "ppiiiippp",

@@ -88,6 +88,22 @@ typedef struct {
 
 int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream);
 
+/* Grouped weight gradients: the ~190 small wgrads of the encoder blocks (autograd's per-layer conv2d_backward weight
+ * calls behind simplified_attention.py:32-43,95-132) are each too small to fill the chip, so the host collects them
+ * per backward segment and runs them as ONE dispatch once their inputs exist.  crd_wgrad_group_build plans the group
+ * on the host (problem descriptors + one work item per workgroup) into host_table; the caller copies the table to
+ * device memory once and replays it with crd_conv_wgrad_grouped.  Calling build with host_table = NULL only fills
+ * info->bytes (size query).  The inputs named by the descriptors must stay valid until the grouped call. */
+typedef struct crd_wgrad_group_info {
+  int32_t n_problems;
+  int32_t n_items[4];      /* work items (workgroups) per tile configuration */
+  int32_t item_offset[4];  /* first item of each configuration */
+  int64_t bytes;           /* table size */
+} crd_wgrad_group_info;
+int crd_wgrad_group_build(const crd_wgrad_desc* descs, int32_t n, void* host_table, int64_t capacity,
+                          crd_wgrad_group_info* info);
+int crd_conv_wgrad_grouped(const void* dev_table, const crd_wgrad_group_info* info, crd_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm family.  Statistics are kept as raw sums over 16-channel slabs ("g16 stats":
  * float [B][C/16][2] = sum, sum of squares); a GroupNorm group is `gmul` consecutive slabs, so

@@ -215,4 +215,6 @@ def test_train_step_graph_matches_eager_autograd_path():
     torch.cuda.synchronize()
     assert abs(ts.losses()["loss"] - float(loss)) < 2e-3 * abs(float(loss))
     assert rel(m2.flat_grad, g1) < 5e-2
-    assert rel(m2.flat, m1.flat) < 1e-3
+    # the first diffGradNorm step is sign-like, so near-zero gradient elements whose sign depends on the fp32 atomic
+    # order move by 2*lr: two runs of the SAME path differ by 0.6e-3..2e-3 here (tools/check_step_noise.py)
+    assert rel(m2.flat, m1.flat) < 5e-3

@@ -27,6 +27,56 @@ def ok(rc, what):
     torch.cuda.synchronize()
 
 
+def _wgrad_problem(case, seed):
+    lib, _ = L()
+    B, Ci, Cp, H, W, Co, k, s, p = case
+    g = torch.Generator().manual_seed(seed)
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = torch.zeros(Co, Ci, k, k, requires_grad=True)
+    bias = torch.zeros(Co, requires_grad=True)
+    y = F.conv2d(x, w, bias, stride=s, padding=p)
+    OH, OW = y.shape[2], y.shape[3]
+    dy = bf(torch.randn(B, Co, OH, OW, generator=g))
+    y.backward(dy)
+    Cop = ((Co + 7) // 8) * 8
+    xpm, dypm = to_pm(x, ld=Cp), to_pm(dy, ld=Cop)
+    dw = torch.zeros(Co, k * k, Cp, device="cuda")
+    db = torch.zeros(Co, device="cuda")
+    return dict(x=xpm, dy=dypm, dw=dw, db=db, wg=w.grad, bg=bias.grad, dims=(B, Ci, Cp, H, W, Co, Cop, k, s, p, OH, OW))
+
+
+def _fill_wgrad_desc(d, pr):
+    B, Ci, Cp, H, W, Co, Cop, k, s, p, OH, OW = pr["dims"]
+    d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = P(pr["x"]), Cp, 0, B, H, W, Cp
+    d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = P(pr["dy"]), Cop, 0, OH, OW, Co
+    d.KH, d.KW, d.stride, d.pad, d.dw, d.dbias = k, k, s, p, P(pr["dw"]), P(pr["db"])
+
+
+def test_conv_wgrad_grouped():
+    """One grouped dispatch over problems of every tile configuration (Cout 21/64/96/160/512), strided and 1x1, equals
+    the per-problem references; the size query and the table build agree."""
+    lib, lb = L()
+    cases = [(3, 256, 256, 4, 7, 256, 1, 1, 0), (2, 64, 64, 40, 52, 512, 1, 1, 0), (1, 640, 640, 6, 7, 160, 1, 1, 0),
+             (2, 64, 64, 16, 24, 64, 8, 8, 0), (2, 128, 128, 10, 11, 21, 3, 1, 1), (2, 136, 136, 19, 23, 96, 3, 1, 1),
+             (2, 160, 160, 16, 26, 160, 2, 2, 0), (8, 160, 160, 1, 1, 160, 1, 1, 0)]
+    probs = [_wgrad_problem(c, 11 + i) for i, c in enumerate(cases)]
+    descs = (lib.WgradDesc * len(probs))()
+    for d, pr in zip(descs, probs):
+        _fill_wgrad_desc(d, pr)
+    info = lib.WgradGroupInfo()
+    lib.check(lb.crd_wgrad_group_build(descs, len(probs), None, 0, C.byref(info)), "size query")
+    assert info.bytes > 0 and info.n_problems == len(probs) and sum(info.n_items) > len(probs)
+    host = (C.c_uint8 * info.bytes)()
+    lib.check(lb.crd_wgrad_group_build(descs, len(probs), host, info.bytes, C.byref(info)), "build")
+    table = torch.frombuffer(bytearray(bytes(host)), dtype=torch.uint8).cuda()
+    ok(lb.crd_conv_wgrad_grouped(P(table), C.byref(info), lib.stream()), "crd_conv_wgrad_grouped")
+    for c, pr in zip(cases, probs):
+        B, Ci, Cp, H, W, Co, Cop, k, s, p, OH, OW = pr["dims"]
+        got = pr["dw"].cpu()[:, :, :Ci].reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
+        assert_close(got, pr["wg"], f"grouped wgrad {c}", rel=2e-3, elem=4e-3)
+        assert_close(pr["db"].cpu(), pr["bg"], f"grouped dbias {c}", rel=2e-3, elem=4e-3)
+
+
 WG_CASES = [
     # B, Cin, Cin_pad, H, W, Cout, k, s, p
     (2, 136, 136, 19, 23, 96, 3, 1, 1),

@@ -45,3 +45,15 @@ for ph, i, op, ms in sorted(rec, key=lambda r: -r[3])[:45]:
 import json
 with open("gpurun_out/ops_all.json", "w") as f:
     json.dump([(ph, i, op.name, (op.meta or {}).get("shape", ""), ms) for ph, i, op, ms in rec], f)
+
+# time per model segment
+marks = plan.fwd_marks + [("end", len(plan.fwd))]
+shift = 2 if len(plan.fwd) > 2 else 0      # two slice copies are inserted at the front after the marks were taken
+print("segment      fwd ms   bwd ms   launches")
+for (tag, a), (_, b2) in zip(marks, marks[1:]):
+    a2, b3 = (a + shift if a > 0 else a), b2 + shift
+    f = sum(ms for ph, i, op, ms in rec if ph == "fwd" and a2 <= i < b3)
+    seg = [sg for sg in plan.bwd_segments if sg[0] == tag]
+    bw = sum(ms for ph, i, op, ms in rec if ph == "bwd" and seg and seg[0][1] <= i < seg[0][2])
+    nl = sum(1 for ph, i, op, ms in rec if (ph == "fwd" and a2 <= i < b3) or (ph == "bwd" and seg and seg[0][1] <= i < seg[0][2]))
+    print(f"{tag:10s} {f:8.2f} {bw:8.2f}   {nl}")

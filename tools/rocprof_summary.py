@@ -19,3 +19,21 @@ text = "\n".join(lines)
 print(text)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(text + "\n")
+
+# Idle analysis over the tail of the trace (the timed graph replays): union of busy intervals vs wall window.
+W = 150e6
+ks = db.execute("select start, end, name from kernels where start > ? order by start", (span[1] - W,)).fetchall()
+busy = 0; cur_s, cur_e = ks[0][0], ks[0][1]; gaps = []
+for s, e, _ in ks[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s; gaps.append(s - cur_e); cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+wall = ks[-1][1] - ks[0][0]
+gaps.sort()
+tail = (f"last {wall / 1e6:.1f} ms of the trace: {len(ks)} dispatches, GPU busy {busy / 1e6:.1f} ms ({100 * busy / wall:.1f} %), "
+        f"{len(gaps)} gaps, median gap {gaps[len(gaps) // 2] / 1e3:.2f} us, total gap {sum(gaps) / 1e6:.2f} ms")
+print(tail)
+if len(sys.argv) > 2:
+    open(sys.argv[2], "a").write(tail + "\n")

@@ -112,13 +112,18 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
 #endif
   };
 
+  // accumulators start at the bias of their column (lane l holds column l&31 of every 32x32 tile): the load overlaps the
+  // first DMA instead of adding a dependent memory latency to the epilogue
   f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (l & 31);
+    const float bias_v = (a.bias && col < a.Cout) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_v;
+  }
 
   // prologue: whole halo of chunk 0 + first weight slab
   if (halo_wave) {

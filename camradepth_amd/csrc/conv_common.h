@@ -40,7 +40,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
     for (int j = 0; j < TN; ++j) {
       const int cl = (wn * TN + j) * 32 + (l & 31), col = n0 + cl;
       const bool colok = col < a.Cout;
-      const float bias_v = (a.bias && colok) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
       float s = 0.f, ss = 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -50,7 +49,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
           bool valid;
           int row;
           pix(i, rr, valid, row);
-          float v = acc[i][j][r] + bias_v;
+          float v = acc[i][j][r];          // bias is already in the accumulator (see the kernels' accumulator init)
           if (a.act == 1) v = sigmoidf_(v);
           const bf16_t q = f2bf(v);
           T[((wm * TM + i) * 32 + rr) * LDT + cl] = q;
@@ -98,7 +97,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
   for (int j = 0; j < TN; ++j) {
     const int col = col0 + j * 32 + (l & 31);
     const bool colok = col < a.Cout;
-    const float bias_v = (a.bias && colok) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
     int pky = 0, pkx = 0, pci = col;
     if (a.out_mode == 1) {
       int tap = col / a.patch_c;
@@ -116,7 +114,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
         int row;
         pix(i, rr, valid, row);
         if (valid && colok) {
-          float v = acc[i][j][r] + bias_v;
+          float v = acc[i][j][r];          // bias is already in the accumulator
           if (a.act == 1) v = sigmoidf_(v);
           long long off;
           if (a.out_mode == 0) off = (long long)row * a.y_ld + col;
@@ -171,5 +169,6 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
 
 // stats[b][g][which] += sum over tiles of the per-tile partials written by conv_epilogue
 __global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, float* stats);
+
 
 }  // namespace crdk

@@ -32,18 +32,26 @@ constexpr int BK = 64;                 // K elements per LDS stage (8 granules o
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 // MODE 0: forward gather (any stride); 1: data-gradient gather, stride 1; 2: data-gradient gather, strided
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NST = LDS stages.  A K-slab of a 64x64 tile is only four MFMAs per wave, so with one slab in flight every K-step of
+// the small encoder GEMMs costs a full memory latency (12 us for K = 640); NST - 1 slabs in flight hide it.
+template <int WM, int WN, int TM, int TN, int MODE, int NST>
 __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr int A_IT = BM / 32, B_IT = (BN + 31) / 32;   // each wave DMAs 8 rows per instruction, 4 waves -> 32 rows per pass
-  __shared__ __attribute__((aligned(16))) bf16_t lds[2 * (BM + BN) * BK];
+  constexpr int A_IT = BM / 32, B_IT = BN / 32;   // each wave DMAs 8 rows per instruction, 4 waves -> 32 rows per pass
+  constexpr int PER = A_IT + B_IT;                // DMA instructions per thread and stage
+  static_assert((NST - 2) * PER < 64, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];     // NST * (BM + BN) * BK
   bf16_t* sA = lds;
-  bf16_t* sB = lds + 2 * BM * BK;
+  bf16_t* sB = lds + NST * BM * BK;
 
   const int t = threadIdx.x, l = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  if (a.dbg & 8) return;
   // hardware-bounds-checked buffer loads: an out-of-range offset returns zeros, which implements the conv padding,
   // the K tail and the partial M/N tiles without a single branch in the load path
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -114,21 +122,29 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
     while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
   };
 
+  // accumulators start at the bias of their column (lane l holds column l&31 of every 32x32 tile): the load overlaps the
+  // first DMA instead of adding a dependent memory latency to the epilogue
   f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + (wn * TN + j) * 32 + (l & 31);
+    const float bias_v = (a.bias && col < a.Cout) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_v;
+  }
 
-  const int nK = (a.Ktot + BK - 1) / BK;
-  stage(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  const int nK = (a.dbg & 16) ? 0 : (a.Ktot + BK - 1) / BK;
+  // Slabs past the K range are still issued (their offsets are out of range: zero fill, no memory traffic), so the
+  // number of DMAs in flight behind slab kt is always (NST - 2) * PER and the wait needs no tail cases.
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) stage(s);
+  int cur = 0, nxt = NST - 1;
   for (int kt = 0; kt < nK; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nK) stage(cur ^ 1);        // DMA of the next K-slab runs under this slab's MFMAs
+    wait_vm<(NST - 2) * PER>();             // this thread's share of slab kt has landed ...
+    __syncthreads();                        // ... everyone's has, and everyone is done reading slab kt-1
+    stage(nxt);                             // refill slab kt-1's buffer under this slab's MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       bf16x8 af[TM], bfr[TN];
@@ -149,9 +165,12 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    cur = cur + 1 == NST ? 0 : cur + 1;
+    nxt = nxt + 1 == NST ? 0 : nxt + 1;
   }
+  wait_vm<0>();                             // the zero-fill slabs still target the LDS the epilogue reuses
+  __syncthreads();
+  if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(a.y)[0] = 1.f; return; }
 
   // ---- epilogue (conv_common.h) ----
   conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
@@ -164,16 +183,29 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   });
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int MODE, int NST>
+void launch_mode(const ConvK& k, dim3 grid, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(bf16_t);
+  static bool attr_done = false;
+  if (!attr_done && lds > 64 * 1024) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<WM, WN, TM, TN, MODE, NST>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, MODE, NST>), grid, dim3(256), lds, st, k);
+}
+
+template <int WM, int WN, int TM, int TN, int NST>
 int launch(const ConvK& k0, int B, hipStream_t st, long long partial_cap) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   ConvK k = k0;
   k.n_tiles = cdiv(k.OHW, BM);
   if ((long long)B * k.n_tiles * k.G16 * 2 > partial_cap) k.stats_partial = nullptr;
   dim3 grid(k.n_tiles, cdiv(k.Cout, BN), B);
-  if (k.gather_mode == 0) hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 0>), grid, dim3(256), 0, st, k);
-  else if (k.stride == 1) hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 1>), grid, dim3(256), 0, st, k);
-  else hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, 2>), grid, dim3(256), 0, st, k);
+  if (k.gather_mode == 0) launch_mode<WM, WN, TM, TN, 0, NST>(k, grid, st);
+  else if (k.stride == 1) launch_mode<WM, WN, TM, TN, 1, NST>(k, grid, st);
+  else launch_mode<WM, WN, TM, TN, 2, NST>(k, grid, st);
   if (k.stats && k.stats_partial)
     hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, k.n_tiles, k.G16, k.stats);
   CRD_LAUNCH_CHECK("crd_conv_igemm");
@@ -222,11 +254,18 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   // small problems: 64x64 tiles so that the launch still covers the 256 CUs
   {
     const long long big_tiles = (long long)cdiv(k.OHW, 128) * cdiv(d->Cout, 128) * d->B;
-    if (d->Cout > 32 && big_tiles < 192) return launch<2, 2, 1, 1>(k, d->B, st, pcap);
+    if (d->Cout > 32 && big_tiles < 192) {
+      // stages follow the K depth: a stage is 16 KB of LDS, and with one or two K-slabs occupancy (workgroups whose
+      // prologue / epilogue latencies overlap) is worth more than prefetch depth
+      const int nK = cdiv(k.Ktot, BK);
+      if (nK <= 2) return launch<2, 2, 1, 1, 2>(k, d->B, st, pcap);
+      if (nK <= 4) return launch<2, 2, 1, 1, 3>(k, d->B, st, pcap);
+      return launch<2, 2, 1, 1, 4>(k, d->B, st, pcap);
+    }
   }
-  if (d->Cout <= 32) return launch<4, 1, 1, 1>(k, d->B, st, pcap);
-  if (d->Cout <= 64) return launch<2, 2, 2, 1>(k, d->B, st, pcap);
-  if (d->Cout <= 96) return launch<4, 1, 1, 3>(k, d->B, st, pcap);
-  if (d->Cout > 128 && d->Cout <= 160) return launch<4, 1, 1, 5>(k, d->B, st, pcap);
-  return launch<2, 2, 2, 2>(k, d->B, st, pcap);
+  if (d->Cout <= 32) return launch<4, 1, 1, 1, 3>(k, d->B, st, pcap);
+  if (d->Cout <= 64) return launch<2, 2, 2, 1, 3>(k, d->B, st, pcap);
+  if (d->Cout <= 96) return launch<4, 1, 1, 3, 2>(k, d->B, st, pcap);
+  if (d->Cout > 128 && d->Cout <= 160) return launch<4, 1, 1, 5, 2>(k, d->B, st, pcap);
+  return launch<2, 2, 2, 2, 2>(k, d->B, st, pcap);
 }

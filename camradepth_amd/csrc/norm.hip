@@ -24,13 +24,22 @@ struct Map {
   }
 };
 
+// sm holds `rows` rows of n floats (one per pixel lane); leaves their sum in row 0.  LDS float atomics for this merge
+// cost 18 us of a 40 us kernel (ablation in tools/bench_gn.py): every lane of a wave hits one of four banks.
+__device__ __forceinline__ void fold_rows(float* sm, int n, int rows) {
+  for (int i = threadIdx.x; i < n; i += TPB) {
+    float a = sm[i];
+    for (int r = 1; r < rows; ++r) a += sm[(long long)r * n + i];
+    sm[i] = a;
+  }
+  __syncthreads();
+}
+
 template <int XF>
 __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
                                                   float* stats, float* chan) {
-  extern __shared__ float sm[];  // [C][2]
+  extern __shared__ float sm[];  // [PL][C][2]: one row of channel sums per pixel lane, folded after the barrier
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) sm[i] = 0.f;
-  __syncthreads();
   Map m(C);
   float s[8], ss[8];
 #pragma unroll
@@ -53,13 +62,12 @@ __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int 
           for (int j = 0; j < 8; ++j) { s[j] += v[u][j]; ss[j] += v[u][j] * v[u][j]; }
         }
     }
+    float4* row = reinterpret_cast<float4*>(sm + (long long)m.pl * 2 * C + m.cg * 16);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&sm[(m.cg * 8 + j) * 2], s[j]);
-      atomicAdd(&sm[(m.cg * 8 + j) * 2 + 1], ss[j]);
-    }
+    for (int j = 0; j < 4; ++j) row[j] = make_float4(s[2 * j], ss[2 * j], s[2 * j + 1], ss[2 * j + 1]);
   }
   __syncthreads();
+  fold_rows(sm, 2 * C, m.PL);
   if (chan)
     for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(&chan[(long long)b * C * 2 + i], sm[i]);
   if (stats)
@@ -123,10 +131,8 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
                                                        int dy_ld, long long P, int C, int chunk, const float* stats,
                                                        int gmul, const float* gamma, const float* beta, int act,
                                                        const float* mask, float* r, float* partial) {
-  extern __shared__ float sm[];  // [C][2]
+  extern __shared__ float sm[];  // [PL][C][2]
   const int b = blockIdx.y;
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) sm[i] = 0.f;
-  __syncthreads();
   Map m(C);
   if (m.active) {
     const int c0 = m.cg * 8;
@@ -163,13 +169,12 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
           }
         }
     }
+    float4* row = reinterpret_cast<float4*>(sm + (long long)m.pl * 2 * C + c0 * 2);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      atomicAdd(&sm[(c0 + j) * 2], s0[j]);
-      atomicAdd(&sm[(c0 + j) * 2 + 1], s1[j]);
-    }
+    for (int j = 0; j < 4; ++j) row[j] = make_float4(s0[2 * j], s1[2 * j], s0[2 * j + 1], s1[2 * j + 1]);
   }
   __syncthreads();
+  fold_rows(sm, 2 * C, m.PL);
   if (partial) {   // plain stores of this workgroup's sums; k_gn_bwd_finalize folds them (no contended atomics)
     float* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 2 * C;
     for (int i = threadIdx.x; i < 2 * C; i += TPB) dst[i] = sm[i];
@@ -320,6 +325,12 @@ int check_common(const char* name, int x_ld, int x_coff, int C, int x_f32) {
   return CRD_OK;
 }
 
+// LDS of the reducing kernels: one row of 2*C sums per pixel lane
+inline size_t lds_rows(int C) {
+  int PL = TPB / (C >> 3); if (PL < 1) PL = 1;
+  return (size_t)PL * 2 * C * sizeof(float);
+}
+
 inline const void* off_ptr(const void* p, int f32, int coff) {
   return f32 ? (const void*)(reinterpret_cast<const float*>(p) + coff) : (const void*)(reinterpret_cast<const bf16_t*>(p) + coff);
 }
@@ -333,9 +344,9 @@ extern "C" int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   if (rc) return rc;
   dim3 grid; int chunk;
   grid_for(P, C, B, grid, chunk, true);
-  if (x_f32) hipLaunchKernelGGL(k_gn_stats<1>, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream), off_ptr(x, x_f32, x_coff),
+  if (x_f32) hipLaunchKernelGGL(k_gn_stats<1>, grid, dim3(TPB), lds_rows(C), as_stream(stream), off_ptr(x, x_f32, x_coff),
                                 x_f32, x_ld, (long long)P, C, chunk, stats, chan_sums);
-  else hipLaunchKernelGGL(k_gn_stats<0>, grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream), off_ptr(x, x_f32, x_coff),
+  else hipLaunchKernelGGL(k_gn_stats<0>, grid, dim3(TPB), lds_rows(C), as_stream(stream), off_ptr(x, x_f32, x_coff),
                           x_f32, x_ld, (long long)P, C, chunk, stats, chan_sums);
   CRD_LAUNCH_CHECK("crd_gn_stats");
   return CRD_OK;
@@ -380,7 +391,7 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
   grid_for(P, C, B, grid, chunk, true);
   float* part = (scratch && (long long)B * grid.x * 2 * C <= scratch_capacity && grid.x > 1) ? scratch : nullptr;
 #define CRD_GN_RED(XF, DF, ACT)                                                                                              \
-  hipLaunchKernelGGL((k_gn_bwd_reduce<XF, DF, ACT>), grid, dim3(TPB), 2 * C * sizeof(float), as_stream(stream),            \
+  hipLaunchKernelGGL((k_gn_bwd_reduce<XF, DF, ACT>), grid, dim3(TPB), lds_rows(C), as_stream(stream),                      \
                      off_ptr(x, x_f32, x_coff), x_f32, x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C, \
                      chunk, stats, gmul, gamma, beta, act, mask, r, part)
   switch ((x_f32 ? 4 : 0) | (dy_f32 ? 2 : 0) | (act ? 1 : 0)) {
@@ -390,7 +401,7 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
     case 6: CRD_GN_RED(1, 1, 0); break;  default: CRD_GN_RED(1, 1, 1); break;
   }
 #undef CRD_GN_RED
-  if (scratch && (long long)B * grid.x * 2 * C <= scratch_capacity && grid.x > 1)
+  if (part)
     hipLaunchKernelGGL(k_gn_bwd_finalize, dim3(cdiv(C, 64), B), dim3(TPB), 0, as_stream(stream), scratch, (int)grid.x, C, gmul,
                        gamma, r, B);
   CRD_LAUNCH_CHECK("crd_gn_bwd_reduce");

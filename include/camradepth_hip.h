@@ -139,6 +139,7 @@ int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff,
                      const float* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
                      int32_t dx_coff, int32_t dx_accumulate, crd_stream_t stream);
 
+
 /* ---------------------------------------------------------------------------------------------
  * Depthwise 3x3 (DWConv, simplified_attention.py:316,318-323), pixel-major bf16 [B][H][W][C].
  * w9 is fp32 [9][C] (tap-major), bias [C] or NULL.  flip=1 mirrors the taps (data gradient).

@@ -90,18 +90,24 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
   }
 }
 
-// dw9[tap][c] += sum_{b,p} dy[p][c]*x[p+tap][c] ; dbias[c] += sum dy.  Same sliding window; a thread keeps its 8 channels
-// (blockIdx.y selects a 64-granule channel window, 4 row-lanes per workgroup) so the 80 partial sums stay in registers
-// across all the row segments it visits; one LDS merge and one set of global atomics per workgroup.
+// dw10[tap][c] += sum_{b,p} dy[p][c]*x[p+tap][c] for tap < 9; dw10[9][c] += sum dy (the bias gradient).  Same sliding
+// window; a thread keeps its 8 channels (blockIdx.y selects a 64-granule channel window; the window's granules are
+// spread over CGW lanes and the remaining lanes of the workgroup take further row segments) so the 80 partial sums stay
+// in registers across all the row segments it visits.  The workgroup folds them with shuffles (row lanes inside a wave)
+// and four LDS rounds (waves) -- LDS float atomics serialise on four banks -- and then adds into ONE of `replicas`
+// copies of the accumulator: an fp32 global atomic costs ~2.6 ns per 128-byte line, so 384 workgroups x 5120 adjacent
+// sums on one copy kept the kernel at 70 us for 27 MB of input.  The caller sums the copies (crd_wgrad_unpack).
 __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int B, int H, int W, int C,
-                                                      float* dw9, float* dbias) {
+                                                      float* dw10, int replicas) {
   __shared__ float sm[10 * 512];
   const int CG = C >> 3;
-  const int cgl = threadIdx.x & 63, lane = threadIdx.x >> 6;
+  const int rem = CG - blockIdx.y * 64;                // granules in this window
+  int CGW = 64;
+  while (CGW > 8 && (CGW >> 1) >= rem) CGW >>= 1;      // lanes per row segment: 8..64, power of two
+  const int RL = TPB / CGW;                            // row lanes per workgroup
+  const int cgl = threadIdx.x & (CGW - 1), lane = threadIdx.x / CGW;
   const int cg = blockIdx.y * 64 + cgl;
   const bool cok = cg < CG;
-  for (int i = threadIdx.x; i < 10 * 512; i += TPB) sm[i] = 0.f;
-  __syncthreads();
   const int c0 = cg * 8;
   const int segs = (W + TP - 1) / TP;
   const long long items = (long long)B * H * segs;
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
   if (cok) {
-    for (long long it = (long long)blockIdx.x * 4 + lane; it < items; it += (long long)gridDim.x * 4) {
+    for (long long it = (long long)blockIdx.x * RL + lane; it < items; it += (long long)gridDim.x * RL) {
       const int seg = (int)(it % segs);
       const long long r2 = it / segs;
       const int py = (int)(r2 % H), b = (int)(r2 / H);
@@ -151,18 +157,34 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
         }
       }
     }
+  }
+  // row lanes inside the wave
+  for (int o = CGW; o < 64; o <<= 1) {
 #pragma unroll
     for (int t = 0; t < 10; ++t)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&sm[t * 512 + cgl * 8 + j], acc[t][j]);
+      for (int j = 0; j < 8; ++j) acc[t][j] += __shfl_xor(acc[t][j], o);
   }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 10 * 512; i += TPB) {
-    const int t = i / 512, cl = i - t * 512, c = blockIdx.y * 512 + cl;
-    if (c < C && sm[i] != 0.f) {
-      if (t < 9) atomicAdd(&dw9[(long long)t * C + c], sm[i]);
-      else atomicAdd(&dbias[c], sm[i]);
+  // waves, one after the other
+  const int wave = threadIdx.x >> 6;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && (threadIdx.x & 63) < CGW && cok) {
+#pragma unroll
+      for (int t = 0; t < 10; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float* p = &sm[t * 512 + cgl * 8 + j];
+          *p = w == 0 ? acc[t][j] : *p + acc[t][j];
+        }
     }
+    __syncthreads();
+  }
+  float* dst = dw10 + (long long)(blockIdx.x % replicas) * 10 * C;
+  const int nch = (rem < 64 ? rem : 64) * 8;          // channels of this window
+  for (int i = threadIdx.x; i < 10 * nch; i += TPB) {
+    const int t = i / nch, cl = i - t * nch;
+    const float v = sm[t * 512 + cl];
+    if (v != 0.f) atomicAdd(&dst[(long long)t * C + blockIdx.y * 512 + cl], v);
   }
 }
 
@@ -264,12 +286,13 @@ __global__ __launch_bounds__(TPB) void k_attn_out_residual(const float* x, const
   }
 }
 
-// dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp[c] += sum dy ; dS[b][n] = sum_c dy*u[b][c]
+// dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp_rows[b][c] += sum_n dy ; dS[b][n] = sum_c dy*u[b][c]
+// Four pixel groups are loaded per iteration (one load in flight per thread left the kernel latency-bound); the sums are
+// folded over the wave's pixel lanes with shuffles and over the waves through LDS, then added with one atomic per value
+// and workgroup into PER-SAMPLE rows (chain depth = workgroups of the sample; crd_wgrad_unpack sums the rows of dbp).
 __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp,
-                                                      long long N, int C, int chunk, float* t, float* dbp, float* dS) {
+                                                      long long N, int C, int chunk, float* t, float* dbp_rows, float* dS) {
   extern __shared__ float sm[];  // [2][C]
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) sm[i] = 0.f;
-  __syncthreads();
   const int b = blockIdx.y;
   const int CG = C >> 3;
   int W2 = 1;
@@ -284,28 +307,47 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
   for (int j = 0; j < 8; ++j) { uu[j] = cok ? u[(long long)b * C + cg * 8 + j] : 0.f; ta[j] = ba[j] = 0.f; }
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > N) p1 = N;
-  for (long long nb = p0 + wave * PPW; nb < p1; nb += 4 * PPW) {
-    const long long n = nb + sub;
-    const bool ok = cok && n < p1;
-    float v[8];
+  constexpr int UN = 4;
+  for (long long nb = p0 + wave * PPW; nb < p1; nb += (long long)UN * 4 * PPW) {
+    float v[UN][8], s[UN];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = 0.f;
-    float s = 0.f;
-    if (ok) { load8(dx1, ((long long)b * N + n) * C + cg * 8, 1, v); s = S[(long long)b * N + n]; }
-    float dot = 0.f;
+    for (int k = 0; k < UN; ++k) {
+      const long long n = nb + (long long)k * 4 * PPW + sub;
+      const bool ok = cok && n < p1;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { v[j] *= dps; dot += v[j] * uu[j]; ta[j] += v[j] * s; ba[j] += v[j]; }
-    for (int o = W2 >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
-    if (ok && cg == 0) dS[(long long)b * N + n] = dot;
+      for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
+      s[k] = 0.f;
+      if (ok) { load8(dx1, ((long long)b * N + n) * C + cg * 8, 1, v[k]); s[k] = S[(long long)b * N + n]; }
+    }
+#pragma unroll
+    for (int k = 0; k < UN; ++k) {
+      const long long n = nb + (long long)k * 4 * PPW + sub;
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[k][j] *= dps; dot += v[k][j] * uu[j]; ta[j] += v[k][j] * s[k]; ba[j] += v[k][j]; }
+      for (int o = W2 >> 1; o > 0; o >>= 1) dot += __shfl_xor(dot, o);
+      if (cok && n < p1 && cg == 0) dS[(long long)b * N + n] = dot;
+    }
   }
-  if (cok) {
+  for (int o = W2; o < 64; o <<= 1) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { atomicAdd(&sm[cg * 8 + j], ta[j]); atomicAdd(&sm[C + cg * 8 + j], ba[j]); }
+    for (int j = 0; j < 8; ++j) { ta[j] += __shfl_xor(ta[j], o); ba[j] += __shfl_xor(ba[j], o); }
   }
-  __syncthreads();
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w && sub == 0 && cok) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float* p0_ = &sm[cg * 8 + j];
+        float* p1_ = &sm[C + cg * 8 + j];
+        *p0_ = w == 0 ? ta[j] : *p0_ + ta[j];
+        *p1_ = w == 0 ? ba[j] : *p1_ + ba[j];
+      }
+    }
+    __syncthreads();
+  }
   for (int i = threadIdx.x; i < C; i += TPB) {
     atomicAdd(&t[(long long)b * C + i], sm[i]);
-    atomicAdd(&dbp[i], sm[C + i]);
+    atomicAdd(&dbp_rows[(long long)b * C + i], sm[C + i]);
   }
 }
 
@@ -372,18 +414,18 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
   return CRD_OK;
 }
 
-extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw9,
-                                   float* dbias, crd_stream_t stream) {
-  CRD_CHECK_ARG(x && dy && dw9 && dbias, "crd_dwconv3x3_wgrad: null pointer");
+extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw10,
+                                   int32_t replicas, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && dy && dw10 && replicas >= 1, "crd_dwconv3x3_wgrad: null pointer / replicas < 1");
   CRD_CHECK_ARG(C % 16 == 0 && C <= 4096, "crd_dwconv3x3_wgrad: C must be a multiple of 16, <= 4096");
   const int cwin = cdiv(C / 8, 64);                         // 512-channel windows
   const long long items = (long long)B * H * cdiv(W, TP);
-  long long nblk = cdiv(items, 4 * 2);                     // >= 2 row segments per thread
-  const long long cap = 384 / cwin > 0 ? 384 / cwin : 1;   // each workgroup ends with up to 5120 global atomics
+  long long nblk = cdiv(items, 4 * 2);                     // >= 2 row segments per row lane of a full window
+  const long long cap = 512 / cwin > 0 ? 512 / cwin : 1;
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
   hipLaunchKernelGGL(k_dwconv_wgrad, dim3((unsigned)nblk, cwin), dim3(TPB), 0, as_stream(stream),
-                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), B, H, W, C, dw9, dbias);
+                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), B, H, W, C, dw10, replicas);
   CRD_LAUNCH_CHECK("crd_dwconv3x3_wgrad");
   return CRD_OK;
 }
@@ -421,8 +463,8 @@ extern "C" int crd_attn_out_residual(const float* x, const float* u, const float
 }
 
 extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
-                                int32_t C, float* t, float* dbp, float* dS, crd_stream_t stream) {
-  CRD_CHECK_ARG(dx1 && u && S && t && dbp && dS, "crd_attn_out_bwd: null pointer");
+                                int32_t C, float* t, float* dbp_rows, float* dS, crd_stream_t stream) {
+  CRD_CHECK_ARG(dx1 && u && S && t && dbp_rows && dS, "crd_attn_out_bwd: null pointer");
   CRD_UNSUPPORTED(C % 8 == 0 && C <= 512, "crd_attn_out_bwd: C must be a multiple of 8 and <= 512");
   int nblk = cdiv(N, 256);
   int cap = 1024 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
@@ -430,7 +472,7 @@ extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S
   int chunk = cdiv(N, nblk);
   nblk = cdiv(N, chunk);
   hipLaunchKernelGGL(k_attn_out_bwd, dim3(nblk, B), dim3(TPB), 2 * C * sizeof(float), as_stream(stream), dx1, u, S, dp,
-                     (long long)N, C, chunk, t, dbp, dS);
+                     (long long)N, C, chunk, t, dbp_rows, dS);
   CRD_LAUNCH_CHECK("crd_attn_out_bwd");
   return CRD_OK;
 }

@@ -199,7 +199,9 @@ __global__ __launch_bounds__(TPB) void k_wgrad_unpack(const crd_unpack_entry* ta
     const int cr = e.cmap ? e.cmap[ci] : (ci < e.Cin_ref ? ci : -1);
     if (cr < 0) continue;
     float* d = e.dst + ((long long)co * e.Cin_ref + cr) * e.taps + tap;
-    *d = accumulate ? *d + e.src[i] : e.src[i];
+    float v = e.src[i];
+    for (int r = 1; r < e.replicas; ++r) v += e.src[(long long)r * e.replica_stride + i];
+    *d = accumulate ? *d + v : v;
   }
 }
 

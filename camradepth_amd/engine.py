@@ -24,6 +24,7 @@ from .params import short_res_block_plan
 
 # developer switch: CRD_NO_GROUP_WGRAD=1 runs every small weight gradient as its own launch (A/B against the grouped launch)
 GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
+DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -124,6 +125,7 @@ class Plan:
         self.convs = []
         self.keep = []                              # keep ctypes structs / tensors alive
         self.dw_entries, self.dw_grads = [], []
+        self.row_grads = []                         # (param, C, rows buffer [R][C], R, tag): gradient = sum of the rows
         self.shapes = {}
         self.fwd_marks = []
         self._defer = None
@@ -636,9 +638,9 @@ class Plan:
         self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc2.bias"))
         self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1))
         self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID)                 # in place: d(H2)
-        dw9 = self.zb(9, hid)
-        self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw9, self._tag))
-        self._emit(g, "crd_dwconv3x3_wgrad", [H1N.t, DHID.t, B, Hs, Ws, hid, dw9, self.g(ml + ".dwconv.dwconv.bias")])
+        dw10 = self.zb(DW_REPLICAS, 10, hid)      # [copy][9 taps + bias][channel]; the unpack kernel sums the copies
+        self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
+        self._emit(g, "crd_dwconv3x3_wgrad", [H1N.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS])
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None])  # d(H1N)
         self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2)                    # in place: d(H1)
         self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc1.bias"))
@@ -646,7 +648,9 @@ class Plan:
         self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1)              # DX = d(X1)
         # attention branch
         T, dSv = self.zb(B, Cs), self.new((B, N), F32)
-        self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, self.g(a + ".proj.bias"), dSv])
+        dbp_rows = self.zb(B, Cs)
+        self.row_grads.append((a + ".proj.bias", Cs, dbp_rows, B, self._tag))
+        self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
         Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         self._emit(g, "crd_f32_to_bf16_rows", [T, Cs, Tb.t, Cs, 0, B, Cs, None, 1, None, 0, 0])
         self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
@@ -731,7 +735,11 @@ class Plan:
         self.zf_arena = self._materialise(self._zf_views)
         self.zb_arena = self._materialise(self._zb_views)
         order = ["dec", "enc3", "enc2", "enc1", "enc0"]
-        items = [(order.index(cw.tag), cw, None) for cw in unpack] + [(order.index(t[3]), None, t) for t in self.dw_grads]
+        items = [(order.index(cw.tag), cw, None) for cw in unpack]
+        for t in self.dw_grads:                        # depthwise: one entry for the 9 taps, one for the bias row
+            items += [(order.index(t[3]), None, t + ("weight",)), (order.index(t[3]), None, t + ("bias",))]
+        for name, Cn, rows, R, tag in self.row_grads:
+            items.append((order.index(tag), None, (name, Cn, rows, tag, ("rows", R))))
         items.sort(key=lambda it: it[0])
         uentries, self.unpack_ranges = [], {}
         for seg_i, cw, dwt in items:
@@ -742,10 +750,23 @@ class Plan:
                 u.Cout, u.Cin_ref, u.taps, u.Cin_pad = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad
                 nel = cw.cout * cw.taps * cw.cin_pad
             else:
-                name, hid, dw9, _ = dwt
-                u.src, u.dst, u.cmap = dw9.t.data_ptr(), self.g(name + ".weight").data_ptr(), None
-                u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, 9, hid
-                nel = 9 * hid
+                name, hid, dw10, _, which = dwt
+                if isinstance(which, tuple):           # per-sample rows of a vector gradient
+                    u.src, u.dst, u.cmap = dw10.t.data_ptr(), self.g(name).data_ptr(), None
+                    u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, 1, hid
+                    u.replicas, u.replica_stride = which[1], hid
+                    nel = hid
+                    lo, hi, mx = self.unpack_ranges.get(order[seg_i], (len(uentries), len(uentries), 1))
+                    self.unpack_ranges[order[seg_i]] = (lo, len(uentries) + 1, max(mx, nel))
+                    uentries.append(u)
+                    max_unpack = max(max_unpack, nel)
+                    continue
+                taps = 9 if which == "weight" else 1
+                u.src = dw10.t.data_ptr() + (0 if which == "weight" else 9 * hid * 4)
+                u.dst, u.cmap = self.g(name + "." + which).data_ptr(), None
+                u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, taps, hid
+                u.replicas, u.replica_stride = DW_REPLICAS, 10 * hid
+                nel = taps * hid
             lo, hi, mx = self.unpack_ranges.get(order[seg_i], (len(uentries), len(uentries), 1))
             self.unpack_ranges[order[seg_i]] = (lo, len(uentries) + 1, max(mx, nel))
             uentries.append(u)

@@ -60,6 +60,7 @@ class UnpackEntry(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("dst", C.c_void_p), ("cmap", C.c_void_p),
         ("Cout", C.c_int32), ("Cin_ref", C.c_int32), ("taps", C.c_int32), ("Cin_pad", C.c_int32),
+        ("replicas", C.c_int32), ("reserved", C.c_int32), ("replica_stride", C.c_int64),
     ]
 
 
@@ -94,7 +95,7 @@ _SIGS = {
     "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiip",
-    "crd_dwconv3x3": "piiiippippp", "crd_dwconv3x3_wgrad": "ppiiiippp",
+    "crd_dwconv3x3": "piiiippippp", "crd_dwconv3x3_wgrad": "ppiiiipip",
     "crd_attn_scores": "ppiiiiifppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_out_residual": "pppppiiipp",
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifppp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_bwd": "piiiiiipiiip",

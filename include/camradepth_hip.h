@@ -147,9 +147,11 @@ int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff,
  * ------------------------------------------------------------------------------------------- */
 int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
                   int32_t flip, void* y, float* stats, crd_stream_t stream);
-/* dw9[tap][c] += sum dy*x_shifted ; dbias[c] += sum dy   (fp32 atomics; caller zeroes) */
-int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw9,
-                        float* dbias, crd_stream_t stream);
+/* dw10: float [replicas][10][C], zeroed by the caller.  Rows 0..8: dw[tap][c] += sum dy*x_shifted; row 9: the bias
+ * gradient sum dy.  Workgroups spread their fp32 atomics over the `replicas` copies (contended atomics on one copy
+ * were the whole cost of this kernel); the true gradient is the sum of the copies (crd_wgrad_unpack does that). */
+int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw10,
+                        int32_t replicas, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Max-pool attention (Attention_MaxPool.forward, simplified_attention.py:90-109).
@@ -166,9 +168,11 @@ int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma
 /* x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])   (fp32 residual stream; Block.forward :143; dp may be NULL) */
 int crd_attn_out_residual(const float* x, const float* u, const float* S, const float* bp, const float* dp,
                           int32_t B, int32_t N, int32_t C, float* x1, crd_stream_t stream);
-/* with dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp[c] += sum_{b,n} dy ; dS[b][n] = sum_c dy*u[b][c] */
+/* with dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp_rows[b][c] += sum_n dy ; dS[b][n] = sum_c dy*u[b][c].
+ * The bias gradient is the sum of the B rows of dbp_rows (float [B][C], zeroed by the caller): per-sample rows keep the
+ * chain of contended atomics at the workgroups of one sample; crd_wgrad_unpack (replicas = B) folds them. */
 int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
-                     int32_t C, float* t, float* dbp, float* dS, crd_stream_t stream);
+                     int32_t C, float* t, float* dbp_rows, float* dS, crd_stream_t stream);
 /* dq[b][n][c] = scale*dS[b][n]*k[b][idx][c] (bf16) ; dk[b][m][c] += scale*dS*q (fp32, caller zeroes) */
 int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
                         int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, crd_stream_t stream);
@@ -237,6 +241,9 @@ typedef struct {
   float* dst;          /* fp32 [Cout][Cin_ref][taps] */
   const int32_t* cmap;
   int32_t Cout, Cin_ref, taps, Cin_pad;
+  int32_t replicas;        /* > 1: the source is the sum of `replicas` copies, replica_stride floats apart */
+  int32_t reserved;
+  int64_t replica_stride;
 } crd_unpack_entry;
 int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int64_t max_elems, int32_t accumulate,
                      crd_stream_t stream);

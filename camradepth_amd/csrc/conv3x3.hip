@@ -6,9 +6,10 @@
 // bound by it.  Here a workgroup owns an 8 x 32 = 256-pixel 2-D output tile and walks K as (channel chunk of 64) x
 // (9 taps):
 //   * the (8+2) x (32+2) input halo of the chunk is brought into LDS ONCE (LDS-DMA, double buffered, the next
-//     chunk's halo is prefetched in small pieces during taps 1..8) and serves all nine taps -- a tap is just a
+//     chunk's halo is prefetched in small pieces during taps 0..5) and serves all nine taps -- a tap is just a
 //     different row offset into the halo image;
-//   * the [Cout tile][64] weight slab of each (chunk, tap) is streamed by LDS-DMA, double buffered;
+//   * the [Cout tile][64] weight slab of each (chunk, tap) is streamed by LDS-DMA through a 4-slot ring, requested
+//     three steps ahead;
 //   * 8 waves, each a (TM x TN) grid of 32x32 v_mfma_f32_32x32x16_bf16 tiles; one barrier per (chunk, tap).
 // Out-of-image halo pixels, the channel tail and partial tiles are zero-filled by the buffer bounds check, so the
 // hot loop has no branches.  MODE 0: forward (weights [Cout][tap][Cin]); MODE 1: data gradient (weights
@@ -26,18 +27,25 @@ constexpr int HGROUPS = (HROWS + 7) / 8;  // 43 DMA groups of 8 rows
 constexpr int HPAD = HGROUPS * 8;         // 344 rows allocated
 constexpr int CK = 64;                    // channels per chunk (8 granules, 128-byte LDS rows)
 constexpr int NW = 8;                     // waves per workgroup
-constexpr int HPT = 6;                    // halo groups prefetched per tap (taps 1..8 -> 48 >= 43)
+constexpr int HTAPS = 6;                  // taps 0..5 of a chunk carry the next chunk's halo (6 x 8 waves = 48 >= 43 groups)
+constexpr int WS = 4;                     // weight-slab ring: the slab of step t+3 is in flight while step t computes
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int WM, int WN, int TM, int TN, int MODE>
 __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
   static_assert(WM * WN == NW && WM * TM == TH, "8 waves cover the 8 tile rows");
   constexpr int BN = WN * TN * 32;
-  constexpr int WGROUPS = BN / 8;         // weight-slab DMA groups
+  constexpr int WGROUPS = BN / 8;                 // weight-slab DMA groups (8 rows each)
+  constexpr int WJ = (WGROUPS + NW - 1) / NW;     // groups per wave
+  constexpr int PER = WJ + 1;                     // DMA instructions every wave issues per step: WJ weight groups, 1 halo group
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   bf16_t* sH = lds;                       // [2][HPAD][CK]
-  bf16_t* sW = lds + 2 * HPAD * CK;       // [2][BN][CK]
+  bf16_t* sW = lds + 2 * HPAD * CK;       // [WS][BN][CK]
+  bf16_t* sD = sW + WS * BN * CK;         // [8][CK] landing area of the zero-fill dummies
 
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -53,62 +61,65 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
   const unsigned OOB = 0x80000000u;
 
   // ---- per-thread DMA descriptors -------------------------------------------------------------------------
-  // Wave roles for staging: waves 0..5 stream the NEXT chunk's halo (HBM latency, ~2 us) and never wait for it until
-  // the chunk boundary; waves 6..7 stream the next tap's weight slab (L2 resident) and wait for it every step.
-  // vmcnt is per wave and in order, so mixing both streams in one wave would make every step pay the HBM latency.
-  // halo: at tap slot s (0..7) wave w < 6 stages group G = 6 s + w: rows 8G + (l>>3), 16-byte slot l&7, which receives
-  // channel granule (l&7) ^ ((row>>1)&7) (source-side swizzle).
-  const bool halo_wave = wv < HPT;
-  unsigned hoff[8];   // byte offset of the pixel (channel 0 of the chunk) or OOB
-  int hch[8];         // channel offset of this lane's granule inside a chunk
+  // Every wave issues the SAME instruction sequence each step -- its WJ groups of the weight slab of step t+3, then one
+  // group of the next chunk's halo (a zero-fill dummy, offset out of range, when there is nothing to fetch) -- so one
+  // counted wait serves all steps: vmcnt is in order, and behind the slab of step t+1 there are exactly 1 + 2*PER
+  // younger DMAs.  A tap step is only ~0.25 us of MFMA work while an L2 hit takes 0.5-1 us, so the slab has to be
+  // requested three steps ahead (a two-slot ring stalled every step); the HBM-latency halo groups sit BEHIND the slab
+  // groups of their step, where nothing waits on them before the chunk ends.
+  // halo: at tap s (0..5) wave w stages group G = 8 s + w: rows 8G + (l>>3), 16-byte slot l&7, which receives channel
+  // granule (l&7) ^ ((row>>1)&7) (source-side swizzle).
+  unsigned hoff[HTAPS];   // byte offset of the pixel (channel 0 of the chunk) or OOB
+  int hch[HTAPS];         // channel offset of this lane's granule inside a chunk
 #pragma unroll
-  for (int s = 0; s < 8; ++s) {
-    const int G = HPT * s + wv;
+  for (int s = 0; s < HTAPS; ++s) {
+    const int G = NW * s + wv;
     const int hr = 8 * G + (l >> 3);
     const int hy = hr / HW_, hx = hr - hy * HW_;
     const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-    const bool ok = halo_wave && G < HGROUPS && hr < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+    const bool ok = G < HGROUPS && hr < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
     hch[s] = ((l & 7) ^ ((hr >> 1) & 7)) * 8;
     hoff[s] = ok ? (unsigned)((iy * W + ix) * a.x_ld * 2) : OOB;
   }
-  // weight slab: wave 6 stages the even 8-row groups, wave 7 the odd ones: rows n = 8 (2j + wsel) + (l>>3);
-  // (n>>1)&7 = (4 wsel + (l>>4)) & 7 does not depend on j
-  const int wsel = wv - HPT;
-  const int wch = ((l & 7) ^ ((4 * wsel + (l >> 4)) & 7)) * 8;
-  constexpr int WJ = BN / 16;            // groups per weight-loader wave
+  // weight slab: wave w stages groups g = 8 j + w: rows n = 8 g + (l>>3); (n>>1)&7 = (4 w + (l>>4)) & 7 for every j
+  const int wch = ((l & 7) ^ ((4 * wv + (l >> 4)) & 7)) * 8;
   unsigned woff[WJ];
 #pragma unroll
   for (int j = 0; j < WJ; ++j) {
-    const int n = 8 * (2 * j + wsel) + (l >> 3), ng = n0 + n;
-    woff[j] = (!halo_wave && ng < a.Cout) ? (unsigned)(ng * a.Ktot * 2) : OOB;
+    const int g = NW * j + wv;
+    const int n = 8 * g + (l >> 3), ng = n0 + n;
+    woff[j] = (g < WGROUPS && ng < a.Cout) ? (unsigned)(ng * a.Ktot * 2) : OOB;
   }
   const int Cin = a.Cin;
   const int nChunks = (Cin + CK - 1) / CK;
 
-  auto stage_halo_piece = [&](int s, int chunk, int buf) {   // s in 0..7, halo waves only
+  // one halo group; s < 0 or a chunk past the end: zero-fill dummy
+  auto stage_halo_piece = [&](int s, int chunk, int buf) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (HPT * s + wv < HGROUPS) {
-      const int ch = chunk * CK + hch[s];
-      const unsigned off = (ch < Cin) ? hoff[s] + (unsigned)(ch * 2) : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sH + buf * HPAD * CK + (HPT * s + wv) * 8 * CK), 16,
-                                               off | (hoff[s] & OOB), 0, 0, 0);
-    }
+    const bool real = s >= 0 && chunk < nChunks && NW * s + wv < HGROUPS;
+    const int si = s < 0 ? 0 : s;
+    const int ch = chunk * CK + hch[si];
+    const unsigned off = (real && ch < Cin) ? hoff[si] + (unsigned)(ch * 2) : OOB;
+    bf16_t* dst = real ? sH + buf * HPAD * CK + (NW * si + wv) * 8 * CK : sD;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)dst, 16, real ? (off | (hoff[si] & OOB)) : OOB, 0, 0, 0);
 #else
     (void)s; (void)chunk; (void)buf;
 #endif
   };
-  auto stage_weights = [&](int chunk, int tap, int buf) {    // weight waves only
+  auto stage_weights = [&](int chunk, int tap, int slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int ch = chunk * CK + wch;
     const unsigned koff = (unsigned)((tap * Cin + ch) * 2);
+    const bool real = chunk < nChunks && ch < Cin;
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
-      const unsigned off = (ch < Cin) ? woff[j] + koff : OOB;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)(sW + buf * BN * CK + 8 * (2 * j + wsel) * CK), 16,
-                                               off | (woff[j] & OOB), 0, 0, 0);
+      const int g = NW * j + wv;
+      const unsigned off = real ? woff[j] + koff : OOB;
+      bf16_t* dst = g < WGROUPS ? sW + slot * BN * CK + 8 * g * CK : sD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, g < WGROUPS ? (off | (woff[j] & OOB)) : OOB, 0, 0, 0);
     }
 #else
-    (void)chunk; (void)tap; (void)buf;
+    (void)chunk; (void)tap; (void)slot;
 #endif
   };
 
@@ -125,29 +136,26 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_v;
   }
 
-  // prologue: whole halo of chunk 0 + first weight slab
-  if (halo_wave) {
+  // prologue, shaped like three steps of the loop: (whole halo of chunk 0, slab 0), (slab 1, dummy), (slab 2, dummy)
 #pragma unroll
-    for (int s = 0; s < 8; ++s) stage_halo_piece(s, 0, 0);
-  } else {
-    stage_weights(0, 0, 0);
-  }
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  for (int s = 0; s < HTAPS; ++s) stage_halo_piece(s, 0, 0);
+  stage_weights(0, 0, 0);
+  stage_weights(0, 1, 1); stage_halo_piece(-1, 0, 1);
+  stage_weights(0, 2, 2); stage_halo_piece(-1, 0, 1);
+  wait_vm<2 * PER>();                     // halo of chunk 0 and slab 0 (everything but the last two "steps")
+  asm volatile("s_barrier" ::: "memory");
 
   int step = 0;
+  int pc = 0, pt = 3;                      // (chunk, tap) of the slab to request: step + 3
   for (int chunk = 0; chunk < nChunks; ++chunk) {
     const int hb = chunk & 1;
     int nks = (Cin - chunk * CK + 15) >> 4;
     if (nks > 4) nks = 4;
     for (int tap = 0; tap < 9; ++tap, ++step) {
-      const int wb = step & 1;
-      if (a.dbg & 2) {
-      } else if (halo_wave) {            // one piece of the next chunk's halo per tap; lands any time before the chunk ends
-        if (tap < 8 && chunk + 1 < nChunks) stage_halo_piece(tap, chunk + 1, hb ^ 1);
-      } else {                    // next weight slab
-        if (tap < 8) stage_weights(chunk, tap + 1, wb ^ 1);
-        else if (chunk + 1 < nChunks) stage_weights(chunk + 1, 0, wb ^ 1);
-      }
+      const int wb = step & (WS - 1);
+      stage_weights(pc, pt, (step + 3) & (WS - 1));
+      stage_halo_piece(tap < HTAPS ? tap : -1, chunk + 1, hb ^ 1);
+      if (++pt == 9) { pt = 0; ++pc; }
       const int ky = tap / 3, kx = tap - ky * 3;
       const int oy = (MODE == 0) ? ky : 2 - ky, ox = (MODE == 0) ? kx : 2 - kx;
       const bf16_t* hbase = sH + hb * HPAD * CK;
@@ -174,12 +182,15 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
       }
-      // weight waves wait for their (L2-resident) slab every step; halo waves only at the chunk boundary.
-      // Raw s_barrier: __syncthreads() would make every wave drain its DMA queue (vmcnt(0)) here.
-      if ((!halo_wave && !(a.dbg & 1)) || tap == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // the slab of step+1 (requested two steps ago) and every older DMA of this wave -- in particular the next chunk's
+      // halo groups, requested in taps 0..5 -- have landed; the barrier extends that to all waves.
+      // Raw s_barrier: __syncthreads() would drain the whole DMA queue (vmcnt(0)) here.
+      wait_vm<1 + 2 * PER>();
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     }
   }
+  wait_vm<0>();                            // dummy slabs / halo groups still target the LDS the epilogue reuses
+  asm volatile("s_barrier" ::: "memory");
 
   if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(a.y)[0] = 1.f; return; }
   conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
@@ -200,7 +211,7 @@ int launch3(const ConvK& k0, int B, hipStream_t st, long long partial_cap) {
   ConvK k = k0;
   k.n_tiles = cdiv(k.IW, TW) * cdiv(k.IH, TH);
   if ((long long)B * k.n_tiles * k.G16 * 2 > partial_cap) k.stats_partial = nullptr;
-  const size_t lds = (size_t)(2 * HPAD * CK + 2 * BN * CK) * sizeof(bf16_t);
+  const size_t lds = (size_t)(2 * HPAD * CK + WS * BN * CK + 8 * CK) * sizeof(bf16_t);
   const int tiles_x = cdiv(k.IW, TW), tiles_y = cdiv(k.IH, TH);
   dim3 grid(tiles_x * tiles_y, cdiv(k.Cout, BN), B);
   static bool attr_done[2] = {false, false};

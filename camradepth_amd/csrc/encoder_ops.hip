@@ -365,21 +365,39 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > N) p1 = N;
   const long long total = (p1 - p0) * CG;
-  for (long long i = threadIdx.x; i < total; i += TPB) {
-    const int cg = (int)(i % CG);
-    const long long n = p0 + i / CG;
-    const int h = (cg * 8) / d;
-    const int m = idx[((long long)b * N + n) * heads + h];
-    const float g = scale * dS[(long long)b * N + n];
-    float kv[8], qv[8];
-    load8(k, ((long long)b * M + m) * C + cg * 8, 0, kv);
-    load8(q, ((long long)b * N + n) * C + cg * 8, 0, qv);
+  // UB items per thread and pass: first the index / gradient scalars of all of them, then the dependent row gathers, so
+  // that a pass costs two memory latencies instead of two per item
+  constexpr int UB = 4;
+  for (long long i0 = threadIdx.x; i0 < total; i0 += (long long)UB * TPB) {
+    int cgv[UB], mv[UB];
+    long long nv[UB];
+    float gv[UB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) kv[j] *= g;
-    store8_bf16(dq, ((long long)b * N + n) * C + cg * 8, kv);
-    float* dst = use_lds ? &sdk[m * C + cg * 8] : &dk[((long long)b * M + m) * C + cg * 8];
+    for (int u = 0; u < UB; ++u) {
+      const long long i = i0 + (long long)u * TPB;
+      const bool ok = i < total;
+      cgv[u] = ok ? (int)(i % CG) : 0;
+      nv[u] = ok ? p0 + i / CG : p0;
+      const int h = (cgv[u] * 8) / d;
+      mv[u] = idx[((long long)b * N + nv[u]) * heads + h];
+      gv[u] = ok ? scale * dS[(long long)b * N + nv[u]] : 0.f;
+    }
+    float kv[UB][8], qv[UB][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(dst + j, g * qv[j]);
+    for (int u = 0; u < UB; ++u) {
+      load8(k, ((long long)b * M + mv[u]) * C + cgv[u] * 8, 0, kv[u]);
+      load8(q, ((long long)b * N + nv[u]) * C + cgv[u] * 8, 0, qv[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (i0 + (long long)u * TPB >= total) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kv[u][j] *= gv[u];
+      store8_bf16(dq, ((long long)b * N + nv[u]) * C + cgv[u] * 8, kv[u]);
+      float* dst = use_lds ? &sdk[mv[u] * C + cgv[u] * 8] : &dk[((long long)b * M + mv[u]) * C + cgv[u] * 8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[u][j]);
+    }
   }
   if (use_lds) {
     __syncthreads();
@@ -485,7 +503,8 @@ extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS
   const int C = heads * d;
   const size_t lds = (size_t)M * C * sizeof(float);
   const int use_lds = lds <= 64 * 1024;
-  int nblk = cdiv(N, use_lds ? 512 : 64);
+  // pixels per workgroup: with the LDS accumulator every workgroup ends with M*C global atomics, so not too few
+  int nblk = cdiv(N, use_lds ? 128 : 64);
   int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   int chunk = cdiv(N, nblk);

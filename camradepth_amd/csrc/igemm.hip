@@ -260,6 +260,10 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
       const int nK = cdiv(k.Ktot, BK);
       if (nK <= 2) return launch<2, 2, 1, 1, 2>(k, d->B, st, pcap);
       if (nK <= 4) return launch<2, 2, 1, 1, 3>(k, d->B, st, pcap);
+      // deep K on a grid that cannot even cover the CUs (the spatial-reduction convs: 32 workgroups x 32..64 K-slabs):
+      // the only parallelism left is memory-level, so a workgroup keeps seven slabs in flight (128 KB of LDS)
+      const long long small_tiles = (long long)cdiv(k.OHW, 64) * cdiv(d->Cout, 64) * d->B;
+      if (nK >= 10 && small_tiles <= 256) return launch<2, 2, 1, 1, 8>(k, d->B, st, pcap);
       return launch<2, 2, 1, 1, 4>(k, d->B, st, pcap);
     }
   }

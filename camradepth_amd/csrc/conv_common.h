@@ -167,6 +167,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
   }
 }
 
+// Waves of a workgroup that hold no output tile (split-K groups 1.. of k_igemm) must still meet the barriers of
+// conv_epilogue: one in the LDS-staged vector path, one before the statistics fold.  Keep in step with conv_epilogue.
+__device__ __forceinline__ void conv_epilogue_idle(const ConvK& a) {
+  const bool vec = a.out_mode == 0 && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
+  if (vec) __syncthreads();
+  if (a.stats) __syncthreads();
+}
+
 // stats[b][g][which] += sum over tiles of the per-tile partials written by conv_epilogue
 __global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, float* stats);
 

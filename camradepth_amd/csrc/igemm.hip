@@ -37,18 +37,25 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 // NST = LDS stages.  A K-slab of a 64x64 tile is only four MFMAs per wave, so with one slab in flight every K-step of
 // the small encoder GEMMs costs a full memory latency (12 us for K = 640); NST - 1 slabs in flight hide it.
-template <int WM, int WN, int TM, int TN, int MODE, int NST>
-__global__ __launch_bounds__(256) void k_igemm(ConvK a) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+// KG > 1: intra-workgroup split-K.  KG groups of 4 waves each walk every KG-th K-slab with their own LDS stages and
+// accumulators; the partial tiles are added through LDS and group 0 runs the epilogue.  For deep K on a grid too small
+// to cover the CUs (the k = sr patch convs: 32 workgroups x 32..64 slabs, fc2 of the small stages) the K loop is bound
+// by the issue cost of the LDS-DMA pieces (~0.45 us per slab whatever the stage count): more waves issue them in
+// parallel.
+template <int WM, int WN, int TM, int TN, int MODE, int NST, int KG = 1>
+__global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
+  static_assert(WM * WN == 4, "4 waves per group");
+  static_assert(KG == 1 || (TM == 1 && TN == 1), "split-K groups exchange a single 32x32 tile per wave");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_IT = BM / 32, B_IT = BN / 32;   // each wave DMAs 8 rows per instruction, 4 waves -> 32 rows per pass
   constexpr int PER = A_IT + B_IT;                // DMA instructions per thread and stage
   static_assert((NST - 2) * PER < 64, "vmcnt is a 6-bit counter");
-  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];     // NST * (BM + BN) * BK
-  bf16_t* sA = lds;
-  bf16_t* sB = lds + NST * BM * BK;
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];     // KG * NST * (BM + BN) * BK
+  const int grp = KG > 1 ? (int)(threadIdx.x >> 8) : 0;
+  bf16_t* sA = lds + grp * NST * (BM + BN) * BK;
+  bf16_t* sB = sA + NST * BM * BK;
 
-  const int t = threadIdx.x, l = t & 63, wave = t >> 6;
+  const int t = threadIdx.x & 255, l = t & 63, wave = t >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (a.dbg & 8) return;
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
     const int n = r0 + 32 * j, ng = n0 + n;
     woff[j] = (n < BN && ng < a.Cout) ? (unsigned)(ng * a.Ktot * 2) : OOB;
   }
-  int kf = g * 8, kc = g * 8, ky = 0, kx = 0;
+  int kf = g * 8 + grp * BK, kc = kf, ky = 0, kx = 0;
   while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
 
   typedef __attribute__((address_space(3))) void* lds_ptr;
@@ -118,7 +125,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
 #endif
       }
     }
-    kf += BK; kc += BK;
+    kf += KG * BK; kc += KG * BK;
     while (kc >= a.Cin) { kc -= a.Cin; if (++kx == a.KW) { kx = 0; ++ky; } }
   };
 
@@ -128,14 +135,14 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (l & 31);
-    const float bias_v = (a.bias && col < a.Cout) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
+    const float bias_v = (a.bias && col < a.Cout && grp == 0) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_v;
   }
 
-  const int nK = (a.dbg & 16) ? 0 : (a.Ktot + BK - 1) / BK;
+  const int nK = ((a.dbg & 16) ? 0 : (a.Ktot + BK - 1) / BK + KG - 1) / KG;     // slabs per group (uniform: the tail is zero fill)
   // Slabs past the K range are still issued (their offsets are out of range: zero fill, no memory traffic), so the
   // number of DMAs in flight behind slab kt is always (NST - 2) * PER and the wait needs no tail cases.
 #pragma unroll
@@ -171,6 +178,25 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   wait_vm<0>();                             // the zero-fill slabs still target the LDS the epilogue reuses
   __syncthreads();
   if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(a.y)[0] = 1.f; return; }
+  if (KG > 1) {    // groups 1.. park their tile in their own (now idle) stage area, group 0 adds them up
+    float* park = reinterpret_cast<float*>(sA);
+    if (grp > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) park[r * 256 + t] = acc[0][0][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int g2 = 1; g2 < KG; ++g2) {
+        const float* src = reinterpret_cast<const float*>(lds + g2 * NST * (BM + BN) * BK);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += src[r * 256 + t];
+      }
+    } else {
+      conv_epilogue_idle(a);       // same barriers as the epilogue below
+      return;
+    }
+  }
 
   // ---- epilogue (conv_common.h) ----
   conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
@@ -183,29 +209,29 @@ __global__ __launch_bounds__(256) void k_igemm(ConvK a) {
   });
 }
 
-template <int WM, int WN, int TM, int TN, int MODE, int NST>
+template <int WM, int WN, int TM, int TN, int MODE, int NST, int KG = 1>
 void launch_mode(const ConvK& k, dim3 grid, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  constexpr size_t lds = (size_t)NST * (BM + BN) * BK * sizeof(bf16_t);
+  constexpr size_t lds = (size_t)KG * NST * (BM + BN) * BK * sizeof(bf16_t);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<WM, WN, TM, TN, MODE, NST>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<WM, WN, TM, TN, MODE, NST, KG>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, MODE, NST>), grid, dim3(256), lds, st, k);
+  hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, MODE, NST, KG>), grid, dim3(256 * KG), lds, st, k);
 }
 
-template <int WM, int WN, int TM, int TN, int NST>
+template <int WM, int WN, int TM, int TN, int NST, int KG = 1>
 int launch(const ConvK& k0, int B, hipStream_t st, long long partial_cap) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   ConvK k = k0;
   k.n_tiles = cdiv(k.OHW, BM);
   if ((long long)B * k.n_tiles * k.G16 * 2 > partial_cap) k.stats_partial = nullptr;
   dim3 grid(k.n_tiles, cdiv(k.Cout, BN), B);
-  if (k.gather_mode == 0) launch_mode<WM, WN, TM, TN, 0, NST>(k, grid, st);
-  else if (k.stride == 1) launch_mode<WM, WN, TM, TN, 1, NST>(k, grid, st);
-  else launch_mode<WM, WN, TM, TN, 2, NST>(k, grid, st);
+  if (k.gather_mode == 0) launch_mode<WM, WN, TM, TN, 0, NST, KG>(k, grid, st);
+  else if (k.stride == 1) launch_mode<WM, WN, TM, TN, 1, NST, KG>(k, grid, st);
+  else launch_mode<WM, WN, TM, TN, 2, NST, KG>(k, grid, st);
   if (k.stats && k.stats_partial)
     hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, k.n_tiles, k.G16, k.stats);
   CRD_LAUNCH_CHECK("crd_conv_igemm");
@@ -260,10 +286,9 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
       const int nK = cdiv(k.Ktot, BK);
       if (nK <= 2) return launch<2, 2, 1, 1, 2>(k, d->B, st, pcap);
       if (nK <= 4) return launch<2, 2, 1, 1, 3>(k, d->B, st, pcap);
-      // deep K on a grid that cannot even cover the CUs (the spatial-reduction convs: 32 workgroups x 32..64 K-slabs):
-      // the only parallelism left is memory-level, so a workgroup keeps seven slabs in flight (128 KB of LDS)
+      // deep K on a grid that cannot even cover the CUs (the spatial-reduction convs: 32 workgroups x 32..64 K-slabs)
       const long long small_tiles = (long long)cdiv(k.OHW, 64) * cdiv(d->Cout, 64) * d->B;
-      if (nK >= 10 && small_tiles <= 256) return launch<2, 2, 1, 1, 8>(k, d->B, st, pcap);
+      if (nK >= 8 && small_tiles <= 256) return launch<2, 2, 1, 1, 2, 4>(k, d->B, st, pcap);   // 4-way split-K inside the workgroup (2 x 4 stages measured slower)
       return launch<2, 2, 1, 1, 4>(k, d->B, st, pcap);
     }
   }

@@ -71,6 +71,24 @@ def per_kernel_timing(ts, reps=3):
     return {k: (v[0] / reps, v[1] / reps, v[2] / reps) for k, v in agg.items()}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
+    tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).  The passes profile this same
+    workload (B = 8, 256x416); returns None for other shapes or when the file is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    ks = json.load(open(path))["kernels"]
+    stem = kernel.rstrip(">").replace(" ", "")
+    n = tot = 0.0
+    for name, v in ks.items():
+        nm = name.replace(" ", "")
+        if nm.startswith(stem + ",") or nm.rstrip(">") == stem:
+            n += v["launches"]
+            tot += v["hbm_bytes_per_launch"] * v["launches"]
+    return round(tot / n) if n else None
+
+
 def cpu_baseline(variant, seconds_budget=25.0):
     """The CPU oracle (oracle/, a port of the reference verified against it) timed on this box's host cores."""
     import numpy as np  # noqa: F401
@@ -186,7 +204,8 @@ def main():
         n, ms_tot, fl = agg[dom]
         ach = fl / (ms_tot * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                           "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+                           "traffic": pmc_traffic(dom) if (a.batch, a.height, a.width, a.variant) == (8, 256, 416, "base") else None,
                            "launches_per_step": n, "avg_launch_us": round(1e3 * ms_tot / n, 2),
                            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
         out["kernels"] = {k: {"launches": v[0], "ms_per_step": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}

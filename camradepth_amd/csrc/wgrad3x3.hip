@@ -11,6 +11,7 @@
 // are filled by LDS-DMA three steps ahead (HBM latency), so every input row is fetched once per strip instead of
 // nine times, and dy once per ci chunk.  Both operands are pixel-major, so MFMA fragments are read with the
 // transposing LDS read ds_read_b64_tr_b16.  Partial results leave the workgroup once, as fp32 atomics.
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -213,7 +214,9 @@ int launch_w3(const Wg3K& k0, hipStream_t st) {
   constexpr int COT = WCO * TCO * 16;
   const size_t lds = (size_t)(XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
   const int chunks = cdiv(k.Cin, XLD);
-  int wgs = 512 / chunks;                        // ~2 workgroups per CU in total
+  // one workgroup per CU in total: every row split adds Cout x 9 x Cin fp32 atomics (37 M per launch at 512 workgroups,
+  // ~0.2 ms at the ~170 G/s the L2s sustain), which a second workgroup per CU does not win back (30.0 vs 30.3 ms/step)
+  int wgs = 256 / chunks;
   if (wgs < 1) wgs = 1;
   if (wgs > k.total_rows / 8) wgs = (int)(k.total_rows / 8 > 0 ? k.total_rows / 8 : 1);
   k.rows_per_wg = (int)((k.total_rows + wgs - 1) / wgs);

@@ -329,12 +329,13 @@ __global__ __launch_bounds__(TPB) void k_head2_bwd_data(const float* gd, const b
   store8_bf16(dz, off, acc);
 }
 
-// dw[c*9 + tap] += sum_p dy[p] * a[p + off(tap)][c] ; db += sum_p dy[p]
+// rows[r][c*9 + tap] += sum_p dy[p] * a[p + off(tap)][c] ; rows[r][288] += sum_p dy[p], r = workgroup % replicas.
+// The 289 sums of a workgroup are folded with shuffles (pixel lanes of a wave) and four LDS rounds (waves); with one
+// accumulator for all 2048 workgroups the chain of contended atomics (2048 x 32 per 128-byte line x 2.6 ns) was the
+// whole 170 us of this kernel, hence the copies (crd_wgrad_unpack sums them).
 __global__ __launch_bounds__(TPB) void k_head2_wgrad(const float* gd, const bf16_t* add, int add_ld, const bf16_t* a, int H, int W,
-                                                     int chunk, float* dw, float* db) {
+                                                     int chunk, float* rows, int replicas) {
   __shared__ float sm[9 * 32 + 1];
-  for (int i = threadIdx.x; i < 9 * 32 + 1; i += TPB) sm[i] = 0.f;
-  __syncthreads();
   const int b = blockIdx.y, q = threadIdx.x & 3, pl = threadIdx.x >> 2;
   const float* gb = gd + (long long)b * H * W;
   const bf16_t* addb = add ? add + (long long)b * H * W * add_ld : nullptr;
@@ -351,7 +352,7 @@ __global__ __launch_bounds__(TPB) void k_head2_wgrad(const float* gd, const bf16
     float dyv = gb[pix];
     if (addb) dyv += bf2f(addb[(long long)pix * add_ld]);
     dyv = bf_round(dyv);
-    if (q == 0) bs += dyv;
+    bs += dyv;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int iy = py + ky - 1;
@@ -367,14 +368,31 @@ __global__ __launch_bounds__(TPB) void k_head2_wgrad(const float* gd, const bf16
       }
     }
   }
+  // pixel lanes of the wave (lane bits 2..5)
+  for (int o = 4; o < 64; o <<= 1) {
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) atomicAdd(&sm[t * 32 + q * 8 + j], acc[t][j]);
-  if (q == 0) atomicAdd(&sm[288], bs);
-  __syncthreads();
-  for (int i = threadIdx.x; i < 288; i += TPB) atomicAdd(&dw[(i & 31) * 9 + (i >> 5)], sm[i]);
-  if (threadIdx.x == 0) atomicAdd(db, sm[288]);
+      for (int j = 0; j < 8; ++j) acc[t][j] += __shfl_xor(acc[t][j], o);
+    bs += __shfl_xor(bs, o);
+  }
+  const int wave = threadIdx.x >> 6, l = threadIdx.x & 63;
+  for (int w = 0; w < TPB / 64; ++w) {
+    if (wave == w && l < 4) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float* p = &sm[t * 32 + q * 8 + j];
+          *p = w == 0 ? acc[t][j] : *p + acc[t][j];
+        }
+      if (l == 0) sm[288] = w == 0 ? bs : sm[288] + bs;
+    }
+    __syncthreads();
+  }
+  float* dst = rows + (long long)((blockIdx.y * gridDim.x + blockIdx.x) % replicas) * 289;
+  for (int i = threadIdx.x; i < 288; i += TPB) atomicAdd(&dst[(i & 31) * 9 + (i >> 5)], sm[i]);
+  if (threadIdx.x == 0) atomicAdd(&dst[288], sm[288]);
 }
 
 inline int blocks_for(long long total) {
@@ -483,8 +501,9 @@ extern "C" int crd_head_conv2_fwd(const void* a, const float* w, const float* bi
 }
 
 extern "C" int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
-                                  int32_t B, int32_t H, int32_t W, void* dz, float* dw, float* dbias, crd_stream_t stream) {
-  CRD_CHECK_ARG(gd && a && w && dz && dw && dbias, "crd_head_conv2_bwd: null pointer");
+                                  int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas,
+                                  crd_stream_t stream) {
+  CRD_CHECK_ARG(gd && a && w && dz && dw_rows && replicas >= 1, "crd_head_conv2_bwd: null pointer / replicas < 1");
   const bf16_t* addp = add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(k_head2_bwd_data, dim3((unsigned)cdiv(4ll * H * W, TPB), B), dim3(TPB), 0, st, gd, addp, add_ld,
@@ -496,7 +515,7 @@ extern "C" int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_
   const int chunk = cdiv(P, nblk);
   nblk = cdiv(P, chunk);
   hipLaunchKernelGGL(k_head2_wgrad, dim3(nblk, B), dim3(TPB), 0, st, gd, addp, add_ld, reinterpret_cast<const bf16_t*>(a), H, W, chunk,
-                     dw, dbias);
+                     dw_rows, replicas);
   CRD_LAUNCH_CHECK("crd_head_conv2_bwd");
   return CRD_OK;
 }

@@ -25,6 +25,7 @@ from .params import short_res_block_plan
 # developer switch: CRD_NO_GROUP_WGRAD=1 runs every small weight gradient as its own launch (A/B against the grouped launch)
 GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
+HEAD_ROWS = 64        # same for Depth_Activation.conv_2 (2048 workgroups x 289 sums)
 
 BF16, F32 = torch.bfloat16, torch.float32
 
@@ -125,7 +126,7 @@ class Plan:
         self.convs = []
         self.keep = []                              # keep ctypes structs / tensors alive
         self.dw_entries, self.dw_grads = [], []
-        self.row_grads = []                         # (param, C, rows buffer [R][C], R, tag): gradient = sum of the rows
+        self.row_grads = []                         # (param, C, rows buffer, R, tag, offset, row stride): gradient = sum of the rows
         self.shapes = {}
         self.fwd_marks = []
         self._defer = None
@@ -490,8 +491,10 @@ class Plan:
             grp = []
             add = (dsrc.t, dsrc.ld, 128) if j < 5 else (None, 0, 0)
             dA = self.act(32, Hj, Wj)
-            self._emit(grp, "crd_head_conv2_bwd", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t,
-                                                   self.g(name + ".conv_2.weight"), self.g(name + ".conv_2.bias")])
+            rows = self.zb(HEAD_ROWS, 289)            # copies of [dw (288) | dbias]; the unpack kernel sums them
+            self.row_grads.append((name + ".conv_2.weight", 288, rows, HEAD_ROWS, self._tag, 0, 289))
+            self.row_grads.append((name + ".conv_2.bias", 1, rows, HEAD_ROWS, self._tag, 288, 289))
+            self._emit(grp, "crd_head_conv2_bwd", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t, rows, HEAD_ROWS])
             self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_1.bias"))
             self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
                       region=("ds", id(dsrc), 0, 128))
@@ -649,7 +652,7 @@ class Plan:
         # attention branch
         T, dSv = self.zb(B, Cs), self.new((B, N), F32)
         dbp_rows = self.zb(B, Cs)
-        self.row_grads.append((a + ".proj.bias", Cs, dbp_rows, B, self._tag))
+        self.row_grads.append((a + ".proj.bias", Cs, dbp_rows, B, self._tag, 0, Cs))
         self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
         Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         self._emit(g, "crd_f32_to_bf16_rows", [T, Cs, Tb.t, Cs, 0, B, Cs, None, 1, None, 0, 0])
@@ -738,8 +741,8 @@ class Plan:
         items = [(order.index(cw.tag), cw, None) for cw in unpack]
         for t in self.dw_grads:                        # depthwise: one entry for the 9 taps, one for the bias row
             items += [(order.index(t[3]), None, t + ("weight",)), (order.index(t[3]), None, t + ("bias",))]
-        for name, Cn, rows, R, tag in self.row_grads:
-            items.append((order.index(tag), None, (name, Cn, rows, tag, ("rows", R))))
+        for name, Cn, rows, R, tag, off, stride in self.row_grads:
+            items.append((order.index(tag), None, (name, Cn, rows, tag, ("rows", R, off, stride))))
         items.sort(key=lambda it: it[0])
         uentries, self.unpack_ranges = [], {}
         for seg_i, cw, dwt in items:
@@ -752,9 +755,9 @@ class Plan:
             else:
                 name, hid, dw10, _, which = dwt
                 if isinstance(which, tuple):           # per-sample rows of a vector gradient
-                    u.src, u.dst, u.cmap = dw10.t.data_ptr(), self.g(name).data_ptr(), None
+                    u.src, u.dst, u.cmap = dw10.t.data_ptr() + 4 * which[2], self.g(name).data_ptr(), None
                     u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, 1, hid
-                    u.replicas, u.replica_stride = which[1], hid
+                    u.replicas, u.replica_stride = which[1], which[3]
                     nel = hid
                     lo, hi, mx = self.unpack_ranges.get(order[seg_i], (len(uentries), len(uentries), 1))
                     self.unpack_ranges[order[seg_i]] = (lo, len(uentries) + 1, max(mx, nel))

@@ -100,7 +100,7 @@ _SIGS = {
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifppp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
     "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiiip", "crd_scale_f32": "pplfp",
-    "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp", "crd_head_conv2_fwd": "pppiiippiip", "crd_head_conv2_bwd": "ppiippiiipppp",
+    "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp", "crd_head_conv2_fwd": "pppiiippiip", "crd_head_conv2_bwd": "ppiippiiippip",
     "crd_weight_pack": "pilp", "crd_wgrad_unpack": "pilip",
     "crd_masked_l1_fwd": "pplpp", "crd_masked_l1_bwd": "pplppfpp", "crd_ce_fwd": "ppiilpp",
     "crd_ce_focal_bwd": "ppiilppfpp",

@@ -215,9 +215,11 @@ int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, int32_t d_ld
 int crd_head_conv2_fwd(const void* a, const float* w, const float* bias, int32_t B, int32_t H, int32_t W, float* depth,
                        void* copy, int32_t copy_ld, int32_t copy_coff, crd_stream_t stream);
 /* Backward of the above fused with the sigmoid backward: dy = gd (+ add, a bf16 channel);
- * dz = a(1-a) * conv2^T(dy) (bf16 [B][H][W][32]); dw[1][32][3][3] += ..., dbias[0] += sum dy (fp32 atomics). */
+ * dz = a(1-a) * conv2^T(dy) (bf16 [B][H][W][32]).  Parameter gradients: dw_rows is float [replicas][289], zeroed by the
+ * caller; every row holds dw[1][32][3][3] (288 values, reference order) followed by dbias, workgroups spread their
+ * fp32 atomics over the rows and the gradient is the sum of the rows (crd_wgrad_unpack, replicas = rows). */
 int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
-                       int32_t B, int32_t H, int32_t W, void* dz, float* dw, float* dbias, crd_stream_t stream);
+                       int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas, crd_stream_t stream);
 /* da <- da * a * (1-a)   (bf16, n elements, n % 8 == 0): backward of the sigmoid in Depth_Activation */
 int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream);
 

@@ -24,6 +24,7 @@ from .params import short_res_block_plan
 
 # developer switch: CRD_NO_GROUP_WGRAD=1 runs every small weight gradient as its own launch (A/B against the grouped launch)
 GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
+SPLIT_N = os.environ.get("CRD_NO_SPLIT_N") is None      # developer switch for the ragged-tile split of 3x3 data gradients
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
 HEAD_ROWS = 64        # same for Depth_Activation.conv_2 (2048 workgroups x 289 sums)
 
@@ -194,6 +195,19 @@ class Plan:
         else:
             flops = 2.0 * self.B * spec["OH"] * spec["OW"] * spec["cout"] * w.cin_ref * w.taps
         halo = spec["k"] == 3 and spec["stride"] == 1 and spec["out_mode"] == 0 and spec["OW"] >= 32 and spec["OH"] >= 8
+        # The halo kernel's widest tile is 128 output channels.  A data gradient with N = 144 / 296 / 304 would run its last
+        # tile 13-37 % full; the ragged tail goes to a second launch with a narrower tile instead (same operands, weight
+        # rows and output slice offset by the split point).
+        cout = spec["cout"]
+        if (halo and SPLIT_N and cout > 128 and 0 < cout % 128 <= 64 and spec["bias"] is None and spec["stats"] is None
+                and spec["res"] is None and "w_row0" not in spec):
+            c_main = cout // 128 * 128
+            for c0, c1 in ((0, c_main), (c_main, cout)):
+                sub = dict(spec)
+                sub.update(cout=c1 - c0, y=spec["y"].sl(c0, c1), w_row0=c0, flops_override=flops * (c1 - c0) / cout)
+                self.conv(lst, sub, None if region is None else region[:-2] + (region[-2] + c0, region[-2] + c1))
+            return None
+        flops = spec.get("flops_override", flops)
         kname = halo_tile(spec["cout"]) if halo else igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B)
         meta = {"kernel": kname, "flops": flops,
                 "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
@@ -261,6 +275,8 @@ class Plan:
             d = L.ConvDesc()
             d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = P(x), x.ld, x.coff, self.B, x.H, x.W, sp["cin"]
             d.w, d.Cout, d.KH, d.KW, d.stride, d.pad = P(w), sp["cout"], sp["k"], sp["k"], sp["stride"], sp["pad"]
+            if sp.get("w_row0"):                          # output-channel sub-range: skip the packed weight rows before it
+                d.w += sp["w_row0"] * sp["k"] * sp["k"] * sp["cin"] * 2
             d.OH, d.OW, d.gather_mode = sp["OH"], sp["OW"], sp["gather"]
             d.y, d.y_ld, d.y_coff, d.y_f32 = P(y), y.ld, y.coff, y.f32
             d.out_mode, d.patch_k, d.patch_c = sp["out_mode"], sp["patch_k"], sp["patch_c"]

@@ -195,61 +195,76 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
 // registers hold 16 keys: the max over keys is in-register plus one cross-half shuffle.
 // One wave = 32 queries; K/Q fragments are read straight from L2-resident global memory.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TPB) void k_attn_scores(const bf16_t* q, const bf16_t* k, int N, int M, int heads, int d,
-                                                     float scale, float* S, short* idx) {
+// One wave = 32 queries x ONE head (blockDim = 64 * heads * qg: wave w -> head w % heads, query group w / heads), so the
+// per-head chain of dependent loads runs in parallel across the waves instead of serially inside one (stage 4: 8 heads);
+// the heads' maxima of a query group meet in LDS.
+__global__ __launch_bounds__(1024) void k_attn_scores(const bf16_t* q, const bf16_t* k, int N, int M, int heads, int d,
+                                                      float scale, float* S, short* idx, int qg) {
+  __shared__ float smax[16][32];
   const int b = blockIdx.y;
   const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int n0 = (blockIdx.x * 4 + wave) * 32;
-  if (n0 >= N) return;
+  const int h = wave % heads, g = wave / heads;
+  const int n0 = (blockIdx.x * qg + g) * 32;
   const int C = heads * d;
   const int n = n0 + (l & 31);
   const bool nok = n < N;
   const bf16_t* qb = q + ((long long)b * N + (nok ? n : 0)) * C;
   const bf16_t* kb = k + (long long)b * M * C;
   const int half = l >> 5;
-  float Ssum = 0.f;
   const int nks = (d + 15) / 16;
-  for (int h = 0; h < heads; ++h) {
-    // query fragments for this head (B operand: col = lane&31, k = 8*half + j within each 16-chunk)
-    bf16x8 qf[4];
+  // query fragments for this head (B operand: col = lane&31, k = 8*half + j within each 16-chunk)
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    uint4 u = make_uint4(0, 0, 0, 0);
+    int kk = ks * 16 + half * 8;
+    if (ks < nks && kk < d && nok) u = *reinterpret_cast<const uint4*>(qb + h * d + kk);
+    qf[ks] = *reinterpret_cast<bf16x8*>(&u);
+  }
+  float best = -INFINITY;
+  int besti = 0;
+  // key fragments (A operand: row = lane&31 -> key, k = 8*half + j) are fetched one 32-key tile ahead of the MFMAs that
+  // consume them
+  auto load_keys = [&](int m0, uint4 (&dst)[4]) {
+    const int mrow = m0 + (l & 31);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      uint4 u = make_uint4(0, 0, 0, 0);
-      int kk = ks * 16 + half * 8;
-      if (ks < nks && kk < d && nok) u = *reinterpret_cast<const uint4*>(qb + h * d + kk);
-      qf[ks] = *reinterpret_cast<bf16x8*>(&u);
+      dst[ks] = make_uint4(0, 0, 0, 0);
+      const int kk = ks * 16 + half * 8;
+      if (ks < nks && kk < d && mrow < M) dst[ks] = *reinterpret_cast<const uint4*>(kb + (long long)mrow * C + h * d + kk);
     }
-    float best = -INFINITY;
-    int besti = 0;
-    for (int m0 = 0; m0 < M; m0 += 32) {
-      f32x16 acc;
+  };
+  uint4 kc[4], kn[4];
+  load_keys(0, kc);
+  for (int m0 = 0; m0 < M; m0 += 32) {
+    if (m0 + 32 < M) load_keys(m0 + 32, kn);
+    f32x16 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const int mrow = m0 + (l & 31);
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        if (ks < nks) {
-          uint4 u = make_uint4(0, 0, 0, 0);
-          int kk = ks * 16 + half * 8;
-          if (kk < d && mrow < M) u = *reinterpret_cast<const uint4*>(kb + (long long)mrow * C + h * d + kk);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&u), qf[ks], acc, 0, 0, 0);
-        }
-      }
+    for (int ks = 0; ks < 4; ++ks)
+      if (ks < nks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&kc[ks]), qf[ks], acc, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        float v = bf_round(bf_round(acc[r]) * scale);
-        if (m < M && v > best) { best = v; besti = m; }
-      }
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      float v = bf_round(bf_round(acc[r]) * scale);
+      if (m < M && v > best) { best = v; besti = m; }
     }
-    // combine the two half-waves (same query column, other 16 rows of every tile)
-    float ob = __shfl_xor(best, 32);
-    int oi = __shfl_xor(besti, 32);
-    if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-    Ssum += best;
-    if (nok && half == 0) idx[((long long)b * N + n) * heads + h] = (short)besti;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) kc[ks] = kn[ks];
   }
-  if (nok && half == 0) S[(long long)b * N + n] = Ssum;
+  // combine the two half-waves (same query column, other 16 rows of every tile)
+  float ob = __shfl_xor(best, 32);
+  int oi = __shfl_xor(besti, 32);
+  if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  if (nok && half == 0) idx[((long long)b * N + n) * heads + h] = (short)besti;
+  if (half == 0) smax[wave][l] = best;
+  __syncthreads();
+  if (h == 0 && half == 0 && nok) {       // S = sum over heads, in head order (as the serial loop did)
+    float Ssum = 0.f;
+    for (int hh = 0; hh < heads; ++hh) Ssum += smax[g * heads + hh][l];
+    S[(long long)b * N + n] = Ssum;
+  }
 }
 
 // xbar[b][c] = mean_n GN(x)[b][n][c] = gamma_c*(mean_n x_c - mu_g)*rstd_g + beta_c   (bf16 out)
@@ -452,9 +467,13 @@ extern "C" int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t 
                                float scale, float* S, int16_t* idx, crd_stream_t stream) {
   CRD_CHECK_ARG(q && k && S && idx, "crd_attn_scores: null pointer");
   CRD_UNSUPPORTED(d % 8 == 0 && d <= 64 && M < 32768, "crd_attn_scores: head dim must be a multiple of 8, <= 64 (got %d)", d);
-  dim3 grid(cdiv(N, 128), B);
-  hipLaunchKernelGGL(k_attn_scores, grid, dim3(TPB), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(q),
-                     reinterpret_cast<const bf16_t*>(k), N, M, heads, d, scale, S, idx);
+  CRD_UNSUPPORTED(heads >= 1 && heads <= 16, "crd_attn_scores: at most 16 heads (got %d)", heads);
+  int qg = 8 / heads;                      // query groups per workgroup: ~8 waves, at most 16
+  if (qg < 1) qg = 1;
+  if (qg > 4) qg = 4;
+  dim3 grid(cdiv(N, 32 * qg), B);
+  hipLaunchKernelGGL(k_attn_scores, grid, dim3(64 * heads * qg), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(q),
+                     reinterpret_cast<const bf16_t*>(k), N, M, heads, d, scale, S, idx, qg);
   CRD_LAUNCH_CHECK("crd_attn_scores");
   return CRD_OK;
 }

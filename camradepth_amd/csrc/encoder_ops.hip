@@ -7,86 +7,122 @@ namespace {
 constexpr int TPB = 256;
 
 // ------------------------------------------------------------------------------------------------
-// Depthwise 3x3, stride 1, pad 1, pixel-major bf16 [B][H][W][C] (ld = C).  Sliding window: one thread owns 8 channels
-// and walks TP consecutive pixels of an image row keeping the 3x3 neighbourhood in registers, so each input pixel is
-// loaded 3 times (once per row it contributes to) instead of 9; weights stay in registers; GroupNorm statistics are
-// accumulated per thread and leave the workgroup once.
+// Depthwise 3x3, stride 1, pad 1, pixel-major bf16 [B][H][W][C] (ld = C).
+// A workgroup owns an 8 x TW pixel tile of a 64-channel window.  The (8+2) x (TW+2) halo of the window is loaded ONCE
+// into LDS with coalesced 16-byte loads, all in flight together (the register sliding-window kernel this replaces read
+// every input three times with ~190 VGPRs and one dependent load batch at a time: 1.5 TB/s); thread (column x, granule g)
+// then walks down the tile's rows keeping the 3x3 neighbourhood of its 8 channels in registers: three ds_read_b128 per
+// output, lanes g-fastest so a wave reads 1 KB contiguous.  Weights stay in registers; GroupNorm statistics are folded
+// with shuffles + LDS and leave the workgroup as one atomic per slab and moment.
+// TW = 32 (256 threads = 32 columns x 8 granules) or 16 (two row halves) for narrow images.
 // ------------------------------------------------------------------------------------------------
-constexpr int TP = 8;   // pixels per thread along x
+constexpr int TP = 8;     // pixels per thread along x (weight-gradient kernel)
+constexpr int DTH = 8;    // tile rows
+constexpr int DCW = 64;   // channel window (8 granules: 128-byte pixel rows in LDS)
 
-template <bool FLIP, bool STATS>
+template <bool FLIP, bool STATS, int TW>
 __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, int C, const float* w9, const float* bias,
-                                                bf16_t* y, float* stats) {
-  extern __shared__ float sm[];  // [C/16][2] when stats
-  const int b = blockIdx.y;
-  const int CG = C >> 3, G16 = C >> 4;
-  if (STATS) {
-    for (int i = threadIdx.x; i < 2 * G16; i += TPB) sm[i] = 0.f;
-    __syncthreads();
-  }
-  const int segs = (W + TP - 1) / TP;
-  const long long total = (long long)H * segs * CG;
+                                                bf16_t* y, float* stats, int tiles_x) {
+  constexpr int HWD = TW + 2;                       // halo width
+  constexpr int HPX = (DTH + 2) * HWD;              // halo pixels
+  constexpr int RSPLIT = 32 / TW;                   // row groups of the thread mapping (TW = 16: rows 0-3 / 4-7)
+  constexpr int ROWS = DTH / RSPLIT;                // rows a thread walks
+  __shared__ __attribute__((aligned(16))) uint4 sh[HPX * 8];
+  __shared__ float sred[4][16];
+  const int b = blockIdx.z;
+  const int c_win = blockIdx.y * DCW;
+  const int tyi = blockIdx.x / tiles_x, txi = blockIdx.x - tyi * tiles_x;
+  const int ty0 = tyi * DTH, tx0 = txi * TW;
   const bf16_t* xb = x + (long long)b * H * W * C;
   bf16_t* yb = y + (long long)b * H * W * C;
-  for (long long idx = (long long)blockIdx.x * TPB + threadIdx.x; idx < total; idx += (long long)gridDim.x * TPB) {
-    const int cg = (int)(idx % CG);
-    const int rest = (int)(idx / CG);
-    const int seg = rest % segs, py = rest / segs;
-    const int c0 = cg * 8, x0 = seg * TP;
-    float wv[9][8], bv[8];
+  const int t = threadIdx.x;
+  const int nG = (C - c_win) >= DCW ? 8 : (C - c_win) >> 3;     // granules of this window that exist
+  // ---- halo -> LDS: piece i = (halo pixel i >> 3, granule i & 7)
+  {
+    uint4 r[(HPX * 8 + TPB - 1) / TPB];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) load8t<1>(w9, (long long)(FLIP ? 8 - t : t) * C + c0, wv[t]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) bv[j] = bias ? bias[c0 + j] : 0.f;
-    float win[3][3][8];   // [row ky][column slot][channel]; column slot rotates with the pixel index
-    auto load_col = [&](int slot, int ix) {
-#pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const int iy = py + ky - 1;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) load8t<0>(xb, ((long long)iy * W + ix) * C + c0, win[ky][slot]);
-        else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) win[ky][slot][j] = 0.f;
-        }
-      }
-    };
-    load_col(0, x0 - 1);
-    load_col(1, x0);
-    float s = 0.f, ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < TP; ++i) {
-      load_col((i + 2) % 3, x0 + i + 1);
-      if (x0 + i < W) {
-        float acc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] = bv[j];
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-          for (int kx = 0; kx < 3; ++kx) {
-            const int slot = (i + kx) % 3;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += win[ky][slot][j] * wv[ky * 3 + kx][j];
-          }
-        uint4 u;
-        u.x = pack_bf2(acc[0], acc[1]); u.y = pack_bf2(acc[2], acc[3]); u.z = pack_bf2(acc[4], acc[5]); u.w = pack_bf2(acc[6], acc[7]);
-        *reinterpret_cast<uint4*>(yb + ((long long)py * W + x0 + i) * C + c0) = u;
-        if (STATS) {
-          s += bf_lo(u.x) + bf_hi(u.x) + bf_lo(u.y) + bf_hi(u.y) + bf_lo(u.z) + bf_hi(u.z) + bf_lo(u.w) + bf_hi(u.w);
-          ss += bf_lo(u.x) * bf_lo(u.x) + bf_hi(u.x) * bf_hi(u.x) + bf_lo(u.y) * bf_lo(u.y) + bf_hi(u.y) * bf_hi(u.y) +
-                bf_lo(u.z) * bf_lo(u.z) + bf_hi(u.z) * bf_hi(u.z) + bf_lo(u.w) * bf_lo(u.w) + bf_hi(u.w) * bf_hi(u.w);
-        }
-      }
+    for (int k = 0; k < (HPX * 8 + TPB - 1) / TPB; ++k) {
+      const int i = t + k * TPB;
+      const int hp = i >> 3, g = i & 7;
+      const int hy = hp / HWD, hx = hp - hy * HWD;
+      const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+      r[k] = make_uint4(0, 0, 0, 0);
+      if (i < HPX * 8 && g < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+        r[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + g * 8);
     }
-    if (STATS) {
-      atomicAdd(&sm[(cg >> 1) * 2], s);
-      atomicAdd(&sm[(cg >> 1) * 2 + 1], ss);
+#pragma unroll
+    for (int k = 0; k < (HPX * 8 + TPB - 1) / TPB; ++k) {
+      const int i = t + k * TPB;
+      if (i < HPX * 8) sh[i] = r[k];
+    }
+  }
+  const int g = t & 7, xc = (t >> 3) % TW, rg = (t >> 3) / TW;
+  const int c0 = c_win + g * 8;
+  const bool gok = g < nG;
+  float wv[9][8], bv[8];
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    if (gok) load8t<1>(w9, (long long)(FLIP ? 8 - tp : tp) * C + c0, wv[tp]);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) wv[tp][j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bv[j] = (bias && gok) ? bias[c0 + j] : 0.f;
+  __syncthreads();
+  auto lds8 = [&](int hy, int hx, float (&v)[8]) {
+    const uint4 u = sh[(hy * HWD + hx) * 8 + g];
+    v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
+    v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+  };
+  // win[row slot][kx][channel]: rows rotate while the thread walks down
+  float win[3][3][8];
+  const int r0 = rg * ROWS;                 // first output row (tile-local); halo row of output row r, tap ky: r + ky
+#pragma unroll
+  for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) lds8(r0 + ky, xc + kx, win[ky][kx]);
+  float s = 0.f, ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < ROWS; ++i) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) lds8(r0 + i + 2, xc + kx, win[(i + 2) % 3][kx]);
+    const int oy = ty0 + r0 + i, ox = tx0 + xc;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = bv[j];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += win[(i + ky) % 3][kx][j] * wv[ky * 3 + kx][j];
+      }
+    if (gok && oy < H && ox < W) {
+      uint4 u;
+      u.x = pack_bf2(acc[0], acc[1]); u.y = pack_bf2(acc[2], acc[3]); u.z = pack_bf2(acc[4], acc[5]); u.w = pack_bf2(acc[6], acc[7]);
+      *reinterpret_cast<uint4*>(yb + ((long long)oy * W + ox) * C + c0) = u;
+      if (STATS) {
+        s += bf_lo(u.x) + bf_hi(u.x) + bf_lo(u.y) + bf_hi(u.y) + bf_lo(u.z) + bf_hi(u.z) + bf_lo(u.w) + bf_hi(u.w);
+        ss += bf_lo(u.x) * bf_lo(u.x) + bf_hi(u.x) * bf_hi(u.x) + bf_lo(u.y) * bf_lo(u.y) + bf_hi(u.y) * bf_hi(u.y) +
+              bf_lo(u.z) * bf_lo(u.z) + bf_hi(u.z) * bf_hi(u.z) + bf_lo(u.w) * bf_lo(u.w) + bf_hi(u.w) * bf_hi(u.w);
+      }
     }
   }
   if (STATS) {
+    // lanes of a wave: granule = lane & 7 -> slab = (lane & 7) >> 1; fold the two granules of a slab and the 8 columns
+    s += __shfl_xor(s, 1); ss += __shfl_xor(ss, 1);
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    const int wave = t >> 6, l = t & 63;
+    if (l < 8 && (l & 1) == 0) { sred[wave][(l >> 1) * 2] = s; sred[wave][(l >> 1) * 2 + 1] = ss; }
     __syncthreads();
-    for (int i = threadIdx.x; i < 2 * G16; i += TPB)
-      if (sm[i] != 0.f) atomicAdd(&stats[(long long)b * G16 * 2 + i], sm[i]);
+    if (t < 8) {                              // (slab, moment) of this 64-channel window
+      const float v = sred[0][t] + sred[1][t] + sred[2][t] + sred[3][t];
+      const int slab = (c_win >> 4) + (t >> 1);
+      if (slab < (C >> 4)) atomicAdd(&stats[((long long)b * (C >> 4) + slab) * 2 + (t & 1)], v);
+    }
   }
 }
 
@@ -427,22 +463,22 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
                              int32_t flip, void* y, float* stats, crd_stream_t stream) {
   CRD_CHECK_ARG(x && w9 && y, "crd_dwconv3x3: null pointer");
   CRD_CHECK_ARG(C % 16 == 0, "crd_dwconv3x3: C must be a multiple of 16");
-  const long long total = (long long)H * cdiv(W, TP) * (C / 8);
-  long long nblk = cdiv(total, TPB);
-  const long long cap = 4096 / (B > 0 ? B : 1);
-  if (nblk > cap) nblk = cap > 0 ? cap : 1;
-  dim3 grid((unsigned)nblk, B);
-  const size_t lds = stats ? (C / 16) * 2 * sizeof(float) : 0;
   const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
   bf16_t* yp = reinterpret_cast<bf16_t*>(y);
   hipStream_t st = as_stream(stream);
-  if (flip) {
-    if (stats) hipLaunchKernelGGL((k_dwconv<true, true>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
-    else hipLaunchKernelGGL((k_dwconv<true, false>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
+  // tile width: 32, or 16 when that wastes fewer columns (W = 13: 16 instead of 32)
+  const int tw = (cdiv(W, 16) * 16 < cdiv(W, 32) * 32) ? 16 : 32;
+  const int tiles_x = cdiv(W, tw), tiles_y = cdiv(H, DTH);
+  dim3 grid(tiles_x * tiles_y, cdiv(C, DCW), B);
+#define CRD_DW(FL, STT, TWV) hipLaunchKernelGGL((k_dwconv<FL, STT, TWV>), grid, dim3(TPB), 0, st, xp, H, W, C, w9, bias, yp, stats, tiles_x)
+  if (tw == 32) {
+    if (flip) { if (stats) CRD_DW(true, true, 32); else CRD_DW(true, false, 32); }
+    else { if (stats) CRD_DW(false, true, 32); else CRD_DW(false, false, 32); }
   } else {
-    if (stats) hipLaunchKernelGGL((k_dwconv<false, true>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
-    else hipLaunchKernelGGL((k_dwconv<false, false>), grid, dim3(TPB), lds, st, xp, H, W, C, w9, bias, yp, stats);
+    if (flip) { if (stats) CRD_DW(true, true, 16); else CRD_DW(true, false, 16); }
+    else { if (stats) CRD_DW(false, true, 16); else CRD_DW(false, false, 16); }
   }
+#undef CRD_DW
   CRD_LAUNCH_CHECK("crd_dwconv3x3");
   return CRD_OK;
 }

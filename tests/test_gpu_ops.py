@@ -189,7 +189,7 @@ def test_groupnorm_forward_backward(C_, gmul, xf32, act):
     assert_close(dxf.cpu() - base, xr.grad.permute(0, 2, 1), "gn dx f32 acc", rel=1e-3, elem=2e-3)
 
 
-@pytest.mark.parametrize("C_,H,W", [(64, 9, 13), (512, 8, 12), (160, 5, 7)])
+@pytest.mark.parametrize("C_,H,W", [(64, 9, 13), (512, 8, 12), (160, 5, 7), (64, 11, 45), (80, 9, 33), (256, 17, 64)])
 def test_dwconv(C_, H, W):
     lib, lb = L()
     g = torch.Generator().manual_seed(2)

@@ -57,3 +57,21 @@ for (tag, a), (_, b2) in zip(marks, marks[1:]):
     bw = sum(ms for ph, i, op, ms in rec if ph == "bwd" and seg and seg[0][1] <= i < seg[0][2])
     nl = sum(1 for ph, i, op, ms in rec if (ph == "fwd" and a2 <= i < b3) or (ph == "bwd" and seg and seg[0][1] <= i < seg[0][2]))
     print(f"{tag:10s} {f:8.2f} {bw:8.2f}   {nl}")
+
+# average time of every op type per encoder stage (eager event timing: ~5 us of launch path included)
+print("op avg us by stage (fwd / bwd):")
+tab = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for (tag, a0), (_, b0) in zip(marks, marks[1:]):
+    a2, b3 = (a0 + shift if a0 > 0 else a0), b0 + shift
+    for ph, i, op, ms in rec:
+        if ph == "fwd" and a2 <= i < b3:
+            e = tab[("F " + op.name)][tag]; e[0] += 1; e[1] += ms
+for tag, a0, b0 in plan.bwd_segments:
+    for ph, i, op, ms in rec:
+        if ph == "bwd" and a0 <= i < b0:
+            e = tab[("B " + op.name)][tag]; e[0] += 1; e[1] += ms
+tags = ["enc0", "enc1", "enc2", "enc3", "dec"]
+print(f"{'':34s}" + "".join(f"{t:>16s}" for t in tags))
+for k in sorted(tab, key=lambda k: -sum(v[1] for v in tab[k].values())):
+    row = "".join((f"{tab[k][t][1] / tab[k][t][0] * 1e3:9.1f} x{tab[k][t][0]:<5d}" if tab[k][t][0] else f"{'':16s}") for t in tags)
+    print(f"{k:34s}{row}")

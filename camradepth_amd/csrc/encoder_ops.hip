@@ -16,7 +16,6 @@ constexpr int TPB = 256;
 // with shuffles + LDS and leave the workgroup as one atomic per slab and moment.
 // TW = 32 (256 threads = 32 columns x 8 granules) or 16 (two row halves) for narrow images.
 // ------------------------------------------------------------------------------------------------
-constexpr int TP = 8;     // pixels per thread along x (weight-gradient kernel)
 constexpr int DTH = 8;    // tile rows
 constexpr int DCW = 64;   // channel window (8 granules: 128-byte pixel rows in LDS)
 
@@ -126,101 +125,129 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
   }
 }
 
-// dw10[tap][c] += sum_{b,p} dy[p][c]*x[p+tap][c] for tap < 9; dw10[9][c] += sum dy (the bias gradient).  Same sliding
-// window; a thread keeps its 8 channels (blockIdx.y selects a 64-granule channel window; the window's granules are
-// spread over CGW lanes and the remaining lanes of the workgroup take further row segments) so the 80 partial sums stay
-// in registers across all the row segments it visits.  The workgroup folds them with shuffles (row lanes inside a wave)
-// and four LDS rounds (waves) -- LDS float atomics serialise on four banks -- and then adds into ONE of `replicas`
-// copies of the accumulator: an fp32 global atomic costs ~2.6 ns per 128-byte line, so 384 workgroups x 5120 adjacent
-// sums on one copy kept the kernel at 70 us for 27 MB of input.  The caller sums the copies (crd_wgrad_unpack).
-__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int B, int H, int W, int C,
-                                                      float* dw10, int replicas) {
-  __shared__ float sm[10 * 512];
-  const int CG = C >> 3;
-  const int rem = CG - blockIdx.y * 64;                // granules in this window
-  int CGW = 64;
-  while (CGW > 8 && (CGW >> 1) >= rem) CGW >>= 1;      // lanes per row segment: 8..64, power of two
-  const int RL = TPB / CGW;                            // row lanes per workgroup
-  const int cgl = threadIdx.x & (CGW - 1), lane = threadIdx.x / CGW;
-  const int cg = blockIdx.y * 64 + cgl;
-  const bool cok = cg < CG;
-  const int c0 = cg * 8;
-  const int segs = (W + TP - 1) / TP;
-  const long long items = (long long)B * H * segs;
+// dw10[tap][c] += sum_{b,p} dy[p][c]*x[p+tap][c] for tap < 9; dw10[9][c] += sum dy (the bias gradient).
+// Same tiling as k_dwconv: per 8 x TW tile the x halo and the dy tile of a 64-channel window go to LDS with coalesced
+// loads, thread (column, granule) walks down the rows with the 3x3 x-neighbourhood in registers and accumulates its 80
+// sums; a workgroup runs over `tiles_per_wg` vertically adjacent tiles before it folds them (shuffles over the columns of
+// a wave, LDS over the waves) and adds them into ONE of `replicas` copies of the accumulator: an fp32 global atomic
+// costs ~2.6 ns per 128-byte line, serialised device-wide, so all workgroups on one copy would be the whole kernel time.
+// The caller sums the copies (crd_wgrad_unpack).
+template <int TW>
+__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, float* dw10,
+                                                      int replicas, int tiles_x, int tiles_y, int tiles_per_wg) {
+  constexpr int HWD = TW + 2;
+  constexpr int HPX = (DTH + 2) * HWD;
+  constexpr int RSPLIT = 32 / TW;
+  constexpr int ROWS = DTH / RSPLIT;
+  extern __shared__ __attribute__((aligned(16))) uint4 dsm[];   // x halo [HPX][8] | dy tile [8*TW][8]
+  uint4* sx = dsm;
+  uint4* sdy = dsm + HPX * 8;
+  const int b = blockIdx.z;
+  const int c_win = blockIdx.y * DCW;
+  const int txi = blockIdx.x % tiles_x, ygrp = blockIdx.x / tiles_x;
+  const int tx0 = txi * TW;
+  const bf16_t* xb = x + (long long)b * H * W * C;
+  const bf16_t* db = dy + (long long)b * H * W * C;
+  const int t = threadIdx.x;
+  const int nG = (C - c_win) >= DCW ? 8 : (C - c_win) >> 3;
+  const int g = t & 7, xc = (t >> 3) % TW, rg = (t >> 3) / TW;
   float acc[10][8];
 #pragma unroll
-  for (int t = 0; t < 10; ++t)
+  for (int tp = 0; tp < 10; ++tp)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[t][j] = 0.f;
-  if (cok) {
-    for (long long it = (long long)blockIdx.x * RL + lane; it < items; it += (long long)gridDim.x * RL) {
-      const int seg = (int)(it % segs);
-      const long long r2 = it / segs;
-      const int py = (int)(r2 % H), b = (int)(r2 / H);
-      const int x0 = seg * TP;
-      const bf16_t* xb = x + (long long)b * H * W * C;
-      const bf16_t* db = dy + (long long)b * H * W * C;
-      float win[3][3][8];
-      auto load_col = [&](int slot, int ix) {
+    for (int j = 0; j < 8; ++j) acc[tp][j] = 0.f;
+  auto unpack8 = [&](const uint4& u, float (&v)[8]) {
+    v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
+    v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+  };
+  for (int it = 0; it < tiles_per_wg; ++it) {
+    const int tyi = ygrp * tiles_per_wg + it;
+    if (tyi >= tiles_y) break;                     // uniform
+    const int ty0 = tyi * DTH;
+    {
+      constexpr int NX = (HPX * 8 + TPB - 1) / TPB, ND = (DTH * TW * 8) / TPB;
+      uint4 rx[NX], rd[ND];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-          const int iy = py + ky - 1;
-          if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) load8t<0>(xb, ((long long)iy * W + ix) * C + c0, win[ky][slot]);
-          else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) win[ky][slot][j] = 0.f;
-          }
-        }
-      };
-      load_col(0, x0 - 1);
-      load_col(1, x0);
-#pragma unroll
-      for (int i = 0; i < TP; ++i) {
-        load_col((i + 2) % 3, x0 + i + 1);
-        if (x0 + i < W) {
-          float d[8];
-          load8t<0>(db, ((long long)py * W + x0 + i) * C + c0, d);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[9][j] += d[j];
-#pragma unroll
-          for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-              const int slot = (i + kx) % 3;
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += d[j] * win[ky][slot][j];
-            }
-        }
+      for (int k = 0; k < NX; ++k) {
+        const int i = t + k * TPB;
+        const int hp = i >> 3, gg = i & 7;
+        const int hy = hp / HWD, hx = hp - hy * HWD;
+        const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
+        rx[k] = make_uint4(0, 0, 0, 0);
+        if (i < HPX * 8 && gg < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
+          rx[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + gg * 8);
       }
+#pragma unroll
+      for (int k = 0; k < ND; ++k) {
+        const int i = t + k * TPB;
+        const int pp = i >> 3, gg = i & 7;
+        const int py = pp / TW, px = pp - py * TW;
+        const int iy = ty0 + py, ix = tx0 + px;
+        rd[k] = make_uint4(0, 0, 0, 0);
+        if (gg < nG && iy < H && ix < W) rd[k] = *reinterpret_cast<const uint4*>(db + ((long long)iy * W + ix) * C + c_win + gg * 8);
+      }
+      if (it > 0) __syncthreads();                 // everyone is done with the previous tile's LDS image
+#pragma unroll
+      for (int k = 0; k < NX; ++k) {
+        const int i = t + k * TPB;
+        if (i < HPX * 8) sx[i] = rx[k];
+      }
+#pragma unroll
+      for (int k = 0; k < ND; ++k) sdy[t + k * TPB] = rd[k];
+    }
+    __syncthreads();
+    float win[3][3][8];
+    const int r0 = rg * ROWS;
+#pragma unroll
+    for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) unpack8(sx[((r0 + ky) * HWD + xc + kx) * 8 + g], win[ky][kx]);
+#pragma unroll
+    for (int i = 0; i < ROWS; ++i) {
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) unpack8(sx[((r0 + i + 2) * HWD + xc + kx) * 8 + g], win[(i + 2) % 3][kx]);
+      float d[8];
+      unpack8(sdy[((r0 + i) * TW + xc) * 8 + g], d);      // zero outside the image / window
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[9][j] += d[j];
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[ky * 3 + kx][j] += d[j] * win[(i + ky) % 3][kx][j];
+        }
     }
   }
-  // row lanes inside the wave
-  for (int o = CGW; o < 64; o <<= 1) {
+  // columns of the wave (lane bits 3..5), then the waves one after the other through LDS
 #pragma unroll
-    for (int t = 0; t < 10; ++t)
+  for (int o = 8; o < 64; o <<= 1) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[t][j] += __shfl_xor(acc[t][j], o);
+    for (int tp = 0; tp < 10; ++tp)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[tp][j] += __shfl_xor(acc[tp][j], o);
   }
-  // waves, one after the other
-  const int wave = threadIdx.x >> 6;
+  __syncthreads();
+  float* sm = reinterpret_cast<float*>(dsm);      // [10][64]
+  const int wave = t >> 6, l = t & 63;
   for (int w = 0; w < 4; ++w) {
-    if (wave == w && (threadIdx.x & 63) < CGW && cok) {
+    if (wave == w && l < 8) {
 #pragma unroll
-      for (int t = 0; t < 10; ++t)
+      for (int tp = 0; tp < 10; ++tp)
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          float* p = &sm[t * 512 + cgl * 8 + j];
-          *p = w == 0 ? acc[t][j] : *p + acc[t][j];
+          float* p = &sm[tp * 64 + l * 8 + j];
+          *p = w == 0 ? acc[tp][j] : *p + acc[tp][j];
         }
     }
     __syncthreads();
   }
-  float* dst = dw10 + (long long)(blockIdx.x % replicas) * 10 * C;
-  const int nch = (rem < 64 ? rem : 64) * 8;          // channels of this window
-  for (int i = threadIdx.x; i < 10 * nch; i += TPB) {
-    const int t = i / nch, cl = i - t * nch;
-    const float v = sm[t * 512 + cl];
-    if (v != 0.f) atomicAdd(&dst[(long long)t * C + blockIdx.y * 512 + cl], v);
+  float* dst = dw10 + (long long)((blockIdx.z * gridDim.x + blockIdx.x) % replicas) * 10 * C;
+  const int nch = nG * 8;
+  for (int i = t; i < 10 * nch; i += TPB) {
+    const int tp = i / nch, cl = i - tp * nch;
+    const float v = sm[tp * 64 + cl];
+    if (v != 0.f) atomicAdd(&dst[(long long)tp * C + c_win + cl], v);
   }
 }
 
@@ -487,14 +514,29 @@ extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int
                                    int32_t replicas, crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && dw10 && replicas >= 1, "crd_dwconv3x3_wgrad: null pointer / replicas < 1");
   CRD_CHECK_ARG(C % 16 == 0 && C <= 4096, "crd_dwconv3x3_wgrad: C must be a multiple of 16, <= 4096");
-  const int cwin = cdiv(C / 8, 64);                         // 512-channel windows
-  const long long items = (long long)B * H * cdiv(W, TP);
-  long long nblk = cdiv(items, 4 * 2);                     // >= 2 row segments per row lane of a full window
-  const long long cap = 512 / cwin > 0 ? 512 / cwin : 1;
-  if (nblk > cap) nblk = cap;
-  if (nblk < 1) nblk = 1;
-  hipLaunchKernelGGL(k_dwconv_wgrad, dim3((unsigned)nblk, cwin), dim3(TPB), 0, as_stream(stream),
-                     reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy), B, H, W, C, dw10, replicas);
+  const int tw = (cdiv(W, 16) * 16 < cdiv(W, 32) * 32) ? 16 : 32;
+  const int tiles_x = cdiv(W, tw), tiles_y = cdiv(H, DTH), wins = cdiv(C, DCW);
+  // vertical runs of tiles per workgroup: as long as possible (one fold + one set of atomics per run) while ~512
+  // workgroups (two per CU: 76 KB of LDS each) remain
+  int ysplit = cdiv(512, (long long)tiles_x * wins * B);
+  if (ysplit > tiles_y) ysplit = tiles_y;
+  if (ysplit < 1) ysplit = 1;
+  const int per = cdiv(tiles_y, ysplit);
+  ysplit = cdiv(tiles_y, per);
+  dim3 grid(tiles_x * ysplit, wins, B);
+  const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
+  const bf16_t* dp = reinterpret_cast<const bf16_t*>(dy);
+  hipStream_t st = as_stream(stream);
+  static bool attr_done[2] = {false, false};
+  if (tw == 32) {
+    const size_t lds = (size_t)((DTH + 2) * 34 * 8 + DTH * 32 * 8) * sizeof(uint4);
+    if (!attr_done[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_wgrad<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+    hipLaunchKernelGGL(k_dwconv_wgrad<32>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per);
+  } else {
+    const size_t lds = (size_t)((DTH + 2) * 18 * 8 + DTH * 16 * 8) * sizeof(uint4);
+    if (!attr_done[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_wgrad<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+    hipLaunchKernelGGL(k_dwconv_wgrad<16>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per);
+  }
   CRD_LAUNCH_CHECK("crd_dwconv3x3_wgrad");
   return CRD_OK;
 }

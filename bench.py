@@ -89,6 +89,36 @@ def pmc_traffic(kernel):
     return round(tot / n) if n else None
 
 
+def forward_only(model, batch, B, H, W, variant, reps=20):
+    """Eval-mode forward (forward-only roofline fraction), replayed from one HIP graph."""
+    model.eval()
+    x = batch["image"].cuda()
+    plan = model._plan_for(x)
+    plan.x_in.copy_(x)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        plan.forward()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            plan.forward()
+        for _ in range(3):
+            g.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+    model.train()
+    ms = e0.elapsed_time(e1) / reps
+    ips = B / (ms * 1e-3)
+    scale = (H * W) / (256 * 416)
+    return {"images_per_s": round(ips, 1), "ms": round(ms, 3),
+            "mfma_frac": round(ips * FWD_GFLOP[variant] * scale / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)}
+
+
 def cpu_baseline(variant, seconds_budget=25.0):
     """The CPU oracle (oracle/, a port of the reference verified against it) timed on this box's host cores."""
     import numpy as np  # noqa: F401
@@ -210,6 +240,8 @@ def main():
                            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3)}
         out["kernels"] = {k: {"launches": v[0], "ms_per_step": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    if rank == 0 and world == 1 and not a.no_roofline:
+        out["forward_only"] = forward_only(model, batch, a.batch, a.height, a.width, a.variant)
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

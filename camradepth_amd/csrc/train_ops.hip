@@ -36,6 +36,34 @@ __global__ __launch_bounds__(TPB) void k_masked_l1_fwd(const float* pred, const 
   block_atomic3(s, cnt, sq, acc);
 }
 
+// Trainer.test metrics (runner.py:443-465), per frame f: pred clipped to [0,1] and both scaled by max_depth, ground truth
+// beyond max_distance dropped; acc[f] = (sum |e|, sum e^2, sum |e|/gt, count)
+__global__ __launch_bounds__(TPB) void k_test_metrics(const float* pred, const float* gt, long long n, float max_depth,
+                                                      float max_distance, float* acc) {
+  const int f = blockIdx.y;
+  const float* p = pred + (long long)f * n;
+  const float* g = gt + (long long)f * n;
+  float sa = 0.f, sq = 0.f, sr = 0.f, cnt = 0.f;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
+    float t = g[i] * max_depth;
+    if (t > max_distance) t = 0.f;
+    if (t > 0.f) {
+      const float e = fminf(fmaxf(p[i], 0.f), 1.f) * max_depth - t;
+      sa += fabsf(e); sq += e * e; sr += fabsf(e) / t; cnt += 1.f;
+    }
+  }
+  sa = wave_sum(sa); sq = wave_sum(sq); sr = wave_sum(sr); cnt = wave_sum(cnt);
+  __shared__ float sm[TPB / 64][4];
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sm[wave][0] = sa; sm[wave][1] = sq; sm[wave][2] = sr; sm[wave][3] = cnt; }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float v = 0.f;
+    for (int w = 0; w < TPB / 64; ++w) v += sm[w][threadIdx.x];
+    atomicAdd(&acc[f * 4 + threadIdx.x], v);
+  }
+}
+
 __global__ __launch_bounds__(TPB) void k_masked_l1_bwd(const float* pred, const float* target, long long n, const float* acc,
                                                        const float* gout, float gmul, float* dpred) {
   const float g = gmul * (gout ? gout[0] : 1.f) / acc[1];
@@ -240,6 +268,15 @@ extern "C" int crd_masked_l1_fwd(const float* pred, const float* target, int64_t
   CRD_CHECK_ARG(pred && target && acc && n > 0, "crd_masked_l1_fwd: bad argument");
   hipLaunchKernelGGL(k_masked_l1_fwd, dim3(blocks_for(n, 512)), dim3(TPB), 0, as_stream(stream), pred, target, (long long)n, acc);
   CRD_LAUNCH_CHECK("crd_masked_l1_fwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_test_metrics(const float* pred, const float* gt, int32_t frames, int64_t n, float max_depth, float max_distance,
+                                float* acc, crd_stream_t stream) {
+  CRD_CHECK_ARG(pred && gt && acc && frames > 0 && n > 0, "crd_test_metrics: bad argument");
+  hipLaunchKernelGGL(k_test_metrics, dim3(blocks_for(n, 64), frames), dim3(TPB), 0, as_stream(stream), pred, gt, (long long)n,
+                     max_depth, max_distance, acc);
+  CRD_LAUNCH_CHECK("crd_test_metrics");
   return CRD_OK;
 }
 

@@ -261,6 +261,12 @@ int crd_dropout_masks(float* out, const float* keep, int32_t rows, int32_t cols,
  * ------------------------------------------------------------------------------------------- */
 /* acc[0] += sum smooth_l1(pred-target), acc[1] += #(target>0), acc[2] += sum (target-pred)^2 ; caller zeroes acc */
 int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, float* acc, crd_stream_t stream);
+/* Trainer.test metrics (runner.py:443-465) for `frames` fp32 maps of n pixels each, without a host sync per frame:
+ * p = clip(pred,0,1)*max_depth, g = gt*max_depth with g > max_distance dropped; on g > 0:
+ * acc[f][0] += sum |p-g|, acc[f][1] += sum (p-g)^2, acc[f][2] += sum |p-g|/g, acc[f][3] += count   (caller zeroes acc;
+ * MAE = acc0/acc3, RMSE = sqrt(acc1/acc3), REL = acc2/acc3; frames with acc3 == 0 are skipped by the reference) */
+int crd_test_metrics(const float* pred, const float* gt, int32_t frames, int64_t n, float max_depth, float max_distance,
+                     float* acc, crd_stream_t stream);
 /* dpred = gmul * gout[0] * clamp(pred-target,-1,1) / acc[1] on target>0, else 0   (gout may be NULL = 1) */
 int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const float* acc, const float* gout,
                       float gmul, float* dpred, crd_stream_t stream);

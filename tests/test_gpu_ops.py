@@ -476,3 +476,29 @@ def test_weight_pack_and_unpack():
     tab2 = torch.frombuffer(bytearray(bytes(u)), dtype=torch.uint8).cuda()
     ok(lb.crd_wgrad_unpack(P(tab2), 1, Co * 9 * Cp, 1, lib.stream()), "wgrad_unpack")
     assert_close(dd.cpu(), 1 + src[:, :, :Ci].permute(0, 2, 1), "unpack", rel=1e-6, elem=1e-6)
+
+
+def test_depth_metrics_match_reference_golden():
+    """crd_test_metrics (device-side Trainer.test metrics) against the reference's golden values and the CPU oracle."""
+    from camradepth_amd import synth
+    from camradepth_amd.metrics import DepthMetrics
+    from oracle import losses as ol
+    from tests.util import load_npz
+    g = load_npz("losses_metrics.npz")
+    b = synth.make_batch(2, 24, 40, seed=3)
+    pred = torch.from_numpy(g["pred"])
+    dm = DepthMetrics()
+    dm.update(pred.cuda(), b["gt_full"].cuda())
+    pf = dm.per_frame()
+    np.testing.assert_allclose([pf[0]["MAE"], pf[0]["RMSE"], pf[0]["REL"]], g["metrics"], rtol=2e-5)
+    for f in range(2):
+        m = ol.test_metrics(pred[f], b["gt_full"][f])
+        np.testing.assert_allclose([pf[f]["MAE"], pf[f]["RMSE"], pf[f]["REL"]], [m["MAE"], m["RMSE"], m["REL"]], rtol=2e-5)
+    # range-limited variant (<= 50 m) and a frame without valid ground truth
+    dm50 = DepthMetrics(max_distance=50.0)
+    gt0 = b["gt_full"].clone(); gt0[1] = 0
+    dm50.update(pred.cuda(), gt0.cuda())
+    m = ol.test_metrics(pred[0], gt0[0], max_distance=50.0)
+    pf = dm50.per_frame()
+    np.testing.assert_allclose([pf[0]["MAE"], pf[0]["RMSE"], pf[0]["REL"]], [m["MAE"], m["RMSE"], m["REL"]], rtol=2e-5)
+    assert pf[1] is None and dm50.result() is not None

@@ -599,7 +599,14 @@ extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS
   CRD_CHECK_ARG(d % 8 == 0, "crd_attn_scores_bwd: head dim must be a multiple of 8");
   const int C = heads * d;
   const size_t lds = (size_t)M * C * sizeof(float);
-  const int use_lds = lds <= 64 * 1024;
+  // dK accumulates in LDS whenever [M][C] fp32 fits (stage 3: 66.5 KB, stage 4: 106 KB); the fallback adds every
+  // contribution to global memory with an atomic of its own and was 50 us per launch on stage 3
+  const int use_lds = lds <= 128 * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_scores_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    attr_done = true;
+  }
   // pixels per workgroup: with the LDS accumulator every workgroup ends with M*C global atomics, so not too few
   int nblk = cdiv(N, use_lds ? 128 : 64);
   int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;

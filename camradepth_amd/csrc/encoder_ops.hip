@@ -19,9 +19,38 @@ constexpr int TPB = 256;
 constexpr int DTH = 8;    // tile rows
 constexpr int DCW = 64;   // channel window (8 granules: 128-byte pixel rows in LDS)
 
+// Optional GroupNorm of the INPUT applied while the halo is staged (Mlp.norm1 between fc1 and the depthwise conv,
+// simplified_attention.py:37-38): xn = bf16((x - mean) * rstd * gamma + beta), exactly what crd_gn_apply would have
+// written, so the normalised hidden tensor is never materialised.  A thread stages the same granule for every piece.
+struct InNorm {
+  const float* stats;   // g16 sums of x [B][C/16][2], or nullptr: no normalisation
+  const float* gamma; const float* beta; int gmul;
+};
+__device__ __forceinline__ void innorm_coeffs(const InNorm& n, int b, int C, long long P, int c0, bool ok, float (&a)[8], float (&s)[8]) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = 1.f; s[j] = 0.f; }
+  if (n.stats == nullptr || !ok) return;
+  float mean, rstd;
+  const int grp = (c0 >> 4) / n.gmul;
+  gn_mean_rstd(n.stats + (long long)b * (C >> 4) * 2, grp * n.gmul, n.gmul, 1.f / ((float)P * 16.f * n.gmul), mean, rstd);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = n.gamma[c0 + j] * rstd;
+    s[j] = n.beta[c0 + j] - mean * a[j];
+  }
+}
+__device__ __forceinline__ uint4 innorm_apply(const uint4& u, const float (&a)[8], const float (&s)[8]) {
+  uint4 r;
+  r.x = pack_bf2(bf_lo(u.x) * a[0] + s[0], bf_hi(u.x) * a[1] + s[1]);
+  r.y = pack_bf2(bf_lo(u.y) * a[2] + s[2], bf_hi(u.y) * a[3] + s[3]);
+  r.z = pack_bf2(bf_lo(u.z) * a[4] + s[4], bf_hi(u.z) * a[5] + s[5]);
+  r.w = pack_bf2(bf_lo(u.w) * a[6] + s[6], bf_hi(u.w) * a[7] + s[7]);
+  return r;
+}
+
 template <bool FLIP, bool STATS, int TW>
 __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, int C, const float* w9, const float* bias,
-                                                bf16_t* y, float* stats, int tiles_x) {
+                                                bf16_t* y, float* stats, int tiles_x, InNorm inn) {
   constexpr int HWD = TW + 2;                       // halo width
   constexpr int HPX = (DTH + 2) * HWD;              // halo pixels
   constexpr int RSPLIT = 32 / TW;                   // row groups of the thread mapping (TW = 16: rows 0-3 / 4-7)
@@ -39,6 +68,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
   // ---- halo -> LDS: piece i = (halo pixel i >> 3, granule i & 7)
   {
     uint4 r[(HPX * 8 + TPB - 1) / TPB];
+    bool inimg[(HPX * 8 + TPB - 1) / TPB];
 #pragma unroll
     for (int k = 0; k < (HPX * 8 + TPB - 1) / TPB; ++k) {
       const int i = t + k * TPB;
@@ -46,13 +76,15 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
       const int hy = hp / HWD, hx = hp - hy * HWD;
       const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
       r[k] = make_uint4(0, 0, 0, 0);
-      if (i < HPX * 8 && g < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-        r[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + g * 8);
+      inimg[k] = i < HPX * 8 && g < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      if (inimg[k]) r[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + g * 8);
     }
+    float na[8], ns[8];
+    innorm_coeffs(inn, b, C, (long long)H * W, c_win + (t & 7) * 8, (t & 7) < nG, na, ns);
 #pragma unroll
     for (int k = 0; k < (HPX * 8 + TPB - 1) / TPB; ++k) {
       const int i = t + k * TPB;
-      if (i < HPX * 8) sh[i] = r[k];
+      if (i < HPX * 8) sh[i] = (inn.stats && inimg[k]) ? innorm_apply(r[k], na, ns) : r[k];   // the zero padding stays zero
     }
   }
   const int g = t & 7, xc = (t >> 3) % TW, rg = (t >> 3) / TW;
@@ -134,7 +166,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
 // The caller sums the copies (crd_wgrad_unpack).
 template <int TW>
 __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, float* dw10,
-                                                      int replicas, int tiles_x, int tiles_y, int tiles_per_wg) {
+                                                      int replicas, int tiles_x, int tiles_y, int tiles_per_wg, InNorm inn) {
   constexpr int HWD = TW + 2;
   constexpr int HPX = (DTH + 2) * HWD;
   constexpr int RSPLIT = 32 / TW;
@@ -160,6 +192,8 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
     v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
     v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
   };
+  float na[8], ns[8];
+  innorm_coeffs(inn, b, C, (long long)H * W, c_win + (t & 7) * 8, (t & 7) < nG, na, ns);
   for (int it = 0; it < tiles_per_wg; ++it) {
     const int tyi = ygrp * tiles_per_wg + it;
     if (tyi >= tiles_y) break;                     // uniform
@@ -167,6 +201,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
     {
       constexpr int NX = (HPX * 8 + TPB - 1) / TPB, ND = (DTH * TW * 8) / TPB;
       uint4 rx[NX], rd[ND];
+      bool inimg[NX];
 #pragma unroll
       for (int k = 0; k < NX; ++k) {
         const int i = t + k * TPB;
@@ -174,8 +209,8 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
         const int hy = hp / HWD, hx = hp - hy * HWD;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
         rx[k] = make_uint4(0, 0, 0, 0);
-        if (i < HPX * 8 && gg < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W)
-          rx[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + gg * 8);
+        inimg[k] = i < HPX * 8 && gg < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+        if (inimg[k]) rx[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + gg * 8);
       }
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
@@ -190,7 +225,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
 #pragma unroll
       for (int k = 0; k < NX; ++k) {
         const int i = t + k * TPB;
-        if (i < HPX * 8) sx[i] = rx[k];
+        if (i < HPX * 8) sx[i] = (inn.stats && inimg[k]) ? innorm_apply(rx[k], na, ns) : rx[k];
       }
 #pragma unroll
       for (int k = 0; k < ND; ++k) sdy[t + k * TPB] = rd[k];
@@ -487,8 +522,11 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
 }  // namespace
 
 extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
-                             int32_t flip, void* y, float* stats, crd_stream_t stream) {
+                             int32_t flip, void* y, float* stats, const float* in_stats, int32_t in_gmul,
+                             const float* in_gamma, const float* in_beta, crd_stream_t stream) {
   CRD_CHECK_ARG(x && w9 && y, "crd_dwconv3x3: null pointer");
+  CRD_CHECK_ARG(!in_stats || (in_gamma && in_beta && in_gmul >= 1 && (C / 16) % in_gmul == 0), "crd_dwconv3x3: bad input-norm arguments");
+  const InNorm inn{in_stats, in_gamma, in_beta, in_gmul};
   CRD_CHECK_ARG(C % 16 == 0, "crd_dwconv3x3: C must be a multiple of 16");
   const bf16_t* xp = reinterpret_cast<const bf16_t*>(x);
   bf16_t* yp = reinterpret_cast<bf16_t*>(y);
@@ -497,7 +535,7 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
   const int tw = (cdiv(W, 16) * 16 < cdiv(W, 32) * 32) ? 16 : 32;
   const int tiles_x = cdiv(W, tw), tiles_y = cdiv(H, DTH);
   dim3 grid(tiles_x * tiles_y, cdiv(C, DCW), B);
-#define CRD_DW(FL, STT, TWV) hipLaunchKernelGGL((k_dwconv<FL, STT, TWV>), grid, dim3(TPB), 0, st, xp, H, W, C, w9, bias, yp, stats, tiles_x)
+#define CRD_DW(FL, STT, TWV) hipLaunchKernelGGL((k_dwconv<FL, STT, TWV>), grid, dim3(TPB), 0, st, xp, H, W, C, w9, bias, yp, stats, tiles_x, inn)
   if (tw == 32) {
     if (flip) { if (stats) CRD_DW(true, true, 32); else CRD_DW(true, false, 32); }
     else { if (stats) CRD_DW(false, true, 32); else CRD_DW(false, false, 32); }
@@ -511,8 +549,11 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
 }
 
 extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw10,
-                                   int32_t replicas, crd_stream_t stream) {
+                                   int32_t replicas, const float* in_stats, int32_t in_gmul, const float* in_gamma,
+                                   const float* in_beta, crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && dw10 && replicas >= 1, "crd_dwconv3x3_wgrad: null pointer / replicas < 1");
+  CRD_CHECK_ARG(!in_stats || (in_gamma && in_beta && in_gmul >= 1 && (C / 16) % in_gmul == 0), "crd_dwconv3x3_wgrad: bad input-norm arguments");
+  const InNorm inn{in_stats, in_gamma, in_beta, in_gmul};
   CRD_CHECK_ARG(C % 16 == 0 && C <= 4096, "crd_dwconv3x3_wgrad: C must be a multiple of 16, <= 4096");
   const int tw = (cdiv(W, 16) * 16 < cdiv(W, 32) * 32) ? 16 : 32;
   const int tiles_x = cdiv(W, tw), tiles_y = cdiv(H, DTH), wins = cdiv(C, DCW);
@@ -531,11 +572,11 @@ extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int
   if (tw == 32) {
     const size_t lds = (size_t)((DTH + 2) * 34 * 8 + DTH * 32 * 8) * sizeof(uint4);
     if (!attr_done[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_wgrad<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
-    hipLaunchKernelGGL(k_dwconv_wgrad<32>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per);
+    hipLaunchKernelGGL(k_dwconv_wgrad<32>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per, inn);
   } else {
     const size_t lds = (size_t)((DTH + 2) * 18 * 8 + DTH * 16 * 8) * sizeof(uint4);
     if (!attr_done[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_wgrad<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
-    hipLaunchKernelGGL(k_dwconv_wgrad<16>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per);
+    hipLaunchKernelGGL(k_dwconv_wgrad<16>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per, inn);
   }
   CRD_LAUNCH_CHECK("crd_dwconv3x3_wgrad");
   return CRD_OK;

@@ -636,13 +636,14 @@ class Plan:
         XN2 = self.act(Cs, Hs, Ws)
         self.gn_stats_apply(X1, st2, None, 1, name + ".norm2", 0, None, XN2)
         c1, c2 = self.new_conv(ml + ".fc1"), self.new_conv(ml + ".fc2")
-        H1, H1N, H2, H3 = (self.act(hid, Hs, Ws) for _ in range(4))
+        H1, H2, H3 = (self.act(hid, Hs, Ws) for _ in range(3))
         sth1, sth2 = self.zf(B, hid // 16, 2), self.zf(B, hid // 16, 2)
         self.conv(F_, self.conv_desc(XN2, c1, hid, 1, 1, 0, Hs, Ws, H1, bias=c1.bias, stats=sth1))
-        self.gn_fwd(H1, sth1, 1, ml + ".norm1", 0, None, H1N)
+        # Mlp.norm1 is applied by the depthwise kernels while they stage H1 (the normalised tensor is never stored)
+        n1 = [sth1, 1, self.p(ml + ".norm1.weight"), self.p(ml + ".norm1.bias")]
         w9 = self.new((9, hid), F32)
         self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9))
-        self._emit(F_, "crd_dwconv3x3", [H1N.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2])
+        self._emit(F_, "crd_dwconv3x3", [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1)
         self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
         X2 = self.act(Cs, Hs, Ws, F32)
         self.conv(F_, self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp))
@@ -659,8 +660,8 @@ class Plan:
         self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID)                 # in place: d(H2)
         dw10 = self.zb(DW_REPLICAS, 10, hid)      # [copy][9 taps + bias][channel]; the unpack kernel sums the copies
         self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
-        self._emit(g, "crd_dwconv3x3_wgrad", [H1N.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS])
-        self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None])  # d(H1N)
+        self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
+        self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None])  # d(H1N)
         self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2)                    # in place: d(H1)
         self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc1.bias"))
         self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1))

@@ -146,12 +146,17 @@ int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff,
  * Optional g16 stats of the rounded output.
  * ------------------------------------------------------------------------------------------- */
 int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
-                  int32_t flip, void* y, float* stats, crd_stream_t stream);
+                  int32_t flip, void* y, float* stats, const float* in_stats, int32_t in_gmul, const float* in_gamma,
+                  const float* in_beta, crd_stream_t stream);
+/* in_stats != NULL (both functions): the input is GroupNorm-ed on load -- xn = bf16((x-mean)*rstd*gamma+beta) with the g16
+ * sums in_stats[B][C/16][2] of x and groups of in_gmul slabs, zero padding applied after the normalisation -- i.e.
+ * crd_gn_apply (Mlp.norm1, simplified_attention.py:37-38) fused into the consumer; the normalised tensor is never stored. */
 /* dw10: float [replicas][10][C], zeroed by the caller.  Rows 0..8: dw[tap][c] += sum dy*x_shifted; row 9: the bias
  * gradient sum dy.  Workgroups spread their fp32 atomics over the `replicas` copies (contended atomics on one copy
  * were the whole cost of this kernel); the true gradient is the sum of the copies (crd_wgrad_unpack does that). */
 int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw10,
-                        int32_t replicas, crd_stream_t stream);
+                        int32_t replicas, const float* in_stats, int32_t in_gmul, const float* in_gamma,
+                        const float* in_beta, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Max-pool attention (Attention_MaxPool.forward, simplified_attention.py:90-109).

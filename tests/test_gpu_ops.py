@@ -206,21 +206,52 @@ def test_dwconv(C_, H, W):
     y = torch.zeros(B, H, W, C_, dtype=torch.bfloat16, device="cuda")
     stats = torch.zeros(B, C_ // 16, 2, device="cuda")
     bc = b.detach().cuda()
-    ok(lb.crd_dwconv3x3(P(xd), B, H, W, C_, P(w9), P(bc), 0, P(y), P(stats), lib.stream()), "dwconv")
+    ok(lb.crd_dwconv3x3(P(xd), B, H, W, C_, P(w9), P(bc), 0, P(y), P(stats), None, 1, None, None, lib.stream()), "dwconv")
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert_close(got, yref.detach(), "dwconv")
     gq = got.reshape(B, C_ // 16, 16, H * W)
     assert_close(stats.cpu(), torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1), "dwconv stats", rel=1e-3, elem=2e-3)
     dyd = to_pm(dy)
     dx = torch.zeros_like(y)
-    ok(lb.crd_dwconv3x3(P(dyd), B, H, W, C_, P(w9), None, 1, P(dx), None, lib.stream()), "dwconv dgrad")
+    ok(lb.crd_dwconv3x3(P(dyd), B, H, W, C_, P(w9), None, 1, P(dx), None, None, 1, None, None, lib.stream()), "dwconv dgrad")
     assert_close(dx.float().cpu().permute(0, 3, 1, 2), xr.grad, "dwconv dx")
     for R in (1, 5):       # accumulator copies the workgroups spread their atomics over; the gradient is their sum
         dw10 = torch.zeros(R, 10, C_, device="cuda")
-        ok(lb.crd_dwconv3x3_wgrad(P(xd), P(dyd), B, H, W, C_, P(dw10), R, lib.stream()), "dwconv wgrad")
+        ok(lb.crd_dwconv3x3_wgrad(P(xd), P(dyd), B, H, W, C_, P(dw10), R, None, 1, None, None, lib.stream()), "dwconv wgrad")
         tot = dw10.sum(0).cpu()
         assert_close(tot[:9].t().reshape(C_, 1, 3, 3), w.grad, "dwconv dw", rel=2e-3, elem=4e-3)
         assert_close(tot[9], b.grad, "dwconv db", rel=2e-3, elem=4e-3)
+
+
+@pytest.mark.parametrize("C_,H,W,gmul", [(64, 9, 13, 1), (256, 17, 40, 4), (80, 8, 33, 1)])
+def test_dwconv_with_fused_input_groupnorm(C_, H, W, gmul):
+    """in_stats != NULL: GroupNorm of the input applied while the halo is staged == crd_gn_apply followed by the plain
+    kernel, bit for bit (forward, statistics and weight gradient)."""
+    lib, lb = L()
+    g = torch.Generator().manual_seed(8)
+    B = 2
+    if (C_ // 16) % gmul:
+        gmul = 1
+    xd = to_pm(bf(torch.randn(B, C_, H, W, generator=g) * 2 + 0.5))
+    dyd = to_pm(bf(torch.randn(B, C_, H, W, generator=g)))
+    w9 = (torch.randn(9, C_, generator=g) / 3).cuda()
+    bc = (torch.randn(C_, generator=g) * 0.1).cuda()
+    gam, bet = (1 + 0.1 * torch.randn(C_, generator=g)).cuda(), (0.1 * torch.randn(C_, generator=g)).cuda()
+    st_in = torch.zeros(B, C_ // 16, 2, device="cuda")
+    ok(lb.crd_gn_stats(P(xd), 0, C_, 0, B, H * W, C_, P(st_in), None, lib.stream()), "gn_stats")
+    xn = torch.zeros_like(xd)
+    ok(lb.crd_gn_apply(P(xd), 0, C_, 0, B, H * W, C_, P(st_in), gmul, P(gam), P(bet), 0, None, P(xn), 0, C_, 0, lib.stream()), "gn_apply")
+    outs = []
+    for src, nrm in ((xn, (None, 1, None, None)), (xd, (P(st_in), gmul, P(gam), P(bet)))):
+        y = torch.zeros(B, H, W, C_, dtype=torch.bfloat16, device="cuda")
+        st = torch.zeros(B, C_ // 16, 2, device="cuda")
+        ok(lb.crd_dwconv3x3(P(src), B, H, W, C_, P(w9), P(bc), 0, P(y), P(st), *nrm, lib.stream()), "dwconv")
+        dw10 = torch.zeros(1, 10, C_, device="cuda")
+        ok(lb.crd_dwconv3x3_wgrad(P(src), P(dyd), B, H, W, C_, P(dw10), 1, *nrm, lib.stream()), "dwconv wgrad")
+        outs.append((y.float().cpu(), st.cpu(), dw10.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]), "fused input norm changes the forward result"
+    assert_close(outs[1][1], outs[0][1], "stats", rel=1e-5, elem=1e-5)
+    assert_close(outs[1][2], outs[0][2], "dw10", rel=1e-5, elem=1e-5)
 
 
 @pytest.mark.parametrize("N,M,heads,d", [(200, 104, 1, 64), (130, 104, 2, 64), (70, 35, 4, 40), (104, 104, 8, 32)])

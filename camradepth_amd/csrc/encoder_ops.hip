@@ -467,7 +467,7 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
 // dq[b][n][c] = scale*dS[b][n]*k[b][idx[b][n][h(c)]][c] ; dk[b][m][c] += scale*dS[b][n]*q[b][n][c]
 __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const bf16_t* k, const float* dS, const short* idx,
                                                          long long N, int M, int heads, int d, float scale, int chunk,
-                                                         bf16_t* dq, float* dk, int use_lds) {
+                                                         bf16_t* dq, float* dk, int use_lds, float* dk_part) {
   extern __shared__ float sdk[];  // [M][C] when use_lds
   const int b = blockIdx.y;
   const int C = heads * d, CG = C >> 3;
@@ -514,8 +514,29 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
   }
   if (use_lds) {
     __syncthreads();
-    for (int i = threadIdx.x; i < M * C; i += TPB)
-      if (sdk[i] != 0.f) atomicAdd(&dk[(long long)b * M * C + i], sdk[i]);
+    if (dk_part) {   // this workgroup's whole accumulator, plain coalesced stores: [workgroup][b][M][C]; the caller sums them
+      float4* dst = reinterpret_cast<float4*>(dk_part + ((long long)blockIdx.x * gridDim.y + b) * M * C);
+      const float4* src = reinterpret_cast<const float4*>(sdk);
+      for (int i = threadIdx.x; i < (M * C) >> 2; i += TPB) dst[i] = src[i];
+    } else {
+      for (int i = threadIdx.x; i < M * C; i += TPB)
+        if (sdk[i] != 0.f) atomicAdd(&dk[(long long)b * M * C + i], sdk[i]);
+    }
+  }
+}
+
+// dst[i] = bf16(sum_r part[r*stride + i]), 8 elements per thread
+__global__ __launch_bounds__(TPB) void k_sum_partials_bf16(const float* part, int replicas, long long stride, bf16_t* dst, long long n8) {
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n8; i += (long long)gridDim.x * TPB) {
+    float v[8];
+    load8(part, i * 8, 1, v);
+    for (int r = 1; r < replicas; ++r) {
+      float w[8];
+      load8(part, (long long)r * stride + i * 8, 1, w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += w[j];
+    }
+    store8_bf16(dst, i * 8, v);
   }
 }
 
@@ -633,30 +654,59 @@ extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S
   return CRD_OK;
 }
 
+// workgroups per sample of the LDS path (0: [M][C] fp32 does not fit in LDS, the atomics path runs)
+static int attn_bwd_blocks(int B, int N, int M, int C) {
+  if ((size_t)M * C * sizeof(float) > 128 * 1024) return 0;
+  int nblk = cdiv(N, 128);
+  int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+  if (nblk > cap) nblk = cap;
+  const int chunk = cdiv(N, nblk);
+  return cdiv(N, chunk);
+}
+
+extern "C" int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d) {
+  return attn_bwd_blocks(B, N, M, heads * d);
+}
+
 extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
-                                   int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk,
+                                   int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
                                    crd_stream_t stream) {
-  CRD_CHECK_ARG(q && k && dS && idx && dq && dk, "crd_attn_scores_bwd: null pointer");
+  CRD_CHECK_ARG(q && k && dS && idx && dq && (dk || dk_partials), "crd_attn_scores_bwd: null pointer");
   CRD_CHECK_ARG(d % 8 == 0, "crd_attn_scores_bwd: head dim must be a multiple of 8");
   const int C = heads * d;
   const size_t lds = (size_t)M * C * sizeof(float);
   // dK accumulates in LDS whenever [M][C] fp32 fits (stage 3: 66.5 KB, stage 4: 106 KB); the fallback adds every
   // contribution to global memory with an atomic of its own and was 50 us per launch on stage 3
-  const int use_lds = lds <= 128 * 1024;
+  int nblk = attn_bwd_blocks(B, N, M, C);
+  const int use_lds = nblk > 0;
+  CRD_CHECK_ARG(use_lds ? (dk_partials || dk) : dk != nullptr, "crd_attn_scores_bwd: this shape needs the dk accumulator");
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_scores_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     attr_done = true;
   }
-  // pixels per workgroup: with the LDS accumulator every workgroup ends with M*C global atomics, so not too few
-  int nblk = cdiv(N, use_lds ? 128 : 64);
-  int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
-  if (nblk > cap) nblk = cap;
+  if (!use_lds) {
+    nblk = cdiv(N, 64);
+    int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+    if (nblk > cap) nblk = cap;
+  }
   int chunk = cdiv(N, nblk);
   nblk = cdiv(N, chunk);
   hipLaunchKernelGGL(k_attn_scores_bwd, dim3(nblk, B), dim3(TPB), use_lds ? lds : 0, as_stream(stream),
                      reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), dS, reinterpret_cast<const short*>(idx),
-                     (long long)N, M, heads, d, scale, chunk, reinterpret_cast<bf16_t*>(dq), dk, use_lds);
+                     (long long)N, M, heads, d, scale, chunk, reinterpret_cast<bf16_t*>(dq), dk, use_lds,
+                     use_lds ? dk_partials : nullptr);
   CRD_LAUNCH_CHECK("crd_attn_scores_bwd");
+  return CRD_OK;
+}
+
+extern "C" int crd_sum_partials_bf16(const float* part, int32_t replicas, int64_t replica_stride, void* dst, int64_t n,
+                                     crd_stream_t stream) {
+  CRD_CHECK_ARG(part && dst && replicas >= 1 && n > 0 && n % 8 == 0 && replica_stride % 8 == 0, "crd_sum_partials_bf16: bad argument");
+  long long nb = (n / 8 + TPB - 1) / TPB;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_sum_partials_bf16, dim3((unsigned)nb), dim3(TPB), 0, as_stream(stream), part, replicas, (long long)replica_stride,
+                     reinterpret_cast<bf16_t*>(dst), (long long)(n / 8));
+  CRD_LAUNCH_CHECK("crd_sum_partials_bf16");
   return CRD_OK;
 }

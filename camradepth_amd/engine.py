@@ -131,6 +131,7 @@ class Plan:
         self.shapes = {}
         self.fwd_marks = []
         self._defer = None
+        self.attn_parts = None
         self.buffers = []
         self._build()
 
@@ -676,14 +677,26 @@ class Plan:
         self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
         E = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)                                           # d(xbar)
         self.conv(g, self.conv_desc(Tb, ("dgrad", cp), Cs, 1, 1, 0, 1, 1, E, gather=1))
-        dK = self.zb(B, M, Cs)
-        self._emit(g, "crd_attn_scores_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK])
+        # dK: per-workgroup partial accumulators (plain stores) folded by the bf16 conversion below; fp32-atomic
+        # accumulation into one buffer only when [M][C] does not fit in LDS
+        nparts = self.lib.crd_attn_scores_bwd_partials(B, N, M, heads, dh)
+        if nparts > 0:
+            if self.attn_parts is None or self.attn_parts.numel() < nparts * B * M * Cs:
+                self.attn_parts = self.new((nparts * B * M * Cs,), F32)     # shared scratch: produced and consumed back to back
+            dK = None
+            self._emit(g, "crd_attn_scores_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, None, self.attn_parts])
+        else:
+            dK = self.zb(B, M, Cs)
+            self._emit(g, "crd_attn_scores_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None])
         self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".q.bias"))
         Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
         self._emit(g, "crd_scale_f32", [E.t, Es.t, B * Cs, 1.0 / N])
         self.conv(g, self.conv_desc(DQ, ("dgrad", cq), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, bias=Es.t, bias_bstride=Cs))
         DKb = self.act(Cs, Hs // sr, Ws // sr)
-        self._emit(g, "crd_f32_to_bf16_rows", [dK, Cs, DKb.t, Cs, 0, B * M, Cs, None, 1, None, 0, 0])
+        if dK is None:
+            self._emit(g, "crd_sum_partials_bf16", [self.attn_parts, nparts, B * M * Cs, DKb.t, B * M * Cs])
+        else:
+            self._emit(g, "crd_f32_to_bf16_rows", [dK, Cs, DKb.t, Cs, 0, B * M, Cs, None, 1, None, 0, 0])
         if sr > 1:
             self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=self.g(a + ".k.bias"))
             DKR = self.act(Cs, Hs // sr, Ws // sr)

@@ -178,9 +178,19 @@ int crd_attn_out_residual(const float* x, const float* u, const float* S, const 
  * chain of contended atomics at the workgroups of one sample; crd_wgrad_unpack (replicas = B) folds them. */
 int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
                      int32_t C, float* t, float* dbp_rows, float* dS, crd_stream_t stream);
-/* dq[b][n][c] = scale*dS[b][n]*k[b][idx][c] (bf16) ; dk[b][m][c] += scale*dS*q (fp32, caller zeroes) */
+/* dq[b][n][c] = scale*dS[b][n]*k[b][idx][c] (bf16) ; dk[b][m][c] += scale*dS*q (fp32, caller zeroes).
+ * Every workgroup accumulates its share of dk in LDS (when [M][C] fp32 fits: always at the reference's sizes).  With
+ * dk_partials != NULL (float [P][B][M][C], P = crd_attn_scores_bwd_partials(B,N,M,heads,d) > 0; contents don't-care)
+ * the workgroups store their accumulators there with plain stores and dk is not touched: dk = sum over P, which
+ * crd_sum_partials_bf16 folds together with the bf16 conversion the next layer needs.  With dk_partials == NULL they add
+ * into dk with fp32 atomics (2.7 M of them per launch at stage 1: ~16 us at the ~170 G/s the L2s sustain). */
+int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d);
 int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
-                        int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, crd_stream_t stream);
+                        int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
+                        crd_stream_t stream);
+/* dst[i] = bf16(sum_{r < replicas} part[r*replica_stride + i]), i < n (n, replica_stride multiples of 8) */
+int crd_sum_partials_bf16(const float* part, int32_t replicas, int64_t replica_stride, void* dst, int64_t n,
+                          crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bicubic x2 up-sampling, A=-0.75, align_corners=False, clamped borders (nn.Upsample, utils.py:241,

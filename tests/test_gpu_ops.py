@@ -280,7 +280,7 @@ def test_attention_scores_and_backward(N, M, heads, d):
     dq = torch.zeros(B, N, C_, dtype=torch.bfloat16, device="cuda")
     dk = torch.zeros(B, M, C_, device="cuda")
     dSc = dS.cuda()
-    ok(lb.crd_attn_scores_bwd(P(qd), P(kd), P(dSc), P(idx), B, N, M, heads, d, scale, P(dq), P(dk), lib.stream()),
+    ok(lb.crd_attn_scores_bwd(P(qd), P(kd), P(dSc), P(idx), B, N, M, heads, d, scale, P(dq), P(dk), None, lib.stream()),
        "attn_scores_bwd")
     ii = idx.cpu().long()
     dq_ref = torch.zeros(B, N, heads, d)
@@ -292,6 +292,17 @@ def test_attention_scores_and_backward(N, M, heads, d):
             dk_ref[b, :, h].index_add_(0, ii[b, :, h], scale * dS[b].unsqueeze(1) * q4[b, :, h])
     assert_close(dq.float().cpu(), dq_ref.reshape(B, N, C_), "dq")
     assert_close(dk.cpu(), dk_ref.reshape(B, M, C_), "dk", rel=1e-4, elem=1e-4)
+    # partial-accumulator variant: per-workgroup stores, folded together with the bf16 conversion
+    nparts = lb.crd_attn_scores_bwd_partials(B, N, M, heads, d)
+    assert nparts >= 1
+    parts = torch.full((nparts, B, M, C_), float("nan"), device="cuda")
+    dq2 = torch.zeros_like(dq)
+    ok(lb.crd_attn_scores_bwd(P(qd), P(kd), P(dSc), P(idx), B, N, M, heads, d, scale, P(dq2), None, P(parts), lib.stream()),
+       "attn_scores_bwd partials")
+    assert torch.equal(dq2, dq)
+    dkb = torch.zeros(B, M, C_, dtype=torch.bfloat16, device="cuda")
+    ok(lb.crd_sum_partials_bf16(P(parts), nparts, B * M * C_, P(dkb), B * M * C_, lib.stream()), "sum_partials")
+    assert_close(dkb.float().cpu(), bf(dk_ref.reshape(B, M, C_)), "dk from partials (bf16)", rel=4e-3, elem=1e-2)
 
 
 def test_attention_output_path():

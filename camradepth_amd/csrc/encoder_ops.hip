@@ -507,9 +507,18 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
 #pragma unroll
       for (int j = 0; j < 8; ++j) kv[u][j] *= gv[u];
       store8_bf16(dq, ((long long)b * N + nv[u]) * C + cgv[u] * 8, kv[u]);
-      float* dst = use_lds ? &sdk[mv[u] * C + cgv[u] * 8] : &dk[((long long)b * M + mv[u]) * C + cgv[u] * 8];
+      // two explicit branches: one pointer that may be LDS or global compiles to FLAT atomics.  (The LDS float atomics are
+      // still 20 of the 28 us of this kernel -- ds_add_f32 retires about one lane every few cycles; an owner-computes scan
+      // over the chunk's pixels instead measured slower, 27-69 us.)
+      if (use_lds) {
+        float* dst = &sdk[mv[u] * C + cgv[u] * 8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[u][j]);
+        for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[u][j]);
+      } else {
+        float* dst = &dk[((long long)b * M + mv[u]) * C + cgv[u] * 8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[u][j]);
+      }
     }
   }
   if (use_lds) {

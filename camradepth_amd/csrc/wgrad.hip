@@ -170,7 +170,12 @@ __device__ __forceinline__ void wgrad_tile(const WgK& a, const int bx, const int
     if (kt + 1 < nK) lstore(cur ^ 1);
     __syncthreads();
   }
-  if (do_bias && m0 + t < a.Cout) atomicAdd(a.dbias + m0 + t, bsum);
+  // The grouped kernel loads its descriptor from memory, so the compiler no longer knows that dw / dbias are global
+  // pointers and would emit FLAT atomics; say so explicitly.
+  typedef __attribute__((address_space(1))) float gfloat;
+  gfloat* gdw = (gfloat*)a.dw;
+  gfloat* gdb = (gfloat*)a.dbias;
+  if (do_bias && m0 + t < a.Cout) __hip_atomic_fetch_add(gdb + m0 + t, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   // D layout (16x16): col = lane&15 -> kf, row = (lane>>4)*4 + r -> co
 #pragma unroll
@@ -181,7 +186,7 @@ __device__ __forceinline__ void wgrad_tile(const WgK& a, const int bx, const int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = m0 + (wm * TMc + i) * 16 + (l >> 4) * 4 + r;
-        if (co < a.Cout && kfo < a.Ktot && (!(a.dbg & 1) || acc[i][j][r] == 123.456f)) atomicAdd(a.dw + (long long)co * a.Ktot + kfo, acc[i][j][r]);
+        if (co < a.Cout && kfo < a.Ktot && (!(a.dbg & 1) || acc[i][j][r] == 123.456f)) __hip_atomic_fetch_add(gdw + (long long)co * a.Ktot + kfo, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
 }

@@ -181,6 +181,13 @@ class TrainStep:
         # undo the warm-up's parameter update side effects on the optimizer state
         for t in (self.m, self.v, self.pg, self.egn, self.nsq, self.fac):
             t.zero_()
+        if self.world == 1:      # no collective between the segments: the whole step is one graph (five fewer launches)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for fn, _ in self._segments():
+                    fn()
+            self.graphs.append((g, None))
+            return
         for fn, after in self._segments():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -219,7 +226,7 @@ class TrainStep:
             if after == "loss":
                 if self.world > 1:
                     dist.all_reduce(self.acc, group=self.sync.group)
-            elif after is not None:
+            elif after is not None and self.world > 1:
                 self.sync.launch(after)
                 if i == len(runs) - 2:
                     self.sync.wait()

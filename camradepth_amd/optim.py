@@ -118,6 +118,33 @@ class diffGradNorm(Optimizer):
                 self.state[p]["step"] = st["step"]
         return loss
 
+    def load_state_dict(self, state_dict):
+        """Restores a checkpoint written by this class or by the reference's diffGradNorm (same per-parameter keys:
+        step, exp_avg, exp_avg_sq, previous_grad, exp_grad_norm; runner.py:369).  torch's loader replaces the state
+        tensors; the kernels work on flat buffers the state entries are views of, so the loaded values are copied into
+        those buffers and the views re-attached."""
+        super().load_state_dict(state_dict)
+        loaded = {p: dict(self.state[p]) for g in self.param_groups for p in g["params"] if p in self.state}
+        if self._groups is None:
+            self._groups = [self._build(g) for g in self.param_groups]
+        for group, st in zip(self.param_groups, self._groups):
+            for t, (p, o) in enumerate(zip(st["ps"], st["offs"])):
+                n = p.numel()
+                views = {"exp_avg": st["m"][o:o + n].view(p.shape), "exp_avg_sq": st["v"][o:o + n].view(p.shape),
+                         "previous_grad": st["pg"][o:o + n].view(p.shape)}
+                src = loaded.get(p)
+                if src is not None:
+                    for k, v in views.items():
+                        if k in src:
+                            v.copy_(torch.as_tensor(src[k]).to(v.device, v.dtype).reshape(p.shape))
+                    if "exp_grad_norm" in src:
+                        st["egn"][t] = float(src["exp_grad_norm"])
+                    st["step"] = max(st["step"], int(src.get("step", 0)))
+                s = self.state[p]
+                s.update(views)
+                s["exp_grad_norm"] = st["egn"][t]
+                s["step"] = st["step"]
+
     def zero_grad(self, set_to_none=False):
         """Gradients live in one flat buffer that the backward kernels accumulate into; they are zeroed in
         place (the reference's set_to_none=True would detach the views the kernels write through)."""

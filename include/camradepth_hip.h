@@ -272,6 +272,20 @@ int crd_dropout_masks(float* out, const float* keep, int32_t rows, int32_t cols,
                       crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Batch assembly (NuscenesDataset.__getitem__, src/data/dataloader.py:202-333) -- SURVEY 8f N1.
+ * ------------------------------------------------------------------------------------------- */
+/* out: fp32 [B][7 or 6][H][W].  Channels 0-2: (img/255 - mean)/std of the uint8 [B][H][W][3] image in the order it was
+ * read (cv2 BGR; the reference applies the RGB ImageNet constants as is, :226-233); 3: clip(radar[...,0], 0, max_depth) /
+ * max_depth (:304-306); 4-5: radar[...,1..2] (:309-310); 6: rad_vel (:315-318; NULL -> 6 channels).  radar: fp32
+ * [B][H][W][3], rad_vel: fp32 [B][H][W]. */
+int crd_assemble_input(const void* img_u8, const float* radar, const float* rad_vel, int32_t B, int32_t H, int32_t W,
+                       float max_depth, float* out, crd_stream_t stream);
+/* Ground-truth pyramid (:236-257): full = inverse-normalised depth (clip to [0, max], g > 0 -> (max - g)/max); half,
+ * quarter, eighth = successive zero-ignoring 3x3 / stride 2 / pad 1 min-pools (:213-222); lower levels may be NULL. */
+int crd_gt_pyramid(const float* depth, int32_t B, int32_t H, int32_t W, float max_depth, float* full, float* half,
+                   float* quarter, float* eighth, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Losses (src/utils/loss_funcs.py:14-46,77-91; combination src/main/runner.py:197-218).
  * ------------------------------------------------------------------------------------------- */
 /* acc[0] += sum smooth_l1(pred-target), acc[1] += #(target>0), acc[2] += sum (target-pred)^2 ; caller zeroes acc */

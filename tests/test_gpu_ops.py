@@ -544,3 +544,39 @@ def test_depth_metrics_match_reference_golden():
     pf = dm50.per_frame()
     np.testing.assert_allclose([pf[0]["MAE"], pf[0]["RMSE"], pf[0]["REL"]], [m["MAE"], m["RMSE"], m["REL"]], rtol=2e-5)
     assert pf[1] is None and dm50.result() is not None
+
+
+def test_batch_assembly_matches_dataloader_arithmetic():
+    """crd_assemble_input / crd_gt_pyramid against the reference dataloader's own torch / numpy arithmetic
+    (dataloader.py:213-222, 226-257, 300-318), restated here: ToTensor + Normalize, clip / scale, MaxPool2d-based minpool."""
+    from camradepth_amd.batch import assemble_batch
+    g = torch.Generator().manual_seed(21)
+    B, H, W, max_depth = 2, 34, 50, 100.0
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    radar = torch.zeros(B, H, W, 3)
+    m = torch.rand(B, H, W, generator=g) < 0.05
+    radar[..., 0][m] = torch.rand(int(m.sum()), generator=g) * 130 - 5          # also below 0 and above max_depth
+    radar[..., 1:][m] = torch.randn(int(m.sum()), 2, generator=g)
+    rad_vel = torch.randn(B, H, W, generator=g) * m
+    depth = torch.rand(B, H, W, generator=g) * 140 * (torch.rand(B, H, W, generator=g) < 0.2)
+    out = assemble_batch(img.cuda(), radar.cuda(), rad_vel.cuda(), depth.cuda(), max_depth)
+    # reference arithmetic
+    mean, std = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1), torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
+    image = (img.permute(0, 3, 1, 2).float() / 255 - mean) / std
+    rd = radar[..., 0].clamp(0, max_depth) / max_depth
+    ref_x = torch.cat([image, rd.unsqueeze(1), radar[..., 1:].permute(0, 3, 1, 2), rad_vel.unsqueeze(1)], 1)
+    assert_close(out["image"].cpu(), ref_x, "assembled input", rel=1e-6, elem=1e-5)
+    gt = depth.clamp(0, max_depth)
+    gt = torch.where(gt > 0, (max_depth - gt) * (1 / max_depth), gt).unsqueeze(1)
+
+    def minpool(t):
+        x = t.clone()
+        x[t == 0] = 255
+        x = -F.max_pool2d(-x, kernel_size=3, stride=2, padding=1)
+        x[x == 255] = 0
+        return x
+    refs = [gt, minpool(gt), minpool(minpool(gt)), minpool(minpool(minpool(gt)))]
+    for name, ref in zip(("gt_full", "gt_half", "gt_quarter", "gt_eighth"), refs):
+        got = out[name].cpu()
+        assert got.shape == ref.shape, (name, got.shape, ref.shape)
+        assert torch.equal(got, ref) or float((got - ref).abs().max()) < 1e-7, name

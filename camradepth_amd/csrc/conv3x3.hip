@@ -28,15 +28,17 @@ constexpr int HPAD = HGROUPS * 8;         // 344 rows allocated
 constexpr int CK = 64;                    // channels per chunk (8 granules, 128-byte LDS rows)
 constexpr int NW = 8;                     // waves per workgroup
 constexpr int HTAPS = 6;                  // taps 0..5 of a chunk carry the next chunk's halo (6 x 8 waves = 48 >= 43 groups)
-constexpr int WS = 4;                     // weight-slab ring: the slab of step t+3 is in flight while step t computes
+// (weight-slab ring size WS is a kernel template parameter: 4 = the slab of step t+3 is in flight while step t computes;
+// 3 for the 160-column tile, whose slabs are 20 KB)
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int WM, int WN, int TM, int TN, int MODE>
+template <int WM, int WN, int TM, int TN, int MODE, int WS>
 __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
+  constexpr int D = WS - 1;                       // prefetch distance of the weight slabs, in steps
   static_assert(WM * WN == NW && WM * TM == TH, "8 waves cover the 8 tile rows");
   constexpr int BN = WN * TN * 32;
   constexpr int WGROUPS = BN / 8;                 // weight-slab DMA groups (8 rows each)
@@ -63,7 +65,7 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
   // ---- per-thread DMA descriptors -------------------------------------------------------------------------
   // Every wave issues the SAME instruction sequence each step -- its WJ groups of the weight slab of step t+3, then one
   // group of the next chunk's halo (a zero-fill dummy, offset out of range, when there is nothing to fetch) -- so one
-  // counted wait serves all steps: vmcnt is in order, and behind the slab of step t+1 there are exactly 1 + 2*PER
+  // counted wait serves all steps: vmcnt is in order, and behind the slab of step t+1 there are exactly 1 + (D-1)*PER
   // younger DMAs.  A tap step is only ~0.25 us of MFMA work while an L2 hit takes 0.5-1 us, so the slab has to be
   // requested three steps ahead (a two-slot ring stalled every step); the HBM-latency halo groups sit BEHIND the slab
   // groups of their step, where nothing waits on them before the chunk ends.
@@ -136,24 +138,24 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_v;
   }
 
-  // prologue, shaped like three steps of the loop: (whole halo of chunk 0, slab 0), (slab 1, dummy), (slab 2, dummy)
+  // prologue, shaped like D steps of the loop: (whole halo of chunk 0, slab 0), then (slab s, dummy) for s = 1..D-1
 #pragma unroll
   for (int s = 0; s < HTAPS; ++s) stage_halo_piece(s, 0, 0);
   stage_weights(0, 0, 0);
-  stage_weights(0, 1, 1); stage_halo_piece(-1, 0, 1);
-  stage_weights(0, 2, 2); stage_halo_piece(-1, 0, 1);
-  wait_vm<2 * PER>();                     // halo of chunk 0 and slab 0 (everything but the last two "steps")
+#pragma unroll
+  for (int s = 1; s < D; ++s) { stage_weights(0, s, s); stage_halo_piece(-1, 0, 1); }
+  wait_vm<(D - 1) * PER>();               // halo of chunk 0 and slab 0 (everything but the last D-1 "steps")
   asm volatile("s_barrier" ::: "memory");
 
   int step = 0;
-  int pc = 0, pt = 3;                      // (chunk, tap) of the slab to request: step + 3
+  int pc = 0, pt = D;                      // (chunk, tap) of the slab to request: step + D
+  int wb = 0, wnext = D % WS;              // ring slots: slab of this step / slab being requested
   for (int chunk = 0; chunk < nChunks; ++chunk) {
     const int hb = chunk & 1;
     int nks = (Cin - chunk * CK + 15) >> 4;
     if (nks > 4) nks = 4;
     for (int tap = 0; tap < 9; ++tap, ++step) {
-      const int wb = step & (WS - 1);
-      stage_weights(pc, pt, (step + 3) & (WS - 1));
+      stage_weights(pc, pt, wnext);
       stage_halo_piece(tap < HTAPS ? tap : -1, chunk + 1, hb ^ 1);
       if (++pt == 9) { pt = 0; ++pc; }
       const int ky = tap / 3, kx = tap - ky * 3;
@@ -185,8 +187,10 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
       // the slab of step+1 (requested two steps ago) and every older DMA of this wave -- in particular the next chunk's
       // halo groups, requested in taps 0..5 -- have landed; the barrier extends that to all waves.
       // Raw s_barrier: __syncthreads() would drain the whole DMA queue (vmcnt(0)) here.
-      wait_vm<1 + 2 * PER>();
+      wait_vm<1 + (D - 1) * PER>();
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      wb = wb + 1 == WS ? 0 : wb + 1;
+      wnext = wnext + 1 == WS ? 0 : wnext + 1;
     }
   }
   wait_vm<0>();                            // dummy slabs / halo groups still target the LDS the epilogue reuses
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(512) void k_conv3x3(ConvK a, int tiles_x) {
   });
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int WS = 4>
 int launch3(const ConvK& k0, int B, hipStream_t st, long long partial_cap) {
   constexpr int BN = WN * TN * 32;
   ConvK k = k0;
@@ -217,16 +221,16 @@ int launch3(const ConvK& k0, int B, hipStream_t st, long long partial_cap) {
   static bool attr_done[2] = {false, false};
   if (k.gather_mode == 0) {
     if (!attr_done[0]) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 0, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done[0] = true;
     }
-    hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 0>), grid, dim3(512), lds, st, k, tiles_x);
+    hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 0, WS>), grid, dim3(512), lds, st, k, tiles_x);
   } else {
     if (!attr_done[1]) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 1, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       attr_done[1] = true;
     }
-    hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 1>), grid, dim3(512), lds, st, k, tiles_x);
+    hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 1, WS>), grid, dim3(512), lds, st, k, tiles_x);
   }
   if (k.stats && k.stats_partial)
     hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, k.n_tiles, k.G16, k.stats);
@@ -241,5 +245,8 @@ int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_ca
   if (k.Cout <= 32) return launch3<8, 1, 1, 1>(k, B, st, partial_cap);
   if (k.Cout <= 64) return launch3<4, 2, 2, 1>(k, B, st, partial_cap);
   if (k.Cout <= 96) return launch3<8, 1, 1, 3>(k, B, st, partial_cap);
+  // 129..160 and 257..320 output channels (data gradients towards 136 / 144 / 296 / 304-channel concat inputs): 160-wide
+  // tiles instead of a nearly empty last 128-wide one
+  if ((k.Cout > 128 && k.Cout <= 160) || (k.Cout > 256 && k.Cout <= 320)) return launch3<8, 1, 1, 5, 3>(k, B, st, partial_cap);
   return launch3<4, 2, 2, 2>(k, B, st, partial_cap);
 }

@@ -85,6 +85,8 @@ def halo_tile(cout):
         return "k_conv3x3<4,2,2,1>"
     if cout <= 96:
         return "k_conv3x3<8,1,1,3>"
+    if 128 < cout <= 160 or 256 < cout <= 320:
+        return "k_conv3x3<8,1,1,5>"
     return "k_conv3x3<4,2,2,2>"
 
 
@@ -200,8 +202,9 @@ class Plan:
         # tile 13-37 % full; the ragged tail goes to a second launch with a narrower tile instead (same operands, weight
         # rows and output slice offset by the split point).
         cout = spec["cout"]
-        if (halo and SPLIT_N and cout > 128 and 0 < cout % 128 <= 64 and spec["bias"] is None and spec["stats"] is None
-                and spec["res"] is None and "w_row0" not in spec):
+        covered = cout <= 160 or 256 < cout <= 320          # the library's 160-column tile handles these without a ragged tail
+        if (halo and SPLIT_N and cout > 128 and 0 < cout % 128 <= 64 and not covered and spec["bias"] is None
+                and spec["stats"] is None and spec["res"] is None and "w_row0" not in spec):
             c_main = cout // 128 * 128
             for c0, c1 in ((0, c_main), (c_main, cout)):
                 sub = dict(spec)

@@ -93,6 +93,10 @@ CASES = [
     (1, 129, 136, 17, 40, 32, 3, 1, 1),
     (2, 128, 128, 9, 33, 21, 3, 1, 1),
     (1, 48, 48, 40, 32, 128, 3, 1, 1),
+    # 160-column tile (3-slot weight ring): one and two tiles, ragged
+    (2, 96, 96, 17, 40, 144, 3, 1, 1),
+    (1, 128, 128, 9, 64, 304, 3, 1, 1),
+    (1, 64, 64, 24, 33, 136, 3, 1, 1),
 ]
 
 
@@ -162,6 +166,8 @@ DGRAD_CASES = [
     (2, 304, 19, 45, 128, 3, 1, 1),      # halo-tile kernel, data-gradient mode (mirrored taps), 3 N tiles
     (1, 144, 17, 40, 96, 3, 1, 1),
     (1, 128, 9, 64, 32, 3, 1, 1),
+    (1, 296, 9, 33, 128, 3, 1, 1),       # 160-column tiles: N = 296 (two tiles), 136 (one)
+    (2, 136, 17, 40, 96, 3, 1, 1),
 ]
 
 

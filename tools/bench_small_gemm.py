@@ -12,6 +12,7 @@ SHAPES = [  # Cin, Cout, H, W, k, stride, gather_mode
     (256, 64, 64, 104, 1, 1, 0), (256, 1024, 8, 13, 1, 1, 0), (1024, 256, 8, 13, 1, 1, 0), (256, 256, 8, 13, 1, 1, 0),
     (640, 160, 16, 26, 1, 1, 1), (160, 640, 16, 26, 1, 1, 1), (512, 128, 32, 52, 1, 1, 1)]
 NSET, REPS = 12, 120
+STATS = len(sys.argv) > 1 and sys.argv[1] == "stats"
 for Cin, Cout, H, W, k, s, mode in SHAPES:
     OH, OW = H // s, W // s
     sets, descs = [], []
@@ -24,7 +25,10 @@ for Cin, Cout, H, W, k, s, mode in SHAPES:
         d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = w.data_ptr(), Cout, k, k, s, 0, OH, OW
         d.gather_mode = mode
         d.y, d.y_ld, d.y_coff, d.y_f32 = y.data_ptr(), Cout, 0, 0
-        sets.append((x, w, y)); descs.append(d)
+        st_ = torch.zeros(B, Cout // 16, 2, device="cuda")
+        if STATS and Cout % 16 == 0:
+            d.stats = st_.data_ptr()
+        sets.append((x, w, y, st_)); descs.append(d)
     st = torch.cuda.Stream()
     with torch.cuda.stream(st):
         def run():

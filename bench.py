@@ -54,6 +54,8 @@ def per_kernel_timing(ts, reps=3):
                 plan.zf_arena.zero_()
             evs = []
             for op in ops:
+                if op.fn is None:                  # join marker of a side branch (this pass runs everything on one stream)
+                    continue
                 if op.meta is None:
                     op.fn(*op.args, st)
                     continue

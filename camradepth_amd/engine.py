@@ -24,6 +24,10 @@ from .params import short_res_block_plan
 
 # developer switch: CRD_NO_GROUP_WGRAD=1 runs every small weight gradient as its own launch (A/B against the grouped launch)
 GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
+# Side branches (q projection, rank-one vector path, depthwise weight gradient on separate graph branches) are recorded
+# only on request: measured 27.7-28.9 ms/step against 26.7 on one stream -- every fork / join costs more in the captured
+# graph than the short kernels it takes off the chain.
+SIDE_STREAMS = os.environ.get("CRD_SIDE_STREAMS") is not None
 SPLIT_N = os.environ.get("CRD_NO_SPLIT_N") is None      # developer switch for the ragged-tile split of 3x3 data gradients
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
 HEAD_ROWS = 64        # same for Depth_Activation.conv_2 (2048 workgroups x 289 sums)
@@ -56,10 +60,13 @@ class PM:
 
 
 class Op:
-    __slots__ = ("fn", "args", "name", "region", "acc_slot", "meta")
+    """One recorded kernel call.  stream: 0 = the main stream; 1, 2 = side branches (ops that do not depend on the main
+    ops recorded after the point where the branch was opened); fn None = join marker: the main stream waits for the branch."""
+    __slots__ = ("fn", "args", "name", "region", "acc_slot", "meta", "stream")
 
-    def __init__(self, fn, args, name, region=None, acc_slot=None, meta=None):
+    def __init__(self, fn, args, name, region=None, acc_slot=None, meta=None, stream=0):
         self.fn, self.args, self.name, self.region, self.acc_slot, self.meta = fn, args, name, region, acc_slot, meta
+        self.stream = stream
 
 
 def igemm_tile(cout, ohw=1 << 30, batch=1):
@@ -133,6 +140,8 @@ class Plan:
         self.shapes = {}
         self.fwd_marks = []
         self._defer = None
+        self._cur_stream = 0
+        self._side_streams = None
         self.attn_parts = None
         self.buffers = []
         self._build()
@@ -173,9 +182,30 @@ class Plan:
 
     # ------------------------------------------------------------------ op emitters
     def _emit(self, lst, fn_name, args, region=None, acc_slot=None):
-        op = Op(getattr(self.lib, fn_name), list(args), fn_name, region, acc_slot)
+        op = Op(getattr(self.lib, fn_name), list(args), fn_name, region, acc_slot, stream=self._cur_stream)
         lst.append(op)
         return op
+
+    class _Side:
+        def __init__(self, plan, s):
+            self.plan, self.s = plan, s
+
+        def __enter__(self):
+            self.prev, self.plan._cur_stream = self.plan._cur_stream, self.s
+
+        def __exit__(self, *a):
+            self.plan._cur_stream = self.prev
+
+    def side(self, s):
+        """`with self.side(1): ...` records the enclosed ops on side branch s (1 or 2): they may only read what was
+        produced before the first op of the branch, and nothing recorded on the main stream before the matching join()
+        may touch what they write.  The step is a chain of ~1500 mostly latency-bound kernels; branches take short
+        independent pieces (a weight gradient, the q projection, the rank-one attention vector path) off that chain."""
+        return Plan._Side(self, s if SIDE_STREAMS else 0)
+
+    def join(self, lst, s):
+        if SIDE_STREAMS:
+            lst.append(Op(None, [], "join", stream=s))
 
     def _push(self, grp):
         """Register the backward ops of one forward unit; units are replayed in reverse order."""
@@ -216,7 +246,8 @@ class Plan:
         meta = {"kernel": kname, "flops": flops,
                 "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
                          f"out{spec['OH']}x{spec['OW']}"}
-        op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None, meta)
+        op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None, meta,
+                stream=self._cur_stream)
         lst.append(op)
         return op
 
@@ -231,7 +262,7 @@ class Plan:
         if self._defer is not None and not stream3:
             self._defer.append((spec, meta))      # runs in the segment's grouped launch (see flush_deferred)
             return
-        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta))
+        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta, stream=self._cur_stream))
 
     def flush_deferred(self, lst):
         """Emit ONE grouped weight-gradient launch for every wgrad deferred since `self._defer = []` (the small GEMMs
@@ -613,7 +644,13 @@ class Plan:
         self.gn_stats_apply(X, st1, ch1, 1, name + ".norm1", 0, None, XN)
         cq, ck, cp = self.new_conv(a + ".q"), self.new_conv(a + ".k"), self.new_conv(a + ".proj")
         Q = self.act(Cs, Hs, Ws)
-        self.conv(F_, self.conv_desc(XN, cq, Cs, 1, 1, 0, Hs, Ws, Q, bias=cq.bias))
+        with self.side(1):       # q projection: independent of the key path below
+            self.conv(F_, self.conv_desc(XN, cq, Cs, 1, 1, 0, Hs, Ws, Q, bias=cq.bias))
+        xbar = PM(self.new((B, 1, Cs)), Cs, 1, 1)
+        U = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
+        with self.side(2):       # rank-one value path: xbar = mean_n GN(x) -> proj
+            self._emit(F_, "crd_attn_xbar", [ch1, st1, self.p(name + ".norm1.weight"), self.p(name + ".norm1.bias"), B, N, Cs, xbar.t])
+            self.conv(F_, self.conv_desc(xbar, cp, Cs, 1, 1, 0, 1, 1, U))
         K = self.act(Cs, Hs // sr, Ws // sr)
         if sr > 1:
             csr = self.new_conv(a + ".sr", scatter=True)
@@ -625,10 +662,8 @@ class Plan:
             self.conv(F_, self.conv_desc(KRN, ck, Cs, 1, 1, 0, Hs // sr, Ws // sr, K, bias=ck.bias))
         else:
             self.conv(F_, self.conv_desc(XN, ck, Cs, 1, 1, 0, Hs, Ws, K, bias=ck.bias))
-        xbar = PM(self.new((B, 1, Cs)), Cs, 1, 1)
-        self._emit(F_, "crd_attn_xbar", [ch1, st1, self.p(name + ".norm1.weight"), self.p(name + ".norm1.bias"), B, N, Cs, xbar.t])
-        U = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
-        self.conv(F_, self.conv_desc(xbar, cp, Cs, 1, 1, 0, 1, 1, U))
+        self.join(F_, 1)
+        self.join(F_, 2)
         Ssum = self.new((B, N), F32)
         idx = self.new((B, N, heads), torch.int16)
         self.keep.append(("idx", name, idx, M))
@@ -664,7 +699,8 @@ class Plan:
         self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID)                 # in place: d(H2)
         dw10 = self.zb(DW_REPLICAS, 10, hid)      # [copy][9 taps + bias][channel]; the unpack kernel sums the copies
         self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
-        self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
+        with self.side(1):       # off the chain: nothing below reads dw10 before the segment's unpack
+            self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None])  # d(H1N)
         self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2)                    # in place: d(H1)
         self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc1.bias"))
@@ -676,10 +712,13 @@ class Plan:
         self.row_grads.append((a + ".proj.bias", Cs, dbp_rows, B, self._tag, 0, Cs))
         self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
         Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
-        self._emit(g, "crd_f32_to_bf16_rows", [T, Cs, Tb.t, Cs, 0, B, Cs, None, 1, None, 0, 0])
-        self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
         E = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)                                           # d(xbar)
-        self.conv(g, self.conv_desc(Tb, ("dgrad", cp), Cs, 1, 1, 0, 1, 1, E, gather=1))
+        Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
+        with self.side(2):       # rank-one vector path, needed again only as the bias of the q data gradient
+            self._emit(g, "crd_f32_to_bf16_rows", [T, Cs, Tb.t, Cs, 0, B, Cs, None, 1, None, 0, 0])
+            self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
+            self.conv(g, self.conv_desc(Tb, ("dgrad", cp), Cs, 1, 1, 0, 1, 1, E, gather=1))
+            self._emit(g, "crd_scale_f32", [E.t, Es.t, B * Cs, 1.0 / N])
         # dK: per-workgroup partial accumulators (plain stores) folded by the bf16 conversion below; fp32-atomic
         # accumulation into one buffer only when [M][C] does not fit in LDS
         nparts = self.lib.crd_attn_scores_bwd_partials(B, N, M, heads, dh)
@@ -692,8 +731,7 @@ class Plan:
             dK = self.zb(B, M, Cs)
             self._emit(g, "crd_attn_scores_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None])
         self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".q.bias"))
-        Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
-        self._emit(g, "crd_scale_f32", [E.t, Es.t, B * Cs, 1.0 / N])
+        self.join(g, 2)
         self.conv(g, self.conv_desc(DQ, ("dgrad", cq), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, bias=Es.t, bias_bstride=Cs))
         DKb = self.act(Cs, Hs // sr, Ws // sr)
         if dK is None:
@@ -712,6 +750,7 @@ class Plan:
             self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".k.bias"))
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=1))
         self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1)               # DX = d(X)
+        self.join(g, 1)           # the depthwise weight gradient reads DHID, which the next block overwrites
         self._push(g)
         return X2
 
@@ -857,6 +896,8 @@ class Plan:
         lib = self.lib
         if os.environ.get("CRD_DEBUG_SYNC"):      # developer aid: name the faulting kernel
             for i, op in enumerate(ops):
+                if op.fn is None:
+                    continue
                 print(f"[crd] op {i} {op.name}", flush=True)
                 rc = op.fn(*op.args, st)
                 torch.cuda.synchronize()
@@ -883,12 +924,35 @@ class Plan:
         pad = int(os.environ.get("CRD_EXP_PAD", "0"))       # experiment: cost of an extra tiny dispatch after every op
         if pad and not hasattr(self, "_pad_buf"):
             self._pad_buf = torch.zeros(64, device=self.dev)
+        main = torch.cuda.current_stream()
+        open_ = {}                                 # side branch -> its stream handle, while the branch is open
         for op in ops:
-            rc = op.fn(*op.args, st)
+            if op.fn is None:                      # join marker
+                if op.stream in open_:
+                    ev = torch.cuda.Event()
+                    ev.record(self._side_streams[op.stream - 1])
+                    main.wait_event(ev)
+                    del open_[op.stream]
+                continue
+            sh = st
+            if op.stream:
+                if op.stream not in open_:         # open the branch here: it sees everything enqueued on main so far
+                    if self._side_streams is None:
+                        self._side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+                    ev = torch.cuda.Event()
+                    ev.record(main)
+                    self._side_streams[op.stream - 1].wait_event(ev)
+                    open_[op.stream] = C.c_void_p(self._side_streams[op.stream - 1].cuda_stream)
+                sh = open_[op.stream]
+            rc = op.fn(*op.args, sh)
             if rc != 0:
                 raise L.CrdError(f"{op.name} failed ({rc}): {lib.crd_last_error().decode()}")
             for _ in range(pad):
                 lib.crd_scale_f32(self._pad_buf.data_ptr(), self._pad_buf.data_ptr(), 64, 1.0, st)
+        for sid in list(open_):                    # never leave a branch open past the end of the list
+            ev = torch.cuda.Event()
+            ev.record(self._side_streams[sid - 1])
+            main.wait_event(ev)
 
     def forward(self, masks=None):
         """x must already be in self.x_in.  masks: optional injected {'drop_path': [...], 'dropout2d': [...]}."""

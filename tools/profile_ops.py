@@ -21,6 +21,8 @@ for rep in range(3):
     for phase, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
         evs = []
         for i, op in enumerate(ops):
+            if op.fn is None:
+                continue
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(); op.fn(*op.args, st); e1.record()
             evs.append((phase, i, op, e0, e1))

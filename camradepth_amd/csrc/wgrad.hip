@@ -12,6 +12,7 @@
 #include "common.h"
 
 int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st);   // wgrad3x3.hip
+int crd_wgrad3x3_splits(const crd_wgrad_desc* d);
 
 namespace {
 
@@ -319,14 +320,23 @@ extern "C" int crd_conv_wgrad_grouped(const void* dev_table, const crd_wgrad_gro
   return CRD_OK;
 }
 
+static bool uses_stream3(const crd_wgrad_desc* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IH == d->OH && d->IW == d->OW && d->IW >= 32 &&
+         d->IH >= 8 && !getenv("CRD_NO_WGRAD3");
+}
+
+extern "C" int crd_conv_wgrad_splits(const crd_wgrad_desc* d) {
+  if (!d || !uses_stream3(d)) return 0;
+  return crd_wgrad3x3_splits(d);
+}
+
 extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
   WgK k;
   { int rc = fill(d, k); if (rc != CRD_OK) return rc; }
   hipStream_t st = as_stream(stream);
   // 3x3 / stride 1 / pad 1 on grids at least one 32-pixel strip wide: streaming halo-row kernel (wgrad3x3.hip)
-  if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IH == d->OH && d->IW == d->OW && d->IW >= 32 &&
-      d->IH >= 8 && !getenv("CRD_NO_WGRAD3"))
-    return crd_wgrad3x3_stream(d, st);
+  if (uses_stream3(d)) return crd_wgrad3x3_stream(d, st);
+  CRD_CHECK_ARG(d->dw_partials == nullptr, "crd_conv_wgrad: dw_partials is only supported where crd_conv_wgrad_splits() > 0");
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   if (d->Cout <= 32) return launch<1, 4, 2, 2>(k, st);
   if (d->Cout <= 64) return launch<1, 4, 4, 2>(k, st);

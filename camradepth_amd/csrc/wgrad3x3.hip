@@ -25,6 +25,7 @@ struct Wg3K {
   long long total_rows;                          // B * strips_x * H
   long long x_bytes, dy_bytes;
   float* dw; float* dbias;
+  float* dw_part;                                // per-row-split copies [gridDim.x][Cout][9][Cin] (plain stores) or nullptr -> atomics into dw
 };
 
 constexpr int XS = 6, YS = 4;                    // ring slots: input rows / dy rows
@@ -202,25 +203,38 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int co = (wco * TCO + i) * 16 + (l >> 4) * 4 + r;
-          if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + (long long)co * Ktot + tp * a.Cin + ci, acc[tp][i][j][r]);
+          if (co < a.Cout && ci < a.Cin) {
+            const long long off = (long long)co * Ktot + tp * a.Cin + ci;
+            // every (row split, chunk) workgroup owns its block of its split's copy: plain stores, the caller sums the
+            // copies (crd_wgrad_unpack); otherwise Cout x 9 x Cin atomics per row split (19 M per launch, ~0.1 ms)
+            if (a.dw_part) a.dw_part[(long long)blockIdx.x * a.Cout * Ktot + off] = acc[tp][i][j][r];
+            else atomicAdd(a.dw + off, acc[tp][i][j][r]);
+          }
         }
       }
   if (do_bias) atomicAdd(a.dbias + t, bsum);
 }
 
-template <int WCO, int WCI, int TCO>
-int launch_w3(const Wg3K& k0, hipStream_t st) {
-  Wg3K k = k0;
-  constexpr int COT = WCO * TCO * 16;
-  const size_t lds = (size_t)(XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
-  const int chunks = cdiv(k.Cin, XLD);
+// row splits (workgroups along x) and strip rows per workgroup
+int plan_rows(long long total_rows, int Cin, int& rows_per_wg) {
+  const int chunks = cdiv(Cin, XLD);
   // one workgroup per CU in total: every row split adds Cout x 9 x Cin fp32 atomics (37 M per launch at 512 workgroups,
   // ~0.2 ms at the ~170 G/s the L2s sustain), which a second workgroup per CU does not win back (30.0 vs 30.3 ms/step)
   int wgs = 256 / chunks;
   if (wgs < 1) wgs = 1;
-  if (wgs > k.total_rows / 8) wgs = (int)(k.total_rows / 8 > 0 ? k.total_rows / 8 : 1);
-  k.rows_per_wg = (int)((k.total_rows + wgs - 1) / wgs);
-  wgs = (int)((k.total_rows + k.rows_per_wg - 1) / k.rows_per_wg);
+  if (wgs > total_rows / 8) wgs = (int)(total_rows / 8 > 0 ? total_rows / 8 : 1);
+  rows_per_wg = (int)((total_rows + wgs - 1) / wgs);
+  return (int)((total_rows + rows_per_wg - 1) / rows_per_wg);
+}
+
+template <int WCO, int WCI, int TCO>
+int launch_w3(const Wg3K& k0, hipStream_t st, int partial_capacity) {
+  Wg3K k = k0;
+  constexpr int COT = WCO * TCO * 16;
+  const size_t lds = (size_t)(XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
+  const int chunks = cdiv(k.Cin, XLD);
+  const int wgs = plan_rows(k.total_rows, k.Cin, k.rows_per_wg);
+  if (wgs > partial_capacity) k.dw_part = nullptr;
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -245,7 +259,15 @@ int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st) {
   k.x_bytes = (long long)d->B * d->IH * d->IW * d->x_ld * 2;
   k.dy_bytes = (long long)d->B * d->IH * d->IW * d->dy_ld * 2;
   k.dw = d->dw; k.dbias = d->dbias;
-  if (d->Cout <= 32) return launch_w3<2, 4, 1>(k, st);
-  if (d->Cout <= 64) return launch_w3<2, 4, 2>(k, st);
-  return launch_w3<4, 2, 2>(k, st);
+  k.dw_part = d->dw_partials;
+  CRD_CHECK_ARG(d->dw_partials == nullptr || d->dw_partial_capacity >= plan_rows(k.total_rows, k.Cin, k.rows_per_wg),
+                "crd_conv_wgrad: dw_partials holds fewer copies than crd_conv_wgrad_splits() reports");
+  if (d->Cout <= 32) return launch_w3<2, 4, 1>(k, st, d->dw_partial_capacity);
+  if (d->Cout <= 64) return launch_w3<2, 4, 2>(k, st, d->dw_partial_capacity);
+  return launch_w3<4, 2, 2>(k, st, d->dw_partial_capacity);
+}
+
+int crd_wgrad3x3_splits(const crd_wgrad_desc* d) {
+  int rows = 0;
+  return plan_rows((long long)d->B * cdiv(d->IW, 32) * d->IH, d->Cin, rows);
 }

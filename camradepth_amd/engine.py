@@ -29,6 +29,7 @@ GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
 # graph than the short kernels it takes off the chain.
 SIDE_STREAMS = os.environ.get("CRD_SIDE_STREAMS") is not None
 SPLIT_N = os.environ.get("CRD_NO_SPLIT_N") is None      # developer switch for the ragged-tile split of 3x3 data gradients
+W3_PARTIALS = os.environ.get("CRD_NO_W3_PARTIALS") is None   # developer switch: streaming 3x3 wgrad with atomics instead
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
 HEAD_ROWS = 64        # same for Depth_Activation.conv_2 (2048 workgroups x 289 sums)
 
@@ -119,6 +120,7 @@ class ConvW:
         self.identity = (cmap is None and self.cin_pad == cin_ref and self.taps == 1)
         self.w_fwd = self.w_dgrad = self.w_scatter = None   # bf16 tensors
         self.dw = None                                        # fp32 [cout][taps][cin_pad] (scratch or direct grad view)
+        self.dw_parts, self.dw_S, self.stream3_geom = None, 0, None   # per-split copies of dw for the streaming 3x3 wgrad
         self.cmap_dev = None
 
 
@@ -255,6 +257,8 @@ class Plan:
         spec = dict(wg=True, x=x, dy=dy, cw=cw, k=k, stride=stride, pad=pad, OH=OH, OW=OW, dbias=dbias,
                     cin=cin if cin is not None else x.C)
         stream3 = k == 3 and stride == 1 and OW >= 32 and OH >= 8
+        if stream3:
+            cw.stream3_geom = (x.H, x.W, spec["cin"])
         kname = ("k_wgrad3x3<2,4,1>" if cw.cout <= 32 else "k_wgrad3x3<2,4,2>" if cw.cout <= 64 else "k_wgrad3x3<4,2,2>") if stream3 \
             else wgrad_tile(cw.cout)
         meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps,
@@ -300,6 +304,8 @@ class Plan:
             d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = P(dy), dy.ld, dy.coff, sp["OH"], sp["OW"], cw.cout
             d.KH, d.KW, d.stride, d.pad = sp["k"], sp["k"], sp["stride"], sp["pad"]
             d.dw, d.dbias = P(cw.dw), P(sp["dbias"])
+            if cw.dw_parts is not None:
+                d.dw_partials, d.dw_partial_capacity = cw.dw_parts.data_ptr(), cw.dw_S
         else:
             x, y, w = sp["x"], sp["y"], sp["w"]
             if isinstance(w, tuple):
@@ -792,8 +798,19 @@ class Plan:
             e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad, cw.cout_pad, 0
             entries.append(e)
             max_elems = max(max_elems, cw.cout * cw.taps * cw.cin_pad, cw.cin_pad * cw.taps * cw.cout_pad)
-            # weight-gradient destination: direct into the flat gradient for identity layouts, else scratch + unpack
-            if cw.identity:
+            # weight-gradient destination: direct into the flat gradient for identity layouts, else scratch + unpack.
+            # The streaming 3x3 kernel splits the pixels S ways; each split stores its block into its own copy (no
+            # atomics, nothing to zero) and the segment's unpack kernel sums the copies.
+            if cw.stream3_geom is not None and W3_PARTIALS:
+                probe = L.WgradDesc()
+                probe.B, probe.IH, probe.IW, probe.OH, probe.OW = self.B, cw.stream3_geom[0], cw.stream3_geom[1], cw.stream3_geom[0], cw.stream3_geom[1]
+                probe.Cin, probe.Cout, probe.KH, probe.KW, probe.stride, probe.pad = cw.stream3_geom[2], cw.cout, 3, 3, 1, 1
+                cw.dw_S = int(self.lib.crd_conv_wgrad_splits(C.byref(probe)))
+            if cw.dw_S > 0:
+                cw.dw_parts = self.new((cw.dw_S, cw.cout, cw.taps, cw.cin_pad), F32)
+                cw.dw = cw.dw_parts
+                unpack.append(cw)
+            elif cw.identity:
                 cw.dw = self.g(cw.name + ".weight")
             else:
                 cw.dw = self.zb(cw.cout, cw.taps, cw.cin_pad)
@@ -820,9 +837,12 @@ class Plan:
         for seg_i, cw, dwt in items:
             u = L.UnpackEntry()
             if cw is not None:
-                u.src, u.dst = cw.dw.t.data_ptr(), self.g(cw.name + ".weight").data_ptr()
+                u.src = cw.dw_parts.data_ptr() if cw.dw_parts is not None else cw.dw.t.data_ptr()
+                u.dst = self.g(cw.name + ".weight").data_ptr()
                 u.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
                 u.Cout, u.Cin_ref, u.taps, u.Cin_pad = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad
+                if cw.dw_parts is not None:
+                    u.replicas, u.replica_stride = cw.dw_S, cw.cout * cw.taps * cw.cin_pad
                 nel = cw.cout * cw.taps * cw.cin_pad
             else:
                 name, hid, dw10, _, which = dwt

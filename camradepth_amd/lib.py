@@ -39,7 +39,7 @@ class WgradDesc(C.Structure):
         ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_coff", C.c_int32),
         ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-        ("dw", C.c_void_p), ("dbias", C.c_void_p),
+        ("dw", C.c_void_p), ("dbias", C.c_void_p), ("dw_partials", C.c_void_p), ("dw_partial_capacity", C.c_int32),
     ]
 
 
@@ -92,7 +92,7 @@ def load():
 
 # Signatures of include/camradepth_hip.h (all return int status). p = pointer, i = int32, l = int64, f = float
 _SIGS = {
-    "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
+    "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiip",
     "crd_dwconv3x3": "piiiippipppippp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",

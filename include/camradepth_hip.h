@@ -84,9 +84,16 @@ typedef struct {
   int32_t KH, KW, stride, pad;
   float* dw;          /* fp32 [Cout][KH*KW][Cin] */
   float* dbias;       /* fp32 [Cout] or NULL */
+  float* dw_partials; /* optional, only where crd_conv_wgrad_splits(d) = S > 0 (the streaming 3x3 kernel): fp32
+                         [S][Cout][9][Cin], contents don't-care.  Every pixel-range split stores its weight-gradient
+                         block into its own copy with plain stores and dw is NOT touched: the gradient is the sum of the
+                         S copies (crd_wgrad_unpack, replicas = S).  NULL: the splits add into dw with fp32 atomics. */
+  int32_t dw_partial_capacity;   /* copies dw_partials can hold (>= S) */
 } crd_wgrad_desc;
 
 int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream);
+/* Number of pixel-range splits the 3x3 streaming kernel uses for this problem, 0 if the generic kernel handles it. */
+int crd_conv_wgrad_splits(const crd_wgrad_desc* d);
 
 /* Grouped weight gradients: the ~190 small wgrads of the encoder blocks (autograd's per-layer conv2d_backward weight
  * calls behind simplified_attention.py:32-43,95-132) are each too small to fill the chip, so the host collects them

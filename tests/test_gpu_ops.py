@@ -128,6 +128,20 @@ def test_conv_wgrad(case):
     assert_close(db.cpu(), bias.grad, f"dbias {case}", rel=2e-3, elem=4e-3)
     if Cp > Ci:
         assert float(dw[:, :, Ci:].abs().max()) == 0.0
+    # streaming 3x3 kernel: per-split copies (plain stores, contents don't-care on entry) summing to the same gradient
+    S = lb.crd_conv_wgrad_splits(C.byref(d))
+    assert (S > 0) == (k == 3 and s == 1 and W >= 32 and H >= 8)
+    if S > 0:
+        parts = torch.full((S + 1, Co, k * k, Cp), float("nan"), device="cuda")
+        dw2 = torch.full_like(dw, 7.0)
+        d.dw, d.dw_partials, d.dw_partial_capacity = P(dw2), P(parts), S + 1
+        db.zero_()
+        ok(lb.crd_conv_wgrad(C.byref(d), lib.stream()), "crd_conv_wgrad partials")
+        assert float((dw2 - 7.0).abs().max()) == 0.0            # dw untouched
+        assert bool(torch.isnan(parts[S]).all())                # copies beyond S untouched
+        got2 = parts[:S].sum(0).cpu()[:, :, :Ci].reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
+        assert_close(got2, w.grad, f"wgrad partials {case}", rel=2e-3, elem=4e-3)
+        assert_close(db.cpu(), bias.grad, f"dbias partials {case}", rel=2e-3, elem=4e-3)
 
 
 @pytest.mark.parametrize("C_,gmul,xf32,act", [(64, 1, 1, 0), (96, 1, 0, 1), (512, 8, 0, 1), (160, 1, 1, 0), (640, 4, 0, 1),

@@ -227,8 +227,16 @@ __global__ __launch_bounds__(TPB) void k_wgrad_unpack(const crd_unpack_entry* ta
     const int cr = e.cmap ? e.cmap[ci] : (ci < e.Cin_ref ? ci : -1);
     if (cr < 0) continue;
     float* d = e.dst + ((long long)co * e.Cin_ref + cr) * e.taps + tap;
-    float v = e.src[i];
-    for (int r = 1; r < e.replicas; ++r) v += e.src[(long long)r * e.replica_stride + i];
+    // copies of a replicated accumulator: four independent partial sums keep several loads in flight
+    float v = e.src[i], v1 = 0.f, v2 = 0.f, v3 = 0.f;
+    int rp = 1;
+    for (; rp + 3 <= e.replicas; rp += 3) {
+      v1 += e.src[(long long)rp * e.replica_stride + i];
+      v2 += e.src[(long long)(rp + 1) * e.replica_stride + i];
+      v3 += e.src[(long long)(rp + 2) * e.replica_stride + i];
+    }
+    for (; rp < e.replicas; ++rp) v += e.src[(long long)rp * e.replica_stride + i];
+    v += (v1 + v2) + v3;
     *d = accumulate ? *d + v : v;
   }
 }
@@ -349,7 +357,7 @@ extern "C" int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int64
 extern "C" int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int64_t max_elems, int32_t accumulate,
                                 crd_stream_t stream) {
   CRD_CHECK_ARG(table_dev && n > 0 && max_elems > 0, "crd_wgrad_unpack: bad argument");
-  hipLaunchKernelGGL(k_wgrad_unpack, dim3(blocks_for(max_elems, 256), n), dim3(TPB), 0, as_stream(stream), table_dev, accumulate);
+  hipLaunchKernelGGL(k_wgrad_unpack, dim3(blocks_for(max_elems, 2048), n), dim3(TPB), 0, as_stream(stream), table_dev, accumulate);
   CRD_LAUNCH_CHECK("crd_wgrad_unpack");
   return CRD_OK;
 }

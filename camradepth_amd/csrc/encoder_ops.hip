@@ -468,16 +468,25 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
 __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const bf16_t* k, const float* dS, const short* idx,
                                                          long long N, int M, int heads, int d, float scale, int chunk,
                                                          bf16_t* dq, float* dk, int use_lds, float* dk_part) {
-  extern __shared__ float sdk[];  // [M][C] when use_lds
+  // LDS (use_lds): the workgroup's pixel chunk -- q rows [chunk][CG] (16-byte granules), g = scale*dS [chunk], and a
+  // counting sort of the pixels by (head, arg-max key): count / offset / cursor [heads*M] ints, lists [heads][chunk] shorts
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
   const int C = heads * d, CG = C >> 3;
-  if (use_lds) {
-    for (int i = threadIdx.x; i < M * C; i += TPB) sdk[i] = 0.f;
-    __syncthreads();
-  }
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > N) p1 = N;
-  const long long total = (p1 - p0) * CG;
+  const int npx = (int)(p1 - p0);
+  const int HM = heads * M;
+  uint4* sq = reinterpret_cast<uint4*>(smem);                                  // [chunk][CG]
+  float* sg = reinterpret_cast<float*>(smem + (size_t)chunk * C * 2);          // [chunk]
+  int* cnt = reinterpret_cast<int*>(sg + chunk);                               // [HM] -> becomes the fill cursor
+  int* off = cnt + HM;                                                         // [HM + 1] exclusive offsets per head-major key
+  short* lst = reinterpret_cast<short*>(off + HM + 1);                         // [heads][chunk]
+  if (use_lds) {
+    for (int i = threadIdx.x; i < HM; i += TPB) cnt[i] = 0;
+    __syncthreads();
+  }
+  const long long total = (long long)npx * CG;
   // UB items per thread and pass: first the index / gradient scalars of all of them, then the dependent row gathers, so
   // that a pass costs two memory latencies instead of two per item
   constexpr int UB = 4;
@@ -495,41 +504,82 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
       mv[u] = idx[((long long)b * N + nv[u]) * heads + h];
       gv[u] = ok ? scale * dS[(long long)b * N + nv[u]] : 0.f;
     }
-    float kv[UB][8], qv[UB][8];
+    uint4 kraw[UB], qraw[UB];
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
-      load8(k, ((long long)b * M + mv[u]) * C + cgv[u] * 8, 0, kv[u]);
-      load8(q, ((long long)b * N + nv[u]) * C + cgv[u] * 8, 0, qv[u]);
+      kraw[u] = *reinterpret_cast<const uint4*>(k + ((long long)b * M + mv[u]) * C + cgv[u] * 8);
+      qraw[u] = *reinterpret_cast<const uint4*>(q + ((long long)b * N + nv[u]) * C + cgv[u] * 8);
     }
 #pragma unroll
     for (int u = 0; u < UB; ++u) {
       if (i0 + (long long)u * TPB >= total) continue;
+      float kv[8];
+      kv[0] = bf_lo(kraw[u].x); kv[1] = bf_hi(kraw[u].x); kv[2] = bf_lo(kraw[u].y); kv[3] = bf_hi(kraw[u].y);
+      kv[4] = bf_lo(kraw[u].z); kv[5] = bf_hi(kraw[u].z); kv[6] = bf_lo(kraw[u].w); kv[7] = bf_hi(kraw[u].w);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kv[u][j] *= gv[u];
-      store8_bf16(dq, ((long long)b * N + nv[u]) * C + cgv[u] * 8, kv[u]);
-      // two explicit branches: one pointer that may be LDS or global compiles to FLAT atomics.  (The LDS float atomics are
-      // still 20 of the 28 us of this kernel -- ds_add_f32 retires about one lane every few cycles; an owner-computes scan
-      // over the chunk's pixels instead measured slower, 27-69 us.)
+      for (int j = 0; j < 8; ++j) kv[j] *= gv[u];
+      store8_bf16(dq, ((long long)b * N + nv[u]) * C + cgv[u] * 8, kv);
       if (use_lds) {
-        float* dst = &sdk[mv[u] * C + cgv[u] * 8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[u][j]);
+        const int nl = (int)(nv[u] - p0);
+        sq[nl * CG + cgv[u]] = qraw[u];
+        const int h = (cgv[u] * 8) / d;
+        if (cgv[u] * 8 == h * d) atomicAdd(&cnt[h * M + mv[u]], 1);      // one count per (pixel, head): integer LDS atomic
+        if (cgv[u] == 0) sg[nl] = gv[u];
       } else {
+        float qv[8];
+        qv[0] = bf_lo(qraw[u].x); qv[1] = bf_hi(qraw[u].x); qv[2] = bf_lo(qraw[u].y); qv[3] = bf_hi(qraw[u].y);
+        qv[4] = bf_lo(qraw[u].z); qv[5] = bf_hi(qraw[u].z); qv[6] = bf_lo(qraw[u].w); qv[7] = bf_hi(qraw[u].w);
         float* dst = &dk[((long long)b * M + mv[u]) * C + cgv[u] * 8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[u][j]);
+        for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[j]);
       }
     }
   }
-  if (use_lds) {
-    __syncthreads();
-    if (dk_part) {   // this workgroup's whole accumulator, plain coalesced stores: [workgroup][b][M][C]; the caller sums them
-      float4* dst = reinterpret_cast<float4*>(dk_part + ((long long)blockIdx.x * gridDim.y + b) * M * C);
-      const float4* src = reinterpret_cast<const float4*>(sdk);
-      for (int i = threadIdx.x; i < (M * C) >> 2; i += TPB) dst[i] = src[i];
+  if (!use_lds) return;
+  // dK of the chunk without float atomics (32 ds_add_f32 per thread were 20 of this kernel's 28 us: LDS fp32 atomics
+  // retire about one lane every few cycles): counting-sort the chunk's pixels by (head, key), then the thread that owns
+  // (key m, granule cg) adds up the q rows of the pixels routed to m.
+  __syncthreads();
+  if ((int)threadIdx.x < heads) {                    // exclusive offsets, one head per thread (M ~ 100 serial adds)
+    int run = threadIdx.x * chunk;                   // head h's list occupies lst[h*chunk ...]
+    for (int m = 0; m < M; ++m) {
+      const int c = cnt[threadIdx.x * M + m];
+      off[threadIdx.x * M + m] = run;
+      cnt[threadIdx.x * M + m] = run;                // fill cursor
+      run += c;
+    }
+  }
+  if (threadIdx.x == 0) off[HM] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < npx * heads; i += TPB) {
+    const int nl = i / heads, h = i - nl * heads;
+    const int m = idx[((long long)b * N + p0 + nl) * heads + h];
+    const int pos = atomicAdd(&cnt[h * M + m], 1);
+    lst[pos] = (short)nl;
+  }
+  __syncthreads();
+  float* outp = dk_part ? dk_part + ((long long)blockIdx.x * gridDim.y + b) * M * C : nullptr;
+  for (int pr = threadIdx.x; pr < M * CG; pr += TPB) {
+    const int m = pr / CG, cg = pr - m * CG;
+    const int h = (cg * 8) / d;
+    const int beg = off[h * M + m], end = cnt[h * M + m];     // the cursor stopped at the end of the key's list
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int p = beg; p < end; ++p) {
+      const int n = lst[p];
+      const uint4 u = sq[n * CG + cg];
+      const float g = sg[n];
+      acc[0] += g * bf_lo(u.x); acc[1] += g * bf_hi(u.x); acc[2] += g * bf_lo(u.y); acc[3] += g * bf_hi(u.y);
+      acc[4] += g * bf_lo(u.z); acc[5] += g * bf_hi(u.z); acc[6] += g * bf_lo(u.w); acc[7] += g * bf_hi(u.w);
+    }
+    if (outp) {
+      store8_f32(outp, (long long)m * C + cg * 8, acc);
     } else {
-      for (int i = threadIdx.x; i < M * C; i += TPB)
-        if (sdk[i] != 0.f) atomicAdd(&dk[(long long)b * M * C + i], sdk[i]);
+      float* dst = &dk[((long long)b * M + m) * C + cg * 8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (acc[j] != 0.f) atomicAdd(dst + j, acc[j]);
     }
   }
 }
@@ -663,18 +713,22 @@ extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S
   return CRD_OK;
 }
 
-// workgroups per sample of the LDS path (0: [M][C] fp32 does not fit in LDS, the atomics path runs)
-static int attn_bwd_blocks(int B, int N, int M, int C) {
-  if ((size_t)M * C * sizeof(float) > 128 * 1024) return 0;
+// LDS of the chunked path: q rows + g + (count, offset) tables + per-head pixel lists of a `chunk`-pixel chunk
+static size_t attn_bwd_lds(int chunk, int M, int heads, int C) {
+  return (size_t)chunk * C * 2 + (size_t)chunk * 4 + (size_t)(2 * heads * M + 1) * 4 + (size_t)heads * chunk * 2 + 16;
+}
+// workgroups per sample of the chunked (LDS) path; 0: a chunk does not fit in LDS, the global-atomics path runs
+static int attn_bwd_blocks(int B, int N, int M, int heads, int C) {
   int nblk = cdiv(N, 128);
   int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   const int chunk = cdiv(N, nblk);
+  if (attn_bwd_lds(chunk, M, heads, C) > 128 * 1024 || chunk > 32767) return 0;
   return cdiv(N, chunk);
 }
 
 extern "C" int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d) {
-  return attn_bwd_blocks(B, N, M, heads * d);
+  return attn_bwd_blocks(B, N, M, heads, heads * d);
 }
 
 extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
@@ -683,10 +737,9 @@ extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS
   CRD_CHECK_ARG(q && k && dS && idx && dq && (dk || dk_partials), "crd_attn_scores_bwd: null pointer");
   CRD_CHECK_ARG(d % 8 == 0, "crd_attn_scores_bwd: head dim must be a multiple of 8");
   const int C = heads * d;
-  const size_t lds = (size_t)M * C * sizeof(float);
-  // dK accumulates in LDS whenever [M][C] fp32 fits (stage 3: 66.5 KB, stage 4: 106 KB); the fallback adds every
-  // contribution to global memory with an atomic of its own and was 50 us per launch on stage 3
-  int nblk = attn_bwd_blocks(B, N, M, C);
+  // the chunked path (q rows of <= 128 pixels staged in LDS, counting sort by key, owner-computes dK) runs whenever the
+  // chunk fits; the fallback adds every contribution to global memory with an atomic of its own
+  int nblk = attn_bwd_blocks(B, N, M, heads, C);
   const int use_lds = nblk > 0;
   CRD_CHECK_ARG(use_lds ? (dk_partials || dk) : dk != nullptr, "crd_attn_scores_bwd: this shape needs the dk accumulator");
   static bool attr_done = false;
@@ -701,6 +754,7 @@ extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS
   }
   int chunk = cdiv(N, nblk);
   nblk = cdiv(N, chunk);
+  const size_t lds = attn_bwd_lds(chunk, M, heads, C);
   hipLaunchKernelGGL(k_attn_scores_bwd, dim3(nblk, B), dim3(TPB), use_lds ? lds : 0, as_stream(stream),
                      reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), dS, reinterpret_cast<const short*>(idx),
                      (long long)N, M, heads, d, scale, chunk, reinterpret_cast<bf16_t*>(dq), dk, use_lds,

@@ -351,7 +351,7 @@ def test_attention_output_path():
     assert_close(xbar.float().cpu(), xn.mean(2), "xbar", rel=4e-3, elem=1e-2)
 
 
-@pytest.mark.parametrize("H,W,C_", [(5, 7, 16), (8, 13, 136), (3, 4, 8), (16, 26, 128)])
+@pytest.mark.parametrize("H,W,C_", [(5, 7, 16), (8, 13, 136), (3, 4, 8), (16, 26, 128), (9, 16, 40), (19, 37, 72)])
 def test_bicubic(H, W, C_):
     lib, lb = L()
     g = torch.Generator().manual_seed(8)

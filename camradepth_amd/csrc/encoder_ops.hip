@@ -48,9 +48,21 @@ __device__ __forceinline__ uint4 innorm_apply(const uint4& u, const float (&a)[8
   return r;
 }
 
+// Optional first phase of the backward of a GroupNorm (gmul = 1, no activation) that FOLLOWS in the backward chain,
+// fused into the producer of its dy: with y = this kernel's (rounded) output as dy and xr the GroupNorm's raw input,
+// r[b][c] += (sum y, sum y*xhat) and rg[b][c/16] += sum_c gamma_c * r (crd_gn_bwd_reduce's outputs), so that only
+// crd_gn_bwd_apply remains.  Mlp.norm1's backward receives d(H1N) from the depthwise data gradient: this saves one pass
+// over (H1, d(H1N)) per block.
+struct RedOut {
+  const bf16_t* xr;       // raw input of the GroupNorm [B][H][W][C], or nullptr: no reduce
+  const float* stats;     // its g16 sums
+  const float* gamma;
+  float* r;               // [B][C][2] then [B][C/16][2]
+};
+
 template <bool FLIP, bool STATS, int TW>
 __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, int C, const float* w9, const float* bias,
-                                                bf16_t* y, float* stats, int tiles_x, InNorm inn) {
+                                                bf16_t* y, float* stats, int tiles_x, InNorm inn, RedOut red) {
   constexpr int HWD = TW + 2;                       // halo width
   constexpr int HPX = (DTH + 2) * HWD;              // halo pixels
   constexpr int RSPLIT = 32 / TW;                   // row groups of the thread mapping (TW = 16: rows 0-3 / 4-7)
@@ -115,6 +127,10 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) lds8(r0 + ky, xc + kx, win[ky][kx]);
   float s = 0.f, ss = 0.f;
+  float rs0[8], rs1[8], rmean = 0.f, rrstd = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) rs0[j] = rs1[j] = 0.f;
+  if (red.xr && gok) gn_mean_rstd(red.stats + (long long)b * (C >> 4) * 2, c0 >> 4, 1, 1.f / ((float)H * W * 16.f), rmean, rrstd);
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
 #pragma unroll
@@ -134,6 +150,13 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
       uint4 u;
       u.x = pack_bf2(acc[0], acc[1]); u.y = pack_bf2(acc[2], acc[3]); u.z = pack_bf2(acc[4], acc[5]); u.w = pack_bf2(acc[6], acc[7]);
       *reinterpret_cast<uint4*>(yb + ((long long)oy * W + ox) * C + c0) = u;
+      if (red.xr) {
+        const uint4 xv = *reinterpret_cast<const uint4*>(red.xr + (((long long)b * H + oy) * W + ox) * C + c0);
+        const float gq[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+        const float xq[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rs0[j] += gq[j]; rs1[j] += gq[j] * ((xq[j] - rmean) * rrstd); }
+      }
       if (STATS) {
         s += bf_lo(u.x) + bf_hi(u.x) + bf_lo(u.y) + bf_hi(u.y) + bf_lo(u.z) + bf_hi(u.z) + bf_lo(u.w) + bf_hi(u.w);
         ss += bf_lo(u.x) * bf_lo(u.x) + bf_hi(u.x) * bf_hi(u.x) + bf_lo(u.y) * bf_lo(u.y) + bf_hi(u.y) * bf_hi(u.y) +
@@ -153,6 +176,37 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
       const float v = sred[0][t] + sred[1][t] + sred[2][t] + sred[3][t];
       const int slab = (c_win >> 4) + (t >> 1);
       if (slab < (C >> 4)) atomicAdd(&stats[((long long)b * (C >> 4) + slab) * 2 + (t & 1)], v);
+    }
+  }
+  if (red.xr) {
+    // fold the 8 columns of the wave, then the 4 waves through LDS (the halo image is no longer needed): [wave][128]
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { rs0[j] += __shfl_xor(rs0[j], o); rs1[j] += __shfl_xor(rs1[j], o); }
+    }
+    __syncthreads();
+    float* fr = reinterpret_cast<float*>(sh);
+    const int wave = t >> 6, l = t & 63;
+    if (l < 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { fr[wave * 128 + (l * 8 + j) * 2] = rs0[j]; fr[wave * 128 + (l * 8 + j) * 2 + 1] = rs1[j]; }
+    }
+    __syncthreads();
+    const int nch = nG * 8;
+    if (t < 2 * nch) {                         // (channel, moment) of this window
+      const float v = fr[t] + fr[128 + t] + fr[256 + t] + fr[384 + t];
+      const int c = c_win + (t >> 1);
+      atomicAdd(&red.r[((long long)b * C + c) * 2 + (t & 1)], v);
+      fr[512 + t] = v * red.gamma[c];
+    }
+    __syncthreads();
+    if (t < 2 * (nch >> 4)) {                  // gamma-weighted sums of the 16-channel groups
+      const int grp = t >> 1, which = t & 1;
+      float a = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) a += fr[512 + (grp * 16 + j) * 2 + which];
+      atomicAdd(&red.r[(long long)gridDim.z * C * 2 + ((long long)b * (C >> 4) + (c_win >> 4) + grp) * 2 + which], a);
     }
   }
 }
@@ -603,8 +657,11 @@ __global__ __launch_bounds__(TPB) void k_sum_partials_bf16(const float* part, in
 
 extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
                              int32_t flip, void* y, float* stats, const float* in_stats, int32_t in_gmul,
-                             const float* in_gamma, const float* in_beta, crd_stream_t stream) {
+                             const float* in_gamma, const float* in_beta, const void* red_x, const float* red_stats,
+                             const float* red_gamma, float* red_r, crd_stream_t stream) {
   CRD_CHECK_ARG(x && w9 && y, "crd_dwconv3x3: null pointer");
+  CRD_CHECK_ARG(!red_x || (red_stats && red_gamma && red_r), "crd_dwconv3x3: incomplete fused-reduce arguments");
+  const RedOut red{reinterpret_cast<const bf16_t*>(red_x), red_stats, red_gamma, red_r};
   CRD_CHECK_ARG(!in_stats || (in_gamma && in_beta && in_gmul >= 1 && (C / 16) % in_gmul == 0), "crd_dwconv3x3: bad input-norm arguments");
   const InNorm inn{in_stats, in_gamma, in_beta, in_gmul};
   CRD_CHECK_ARG(C % 16 == 0, "crd_dwconv3x3: C must be a multiple of 16");
@@ -615,7 +672,7 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
   const int tw = (cdiv(W, 16) * 16 < cdiv(W, 32) * 32) ? 16 : 32;
   const int tiles_x = cdiv(W, tw), tiles_y = cdiv(H, DTH);
   dim3 grid(tiles_x * tiles_y, cdiv(C, DCW), B);
-#define CRD_DW(FL, STT, TWV) hipLaunchKernelGGL((k_dwconv<FL, STT, TWV>), grid, dim3(TPB), 0, st, xp, H, W, C, w9, bias, yp, stats, tiles_x, inn)
+#define CRD_DW(FL, STT, TWV) hipLaunchKernelGGL((k_dwconv<FL, STT, TWV>), grid, dim3(TPB), 0, st, xp, H, W, C, w9, bias, yp, stats, tiles_x, inn, red)
   if (tw == 32) {
     if (flip) { if (stats) CRD_DW(true, true, 32); else CRD_DW(true, false, 32); }
     else { if (stats) CRD_DW(false, true, 32); else CRD_DW(false, false, 32); }

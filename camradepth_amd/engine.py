@@ -360,11 +360,13 @@ class Plan:
         self._emit(self.fwd, "crd_gn_stats", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, chan])
         self.gn_fwd(x, stats, gmul, gname, act, mask, y)
 
-    def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0):
+    def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0, r=None):
+        """r given: the reduce phase was fused into the kernel that produced dy (only the apply phase is emitted)."""
         common = [x.t, x.f32, x.ld, x.coff, dy.t, dy.f32, dy.ld, dy.coff, self.B, x.P, x.C, stats, gmul,
                   self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask]
-        r = self.zb(self.B * x.C * 2 + self.B * (x.C // (16 * gmul)) * 2)
-        self._emit(grp, "crd_gn_bwd_reduce", common + [r, None, 0])
+        if r is None:
+            r = self.zb(self.B * x.C * 2 + self.B * (x.C // (16 * gmul)) * 2)
+            self._emit(grp, "crd_gn_bwd_reduce", common + [r, None, 0])
         args = common + [r, self.g(gname + ".weight"), self.g(gname + ".bias"), dx.t, dx.f32, dx.ld, dx.coff, dx_acc]
         self._emit(grp, "crd_gn_bwd_apply", args, region, len(args) - 1 if region else None)
 
@@ -688,7 +690,7 @@ class Plan:
         n1 = [sth1, 1, self.p(ml + ".norm1.weight"), self.p(ml + ".norm1.bias")]
         w9 = self.new((9, hid), F32)
         self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9))
-        self._emit(F_, "crd_dwconv3x3", [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1)
+        self._emit(F_, "crd_dwconv3x3", [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1 + [None, None, None, None])
         self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
         X2 = self.act(Cs, Hs, Ws, F32)
         self.conv(F_, self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp))
@@ -707,8 +709,11 @@ class Plan:
         self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
         with self.side(1):       # off the chain: nothing below reads dw10 before the segment's unpack
             self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
-        self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None])  # d(H1N)
-        self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2)                    # in place: d(H1)
+        # d(H1N), with the reduce phase of Mlp.norm1's backward fused in (it needs exactly this output and H1)
+        r1 = self.zb(B * hid * 2 + B * (hid // 16) * 2)
+        self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None,
+                                        H1.t, sth1, self.p(ml + ".norm1.weight"), r1])
+        self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2, r=r1)             # in place: d(H1)
         self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc1.bias"))
         self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1))
         self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1)              # DX = d(X1)

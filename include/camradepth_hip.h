@@ -154,7 +154,12 @@ int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff,
  * ------------------------------------------------------------------------------------------- */
 int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
                   int32_t flip, void* y, float* stats, const float* in_stats, int32_t in_gmul, const float* in_gamma,
-                  const float* in_beta, crd_stream_t stream);
+                  const float* in_beta, const void* red_x, const float* red_stats, const float* red_gamma, float* red_r,
+                  crd_stream_t stream);
+/* red_x != NULL: the first phase of the backward of the GroupNorm (gmul = 1, no activation) whose dy this call produces
+ * is fused in -- red_x is that GroupNorm's raw input (bf16 [B][H][W][C]), red_stats its g16 sums, red_gamma its weight,
+ * red_r the buffer crd_gn_bwd_reduce would fill (float [B*C*2 + B*(C/16)*2], zeroed by the caller); only
+ * crd_gn_bwd_apply remains to be called (Mlp.norm1's backward after the depthwise data gradient). */
 /* in_stats != NULL (both functions): the input is GroupNorm-ed on load -- xn = bf16((x-mean)*rstd*gamma+beta) with the g16
  * sums in_stats[B][C/16][2] of x and groups of in_gmul slabs, zero padding applied after the normalisation -- i.e.
  * crd_gn_apply (Mlp.norm1, simplified_attention.py:37-38) fused into the consumer; the normalised tensor is never stored. */

@@ -220,14 +220,14 @@ def test_dwconv(C_, H, W):
     y = torch.zeros(B, H, W, C_, dtype=torch.bfloat16, device="cuda")
     stats = torch.zeros(B, C_ // 16, 2, device="cuda")
     bc = b.detach().cuda()
-    ok(lb.crd_dwconv3x3(P(xd), B, H, W, C_, P(w9), P(bc), 0, P(y), P(stats), None, 1, None, None, lib.stream()), "dwconv")
+    ok(lb.crd_dwconv3x3(P(xd), B, H, W, C_, P(w9), P(bc), 0, P(y), P(stats), None, 1, None, None, None, None, None, None, lib.stream()), "dwconv")
     got = y.float().cpu().permute(0, 3, 1, 2)
     assert_close(got, yref.detach(), "dwconv")
     gq = got.reshape(B, C_ // 16, 16, H * W)
     assert_close(stats.cpu(), torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1), "dwconv stats", rel=1e-3, elem=2e-3)
     dyd = to_pm(dy)
     dx = torch.zeros_like(y)
-    ok(lb.crd_dwconv3x3(P(dyd), B, H, W, C_, P(w9), None, 1, P(dx), None, None, 1, None, None, lib.stream()), "dwconv dgrad")
+    ok(lb.crd_dwconv3x3(P(dyd), B, H, W, C_, P(w9), None, 1, P(dx), None, None, 1, None, None, None, None, None, None, lib.stream()), "dwconv dgrad")
     assert_close(dx.float().cpu().permute(0, 3, 1, 2), xr.grad, "dwconv dx")
     for R in (1, 5):       # accumulator copies the workgroups spread their atomics over; the gradient is their sum
         dw10 = torch.zeros(R, 10, C_, device="cuda")
@@ -259,13 +259,26 @@ def test_dwconv_with_fused_input_groupnorm(C_, H, W, gmul):
     for src, nrm in ((xn, (None, 1, None, None)), (xd, (P(st_in), gmul, P(gam), P(bet)))):
         y = torch.zeros(B, H, W, C_, dtype=torch.bfloat16, device="cuda")
         st = torch.zeros(B, C_ // 16, 2, device="cuda")
-        ok(lb.crd_dwconv3x3(P(src), B, H, W, C_, P(w9), P(bc), 0, P(y), P(st), *nrm, lib.stream()), "dwconv")
+        ok(lb.crd_dwconv3x3(P(src), B, H, W, C_, P(w9), P(bc), 0, P(y), P(st), *nrm, None, None, None, None, lib.stream()), "dwconv")
         dw10 = torch.zeros(1, 10, C_, device="cuda")
         ok(lb.crd_dwconv3x3_wgrad(P(src), P(dyd), B, H, W, C_, P(dw10), 1, *nrm, lib.stream()), "dwconv wgrad")
         outs.append((y.float().cpu(), st.cpu(), dw10.cpu()))
     assert torch.equal(outs[0][0], outs[1][0]), "fused input norm changes the forward result"
     assert_close(outs[1][1], outs[0][1], "stats", rel=1e-5, elem=1e-5)
     assert_close(outs[1][2], outs[0][2], "dw10", rel=1e-5, elem=1e-5)
+    # data gradient with the reduce phase of the following GroupNorm backward fused in == plain kernel + crd_gn_bwd_reduce
+    G = C_ // 16
+    dxa = torch.zeros(B, H, W, C_, dtype=torch.bfloat16, device="cuda")
+    ok(lb.crd_dwconv3x3(P(dyd), B, H, W, C_, P(w9), None, 1, P(dxa), None, None, 1, None, None, None, None, None, None, lib.stream()), "dgrad")
+    r_ref = torch.zeros(B * C_ * 2 + B * G * 2, device="cuda")
+    ok(lb.crd_gn_bwd_reduce(P(xd), 0, C_, 0, P(dxa), 0, C_, 0, B, H * W, C_, P(st_in), 1, P(gam), P(bet), 0, None, P(r_ref), None, 0,
+                            lib.stream()), "gn_bwd_reduce")
+    dxb = torch.zeros_like(dxa)
+    r_fused = torch.zeros_like(r_ref)
+    ok(lb.crd_dwconv3x3(P(dyd), B, H, W, C_, P(w9), None, 1, P(dxb), None, None, 1, None, None, P(xd), P(st_in), P(gam), P(r_fused),
+                        lib.stream()), "dgrad + fused reduce")
+    assert torch.equal(dxa, dxb)
+    assert_close(r_fused.cpu(), r_ref.cpu(), "fused gn-bwd reduce", rel=2e-4, elem=2e-4)
 
 
 @pytest.mark.parametrize("N,M,heads,d", [(200, 104, 1, 64), (130, 104, 2, 64), (70, 35, 4, 40), (104, 104, 8, 32)])

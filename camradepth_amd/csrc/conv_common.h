@@ -15,6 +15,11 @@ struct ConvK {
   int accumulate; float* stats; int G16;
   float* stats_partial; int n_tiles;   // per-tile partial sums [B][n_tiles][G16][2] (plain stores) or nullptr -> atomics
   int vec_ok;   // y base/offset 16-byte aligned: the vectorised epilogue may be used
+  // Optional: reduce phase of the backward of the GroupNorm (+GELU) whose dy this launch produces (vector path only).
+  // red_x = that GroupNorm's raw bf16 input [pixels][red_x_ld], batch stride red_x_bstride; r as in crd_gn_bwd_reduce.
+  const bf16_t* red_x; int red_x_ld; long long red_x_bstride;
+  const float* red_stats; const float* red_gamma; const float* red_beta; int red_gmul, red_act;
+  float* red_r;
   int dbg;   // developer experiments only (CRD_DBG env): 1 no weight-DMA wait, 2 no DMA at all, 4 no epilogue
 };
 
@@ -69,6 +74,21 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
     __syncthreads();
     bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
     constexpr int GPR = BN / 8;
+    // fused GroupNorm-backward reduce: a thread keeps the same 8 columns for all its rows (NT % GPR == 0)
+    const bool redo = (NT % GPR == 0) && a.red_x != nullptr;
+    float rs0[8], rs1[8], rga[8], rbe[8], rmean = 0.f, rrstd = 0.f;
+    const int rcol = n0 + (threadIdx.x % GPR) * 8;
+    if (redo) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { rs0[j] = rs1[j] = 0.f; rga[j] = 1.f; rbe[j] = 0.f; }
+      if (rcol < a.Cout) {
+        const int cpg = 16 * a.red_gmul;
+        gn_mean_rstd(a.red_stats + (long long)b * (a.Cout >> 4) * 2, (rcol / cpg) * a.red_gmul, a.red_gmul,
+                     1.f / ((float)a.OHW * cpg), rmean, rrstd);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { rga[j] = a.red_gamma[rcol + j]; rbe[j] = a.red_beta[rcol + j]; }
+      }
+    }
     for (int idx = threadIdx.x; idx < BM * GPR; idx += NT) {
       const int rl = idx / GPR, g = idx - rl * GPR;
       bool valid;
@@ -86,6 +106,51 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
           u.w = pack_bf2(bf_lo(u.w) + bf_lo(o.w), bf_hi(u.w) + bf_hi(o.w));
         }
         *reinterpret_cast<uint4*>(dst) = u;
+        if (redo) {
+          const uint4 xv = *reinterpret_cast<const uint4*>(a.red_x + (long long)b * a.red_x_bstride + (long long)p * a.red_x_ld + col);
+          const float dq[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
+          const float xq[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (xq[j] - rmean) * rrstd;
+            float gg = dq[j];
+            if (a.red_act == 1) gg *= gelu_grad(xh * rga[j] + rbe[j]);
+            rs0[j] += gg; rs1[j] += gg * xh;
+          }
+        }
+      }
+    }
+    if (redo) {
+      // threads t, t + GPR, ... share a column group: fold them through LDS (the staging tile is free again)
+      __syncthreads();
+      float* fr = reinterpret_cast<float*>(smem);            // [NT][16], then [GPR*16] gamma-weighted
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { fr[threadIdx.x * 16 + j * 2] = rs0[j]; fr[threadIdx.x * 16 + j * 2 + 1] = rs1[j]; }
+      __syncthreads();
+      float* fw = fr + NT * 16;
+      if ((int)threadIdx.x < GPR * 16) {
+        const int g = threadIdx.x >> 4, jk = threadIdx.x & 15;
+        float v = 0.f;
+        for (int m = 0; m < NT / GPR; ++m) v += fr[(g + m * GPR) * 16 + jk];
+        const int c = n0 + g * 8 + (jk >> 1);
+        float wv = 0.f;
+        if (c < a.Cout) {
+          atomicAdd(&a.red_r[((long long)b * a.Cout + c) * 2 + (jk & 1)], v);
+          wv = v * a.red_gamma[c];
+        }
+        fw[threadIdx.x] = wv;
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < (BN / 16) * 2) {                   // gamma-weighted sums of the tile's 16-channel slabs
+        const int slab = threadIdx.x >> 1, which = threadIdx.x & 1;
+        const int c0s = n0 + slab * 16;
+        if (c0s < a.Cout) {
+          float s2 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) s2 += fw[(slab * 16 + j) * 2 + which];
+          const int cpg = 16 * a.red_gmul;
+          atomicAdd(&a.red_r[(long long)gridDim.z * a.Cout * 2 + ((long long)b * (a.Cout / cpg) + c0s / cpg) * 2 + which], s2);
+        }
       }
     }
   } else {
@@ -172,6 +237,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
 __device__ __forceinline__ void conv_epilogue_idle(const ConvK& a) {
   const bool vec = a.out_mode == 0 && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
   if (vec) __syncthreads();
+  if (vec && a.red_x) { __syncthreads(); __syncthreads(); __syncthreads(); }
   if (a.stats) __syncthreads();
 }
 

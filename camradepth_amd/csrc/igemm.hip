@@ -270,9 +270,20 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   k.accumulate = d->accumulate; k.stats = d->stats; k.G16 = d->Cout / 16;
   k.stats_partial = d->stats ? d->stats_partial : nullptr; k.n_tiles = 0;
   k.vec_ok = (d->y_coff % 8 == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0);
+  k.red_x = reinterpret_cast<const bf16_t*>(d->red_x); k.red_x_ld = d->red_x_ld;
+  k.red_x_bstride = (long long)YH * YW * d->red_x_ld;
+  k.red_stats = d->red_stats; k.red_gamma = d->red_gamma; k.red_beta = d->red_beta; k.red_gmul = d->red_gmul;
+  k.red_act = d->red_act; k.red_r = d->red_r;
   const long long pcap = d->stats_partial ? d->stats_partial_capacity : 0;
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   hipStream_t st = as_stream(stream);
+  if (d->red_x) {
+    const bool halo_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IW >= 32 && d->IH >= 8;
+    CRD_CHECK_ARG(d->red_stats && d->red_gamma && d->red_beta && d->red_r && d->red_gmul >= 1 && d->red_x_ld % 8 == 0 &&
+                  (d->Cout / 16) % d->red_gmul == 0, "crd_conv_igemm: incomplete fused-reduce arguments");
+    CRD_UNSUPPORTED(d->Cout > 160 && d->Cout % 16 == 0 && !halo_shape && d->out_mode == 0 && !d->y_f32 && !d->res && d->y_ld % 8 == 0 &&
+                    k.vec_ok, "crd_conv_igemm: the fused GroupNorm-backward reduce needs a bf16 vector-path output with Cout > 160");
+  }
   // 3x3 / stride 1 / pad 1 on grids at least one tile wide: halo-tile kernel (conv3x3.hip)
   if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == 0 && d->IH == d->OH && d->IW == d->OW &&
       d->IW >= 32 && d->IH >= 8)

@@ -28,6 +28,11 @@ GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
 # only on request: measured 27.7-28.9 ms/step against 26.7 on one stream -- every fork / join costs more in the captured
 # graph than the short kernels it takes off the chain.
 SIDE_STREAMS = os.environ.get("CRD_SIDE_STREAMS") is not None
+# GroupNorm-backward reduce of Mlp.norm2 inside the fc2 data-gradient epilogue (crd_conv_desc.red_*): opt-in.  It removes
+# a pass over (H2, d(H3)) per block but measured 26.6 vs 26.4 ms/step: the GELU' + fold + atomics in the GEMM epilogue
+# cost more than the streaming reduce kernel they replace.  (The same fusion into the depthwise data gradient, for
+# Mlp.norm1 without activation, does pay and is always on.)
+FUSE_GN_RED = os.environ.get("CRD_FUSE_GN_RED") is not None
 SPLIT_N = os.environ.get("CRD_NO_SPLIT_N") is None      # developer switch for the ragged-tile split of 3x3 data gradients
 W3_PARTIALS = os.environ.get("CRD_NO_W3_PARTIALS") is None   # developer switch: streaming 3x3 wgrad with atomics instead
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
@@ -215,11 +220,11 @@ class Plan:
         self.bwd_tags.append(self._tag)
 
     def conv_desc(self, x, w_t, cout, k, stride, pad, OH, OW, y, cin=None, gather=0, out_mode=0, patch_k=0, patch_c=0,
-                  bias=None, bias_bstride=0, act=0, res=None, res_scale=None, stats=None, accumulate=0):
+                  bias=None, bias_bstride=0, act=0, res=None, res_scale=None, stats=None, accumulate=0, red=None):
         """Specification of one crd_conv_igemm call; turned into a ctypes ConvDesc in _finalise."""
         return dict(x=x, w=w_t, cout=cout, k=k, stride=stride, pad=pad, OH=OH, OW=OW, y=y, cin=cin if cin is not None else x.C,
                     gather=gather, out_mode=out_mode, patch_k=patch_k, patch_c=patch_c, bias=bias, bias_bstride=bias_bstride,
-                    act=act, res=res, res_scale=res_scale, stats=stats, accumulate=accumulate)
+                    act=act, res=res, res_scale=res_scale, stats=stats, accumulate=accumulate, red=red)
 
     def conv(self, lst, spec, region=None):
         w, x = spec["w"], spec["x"]
@@ -325,6 +330,11 @@ class Plan:
             res = sp["res"]
             d.res, d.res_ld, d.res_scale = P(res), (res.ld if res is not None else 0), P(sp["res_scale"])
             d.accumulate, d.stats = sp["accumulate"], P(sp["stats"])
+            if sp.get("red") is not None:        # fused reduce phase of the GroupNorm backward this output feeds
+                rx, rstats, rgamma, rbeta, rgmul, ract, rr = sp["red"]
+                assert rx.coff == 0, "the fused reduce reads the GroupNorm input from channel 0"
+                d.red_x, d.red_x_ld, d.red_gmul, d.red_act = P(rx), rx.ld, rgmul, ract
+                d.red_stats, d.red_gamma, d.red_beta, d.red_r = P(rstats), P(rgamma), P(rbeta), P(rr)
             # stats_partial stays NULL: workgroup-level sums go in with one fp32 atomic each.  The library's deterministic
             # partial-store + finalize path measured the same step time (34.6 vs 34.9 ms) and costs 261 more dispatches.
         self.keep.append(d)
@@ -703,8 +713,11 @@ class Plan:
             DH, DHID2, DQ = self.act(Cs, Hs, Ws), self.act(hid, Hs, Ws), self.act(Cs, Hs, Ws)
         self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
         self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc2.bias"))
-        self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1))
-        self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID)                 # in place: d(H2)
+        # fc2's data gradient also runs the reduce phase of Mlp.norm2's backward on its own output (FUSE_GN_RED)
+        r2 = self.zb(B * hid * 2 + B * (hid // (16 * ratio)) * 2) if FUSE_GN_RED and hid > 160 else None
+        red = None if r2 is None else (H2, sth2, self.p(ml + ".norm2.weight"), self.p(ml + ".norm2.bias"), ratio, 1, r2)
+        self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1, red=red))
+        self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID, r=r2)           # in place: d(H2)
         dw10 = self.zb(DW_REPLICAS, 10, hid)      # [copy][9 taps + bias][channel]; the unpack kernel sums the copies
         self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
         with self.side(1):       # off the chain: nothing below reads dw10 before the segment's unpack

@@ -71,6 +71,18 @@ typedef struct {
   float* stats_partial;           /* optional scratch: per-tile partial sums are written here with plain stores and
                                      folded into `stats` by a small second kernel (avoids contended atomics) */
   int64_t stats_partial_capacity; /* floats available in stats_partial; needs B*ceil(OH*OW/64)*(Cout/16)*2 */
+  /* Optional (red_x != NULL; bf16 output, no residual, Cout > 160, not the 3x3 halo shapes): this launch produces the dy
+   * of a GroupNorm (+GELU) backward -- e.g. the data gradient of Mlp.fc2 feeding Mlp.norm2 -- and also computes that
+   * backward's reduce phase: red_x is the GroupNorm's raw bf16 input laid out like y (pixel-major, red_x_ld channels per
+   * pixel, same pixel grid), red_stats its g16 sums, red_gmul its slabs per group, red_act 1 for GELU; red_r is the
+   * buffer crd_gn_bwd_reduce would fill (float [B*Cout*2 + B*(Cout/(16*red_gmul))*2], zeroed by the caller).  Only
+   * crd_gn_bwd_apply remains to be called. */
+  const void* red_x;
+  int32_t red_x_ld, red_gmul, red_act, red_reserved;
+  const float* red_stats;
+  const float* red_gamma;
+  const float* red_beta;
+  float* red_r;
 } crd_conv_desc;
 
 int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);

@@ -62,7 +62,7 @@ def test_binding_signatures_match_header(built):
 def test_struct_layouts_match_header(built, tmp_path):
     """sizeof/offsetof of the descriptor structs as gcc lays them out vs the ctypes mirror."""
     import subprocess
-    fields = {"crd_conv_desc": (built.ConvDesc, ["x", "w", "OH", "y", "bias", "res", "res_scale", "stats"]),
+    fields = {"crd_conv_desc": (built.ConvDesc, ["x", "w", "OH", "y", "bias", "res", "res_scale", "stats", "red_x", "red_act", "red_stats", "red_r"]),
               "crd_wgrad_desc": (built.WgradDesc, ["x", "dy", "Cout", "dw", "dbias", "dw_partials", "dw_partial_capacity"]),
               "crd_pack_entry": (built.PackEntry, ["src", "cmap", "Cout", "dst_f32"]),
               "crd_unpack_entry": (built.UnpackEntry, ["src", "cmap", "Cin_pad", "replicas", "replica_stride"]),

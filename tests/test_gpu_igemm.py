@@ -40,7 +40,7 @@ def pack_w(w, cin_pad=None):
 
 def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, OH, OW, y, y_ld, y_coff, y_f32=0,
              gather_mode=0, out_mode=0, patch_k=0, patch_c=0, bias=None, act=0, res=None, res_ld=0, res_scale=None,
-             accumulate=0, stats=None, partial=None):
+             accumulate=0, stats=None, partial=None, red=None):
     lib = _lib()
     L = lib.load()
     d = lib.ConvDesc()
@@ -58,6 +58,10 @@ def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, O
     d.stats = stats.data_ptr() if stats is not None else None
     if partial is not None:
         d.stats_partial, d.stats_partial_capacity = partial.data_ptr(), partial.numel()
+    if red is not None:
+        rx, rstats, rgamma, rbeta, rgmul, ract, rr = red
+        d.red_x, d.red_x_ld, d.red_gmul, d.red_act = rx.data_ptr(), rx.shape[-1], rgmul, ract
+        d.red_stats, d.red_gamma, d.red_beta, d.red_r = rstats.data_ptr(), rgamma.data_ptr(), rbeta.data_ptr(), rr.data_ptr()
     lib.check(L.crd_conv_igemm(C.byref(d), lib.stream()), "crd_conv_igemm")
     torch.cuda.synchronize()
 
@@ -187,6 +191,35 @@ def test_conv_dgrad_gather_mode(case):
     dx = torch.zeros(B, H, W, Ci, dtype=torch.bfloat16, device="cuda")
     run_conv(dypm, Co, 0, B, OH, OW, Co, wd, Ci, k, k, s, p, H, W, dx, Ci, 0, gather_mode=1)
     assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, f"dgrad {case}")
+
+
+@pytest.mark.parametrize("Ci,Co,H,W,gmul,act", [(640, 160, 16, 26, 4, 1), (512, 64, 24, 40, 8, 1), (256, 64, 9, 7, 1, 0), (1024, 256, 2, 3, 4, 1), (1024, 256, 8, 13, 4, 1)])
+def test_conv_dgrad_with_fused_groupnorm_backward_reduce(Ci, Co, H, W, gmul, act):
+    """Data gradient of a 1x1 conv (Mlp.fc2) that also runs the reduce phase of the GroupNorm(+GELU) backward on its own
+    output: same dx, and r equal to crd_gn_bwd_reduce on (x_gn, dx).  Both tile configurations (64- and 128-wide)."""
+    lib = _lib()
+    L = lib.load()
+    g = torch.Generator().manual_seed(13)
+    B = 2
+    w = bf(torch.randn(Co, Ci, 1, 1, generator=g) / Co ** 0.5)
+    dy = bf(torch.randn(B, Co, H, W, generator=g))
+    wd = w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 1, Co).to(torch.bfloat16).cuda()
+    dypm = to_pm(dy)
+    xg = to_pm(bf(torch.randn(B, Ci, H, W, generator=g) * 1.3 + 0.2))       # the GroupNorm's raw input, [B, H*W, Ci]
+    gam, bet = (1 + 0.1 * torch.randn(Ci, generator=g)).cuda(), (0.1 * torch.randn(Ci, generator=g)).cuda()
+    stats = torch.zeros(B, Ci // 16, 2, device="cuda")
+    lib.check(L.crd_gn_stats(xg.data_ptr(), 0, Ci, 0, B, H * W, Ci, stats.data_ptr(), None, lib.stream()), "gn_stats")
+    G = Ci // (16 * gmul)
+    dx0 = torch.zeros(B, H, W, Ci, dtype=torch.bfloat16, device="cuda")
+    run_conv(dypm, Co, 0, B, H, W, Co, wd, Ci, 1, 1, 1, 0, H, W, dx0, Ci, 0, gather_mode=1)
+    r_ref = torch.zeros(B * Ci * 2 + B * G * 2, device="cuda")
+    lib.check(L.crd_gn_bwd_reduce(xg.data_ptr(), 0, Ci, 0, dx0.data_ptr(), 0, Ci, 0, B, H * W, Ci, stats.data_ptr(), gmul,
+                                  gam.data_ptr(), bet.data_ptr(), act, None, r_ref.data_ptr(), None, 0, lib.stream()), "gn_bwd_reduce")
+    dx1 = torch.zeros_like(dx0)
+    r = torch.zeros_like(r_ref)
+    run_conv(dypm, Co, 0, B, H, W, Co, wd, Ci, 1, 1, 1, 0, H, W, dx1, Ci, 0, gather_mode=1, red=(xg, stats, gam, bet, gmul, act, r))
+    assert torch.equal(dx0, dx1)
+    assert_close(r.cpu(), r_ref.cpu(), "fused gn-bwd reduce", rel=3e-4, elem=3e-4)
 
 
 @pytest.mark.parametrize("k,C", [(8, 64), (4, 128), (2, 160)])

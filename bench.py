@@ -81,11 +81,11 @@ def pmc_traffic(kernel):
     if not os.path.exists(path):
         return None
     ks = json.load(open(path))["kernels"]
-    stem = kernel.rstrip(">").replace(" ", "")
+    stem = kernel.replace("<*>", "<").rstrip(">").replace(" ", "")
     n = tot = 0.0
     for name, v in ks.items():
         nm = name.replace(" ", "")
-        if nm.startswith(stem + ",") or nm.rstrip(">") == stem:
+        if nm.startswith(stem + ",") or nm.rstrip(">") == stem or (stem.endswith("<") and nm.startswith(stem)):
             n += v["launches"]
             tot += v["hbm_bytes_per_launch"] * v["launches"]
     return round(tot / n) if n else None
@@ -232,8 +232,14 @@ def main():
 
     if rank == 0 and not a.no_roofline:
         agg = per_kernel_timing(ts)
-        dom = max(agg, key=lambda k: agg[k][1])
-        n, ms_tot, fl = agg[dom]
+        # the dominant kernel is a kernel TEMPLATE (all its tile instantiations together): k_conv3x3<*>, k_igemm<*>, ...
+        fam = {}
+        for k, (n_, ms_, fl_) in agg.items():
+            f = fam.setdefault(k.split("<")[0], [0.0, 0.0, 0.0])
+            f[0] += n_; f[1] += ms_; f[2] += fl_
+        domf = max(fam, key=lambda k: fam[k][1])
+        n, ms_tot, fl = fam[domf]
+        dom = domf + "<*>"
         ach = fl / (ms_tot * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),

@@ -182,8 +182,12 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
-    if world > 1:
+    # CRD_FORCE_DIST=1 (developer aid): take the multi-GPU code path -- RCCL process group, loss all-reduce, bucketed
+    # gradient all-reduce between the per-segment graphs -- with a single rank, to exercise it on a 1-GPU box
+    force_dist = os.environ.get("CRD_FORCE_DIST") is not None
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from camradepth_amd import synth
@@ -256,7 +260,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(a.variant)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

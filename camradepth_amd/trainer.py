@@ -13,6 +13,7 @@ transfer overlaps the remaining backward.  The masked-mean denominators are made
 (one 16-float all-reduce), which reproduces the reference's loss over the gathered batch exactly.
 """
 import math
+import os
 
 import torch
 import torch.distributed as dist
@@ -49,6 +50,8 @@ class GradSync:
     def __init__(self, model, group=None):
         self.model, self.group = model, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # CRD_FORCE_DIST=1: run the collectives even in a group of one (exercises the multi-GPU control flow on one GPU)
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("CRD_FORCE_DIST") is not None)
         names, offs = model._names, model._offsets
         total = model.flat.numel()
 
@@ -64,7 +67,7 @@ class GradSync:
         return self.model.flat_grad[lo:hi]
 
     def launch(self, key):
-        if self.world > 1:
+        if self.active:
             self.pending.append(dist.all_reduce(self.bucket(key), op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
@@ -97,6 +100,7 @@ class TrainStep:
         self.update_interval = update_interval
         self.sync = GradSync(model, group)
         self.world = self.sync.world
+        self.dist_active = self.sync.active
         # optimizer state over the flat buffers
         n = model.flat.numel()
         self.m, self.v, self.pg = (torch.zeros(n, device=self.dev) for _ in range(3))
@@ -181,7 +185,7 @@ class TrainStep:
         # undo the warm-up's parameter update side effects on the optimizer state
         for t in (self.m, self.v, self.pg, self.egn, self.nsq, self.fac):
             t.zero_()
-        if self.world == 1:      # no collective between the segments: the whole step is one graph (five fewer launches)
+        if not self.dist_active:      # no collective between the segments: the whole step is one graph (five fewer launches)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for fn, _ in self._segments():
@@ -224,9 +228,9 @@ class TrainStep:
             else:
                 fns[i]()
             if after == "loss":
-                if self.world > 1:
+                if self.dist_active:
                     dist.all_reduce(self.acc, group=self.sync.group)
-            elif after is not None and self.world > 1:
+            elif after is not None and self.dist_active:
                 self.sync.launch(after)
                 if i == len(runs) - 2:
                     self.sync.wait()

@@ -431,6 +431,61 @@ __global__ void k_attn_xbar(const float* chan, const float* stats, const float* 
   }
 }
 
+// Rank-one value path of the attention in one launch per direction (they were xbar + a [B,1,C] 1x1 "conv", and a
+// conversion + [B,1,C] data-gradient "conv" + a scale: three to four dependent dispatches of a few hundred threads).
+// Forward: xbar[b][c] = bf16(mean_n GroupNorm(x)[b][n][c]) (as k_attn_xbar), u[b][co] = sum_ci W[co][ci] * xbar[b][ci]
+// with W the proj weight in its packed bf16 forward form [C][C] (bf16 products, fp32 accumulation, as the MFMA path).
+__global__ __launch_bounds__(TPB) void k_attn_xbar_proj(const float* chan, const float* stats, const float* gamma, const float* beta,
+                                                        const bf16_t* w, int N, int C, bf16_t* xbar, float* u) {
+  __shared__ float sx[1024];
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    float mean, rstd;
+    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
+    const float mc = chan[((long long)b * C + c) * 2] / (float)N;
+    const bf16_t q = f2bf(gamma[c] * (mc - mean) * rstd + beta[c]);
+    xbar[(long long)b * C + c] = q;
+    sx[c] = bf2f(q);
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < C; co += TPB) {
+    const bf16_t* wr = w + (long long)co * C;
+    float acc = 0.f;
+    for (int ci = 0; ci < C; ci += 8) {
+      float wv[8];
+      load8(wr, ci, 0, wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += wv[j] * sx[ci + j];
+    }
+    u[(long long)b * C + co] = acc;
+  }
+}
+
+// Backward: tb = bf16(t); es[b][ci] = inv_n * sum_co W[co][ci] * tb[b][co], with wt the proj weight in its packed bf16
+// data-gradient form [C][Cpad] (row ci, contiguous over co).
+__global__ __launch_bounds__(TPB) void k_attn_vec_bwd(const float* t, const bf16_t* wt, int C, int Cpad, float inv_n, bf16_t* tb,
+                                                      float* es) {
+  __shared__ float st[1024];
+  const int b = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += TPB) {
+    const bf16_t q = f2bf(t[(long long)b * C + c]);
+    tb[(long long)b * C + c] = q;
+    st[c] = bf2f(q);
+  }
+  __syncthreads();
+  for (int ci = threadIdx.x; ci < C; ci += TPB) {
+    const bf16_t* wr = wt + (long long)ci * Cpad;
+    float acc = 0.f;
+    for (int co = 0; co < C; co += 8) {
+      float wv[8];
+      load8(wr, co, 0, wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += wv[j] * st[co + j];
+    }
+    es[(long long)b * C + ci] = acc * inv_n;
+  }
+}
+
 // x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])
 __global__ __launch_bounds__(TPB) void k_attn_out_residual(const float* x, const float* u, const float* S, const float* bp,
                                                            const float* dp, long long N, int C, float* x1) {
@@ -740,6 +795,26 @@ extern "C" int crd_attn_xbar(const float* chan_sums, const float* stats, const f
   hipLaunchKernelGGL(k_attn_xbar, dim3(B), dim3(256), 0, as_stream(stream), chan_sums, stats, gamma, beta, N, C,
                      reinterpret_cast<bf16_t*>(xbar));
   CRD_LAUNCH_CHECK("crd_attn_xbar");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_xbar_proj(const float* chan_sums, const float* stats, const float* gamma, const float* beta, const void* w_fwd,
+                                  int32_t B, int32_t N, int32_t C, void* xbar, float* u, crd_stream_t stream) {
+  CRD_CHECK_ARG(chan_sums && stats && gamma && beta && w_fwd && xbar && u, "crd_attn_xbar_proj: null pointer");
+  CRD_UNSUPPORTED(C % 16 == 0 && C <= 1024, "crd_attn_xbar_proj: C must be a multiple of 16, <= 1024");
+  hipLaunchKernelGGL(k_attn_xbar_proj, dim3(B), dim3(TPB), 0, as_stream(stream), chan_sums, stats, gamma, beta,
+                     reinterpret_cast<const bf16_t*>(w_fwd), N, C, reinterpret_cast<bf16_t*>(xbar), u);
+  CRD_LAUNCH_CHECK("crd_attn_xbar_proj");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_vec_bwd(const float* t, const void* w_dgrad, int32_t B, int32_t C, int32_t Cpad, float inv_n, void* tb, float* es,
+                                crd_stream_t stream) {
+  CRD_CHECK_ARG(t && w_dgrad && tb && es, "crd_attn_vec_bwd: null pointer");
+  CRD_UNSUPPORTED(C % 8 == 0 && C <= 1024 && Cpad >= C && Cpad % 8 == 0, "crd_attn_vec_bwd: C must be a multiple of 8, <= 1024");
+  hipLaunchKernelGGL(k_attn_vec_bwd, dim3(B), dim3(TPB), 0, as_stream(stream), t, reinterpret_cast<const bf16_t*>(w_dgrad), C, Cpad,
+                     inv_n, reinterpret_cast<bf16_t*>(tb), es);
+  CRD_LAUNCH_CHECK("crd_attn_vec_bwd");
   return CRD_OK;
 }
 

@@ -667,8 +667,9 @@ class Plan:
         xbar = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         U = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
         with self.side(2):       # rank-one value path: xbar = mean_n GN(x) -> proj
-            self._emit(F_, "crd_attn_xbar", [ch1, st1, self.p(name + ".norm1.weight"), self.p(name + ".norm1.bias"), B, N, Cs, xbar.t])
-            self.conv(F_, self.conv_desc(xbar, cp, Cs, 1, 1, 0, 1, 1, U))
+            assert cp.cin_pad == Cs and cp.cout_pad == Cs
+            self._emit(F_, "crd_attn_xbar_proj", [ch1, st1, self.p(name + ".norm1.weight"), self.p(name + ".norm1.bias"),
+                                                  _WPtr(cp, "w_fwd"), B, N, Cs, xbar.t, U.t])
         K = self.act(Cs, Hs // sr, Ws // sr)
         if sr > 1:
             csr = self.new_conv(a + ".sr", scatter=True)
@@ -736,13 +737,10 @@ class Plan:
         self.row_grads.append((a + ".proj.bias", Cs, dbp_rows, B, self._tag, 0, Cs))
         self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
         Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
-        E = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)                                           # d(xbar)
         Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
         with self.side(2):       # rank-one vector path, needed again only as the bias of the q data gradient
-            self._emit(g, "crd_f32_to_bf16_rows", [T, Cs, Tb.t, Cs, 0, B, Cs, None, 1, None, 0, 0])
+            self._emit(g, "crd_attn_vec_bwd", [T, _WPtr(cp, "w_dgrad"), B, Cs, cp.cout_pad, 1.0 / N, Tb.t, Es.t])   # Es = d(xbar)/N
             self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
-            self.conv(g, self.conv_desc(Tb, ("dgrad", cp), Cs, 1, 1, 0, 1, 1, E, gather=1))
-            self._emit(g, "crd_scale_f32", [E.t, Es.t, B * Cs, 1.0 / N])
         # dK: per-workgroup partial accumulators (plain stores) folded by the bf16 conversion below; fp32-atomic
         # accumulation into one buffer only when [M][C] does not fit in LDS
         nparts = self.lib.crd_attn_scores_bwd_partials(B, N, M, heads, dh)
@@ -924,7 +922,7 @@ class Plan:
     def _resolve(self, a):
         if isinstance(a, dict):
             return self._make_desc(a)
-        if isinstance(a, (_Lazy, torch.Tensor)):
+        if isinstance(a, (_Lazy, _WPtr, torch.Tensor)):
             return a.data_ptr()
         return a
 
@@ -1024,6 +1022,17 @@ class Plan:
                 lo, hi, mx = self.unpack_ranges[tag]
                 L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1,
                                                   L.stream()), "crd_wgrad_unpack")
+
+
+class _WPtr:
+    """Packed bf16 weights of a conv (allocated in Plan._finalise) as a raw-pointer op argument."""
+    __slots__ = ("cw", "kind")
+
+    def __init__(self, cw, kind):
+        self.cw, self.kind = cw, kind
+
+    def data_ptr(self):
+        return getattr(self.cw, self.kind).data_ptr()
 
 
 class _Lazy:

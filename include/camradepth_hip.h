@@ -194,6 +194,15 @@ int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t 
 /* xbar[b][c] (bf16) from per-channel sums chan[b][c][2] and g16 stats of x (gmul = 1). */
 int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma, const float* beta, int32_t B,
                   int32_t N, int32_t C, void* xbar, crd_stream_t stream);
+/* crd_attn_xbar followed by u[b][co] = sum_ci Wp[co][ci] * xbar[b][ci] (the `proj` Conv1d applied to the rank-one value,
+ * simplified_attention.py:103-107) in one launch; w_fwd is Wp in its packed bf16 forward form [C][C].  u: fp32 [B][C]. */
+int crd_attn_xbar_proj(const float* chan_sums, const float* stats, const float* gamma, const float* beta, const void* w_fwd,
+                       int32_t B, int32_t N, int32_t C, void* xbar, float* u, crd_stream_t stream);
+/* Backward of that path: tb = bf16(t) (bf16 [B][C], the dy operand of proj's weight gradient) and
+ * es[b][ci] = inv_n * sum_co Wp[co][ci] * tb[b][co] (fp32 [B][C]); w_dgrad is Wp in its packed bf16 data-gradient form
+ * [C][Cpad]. */
+int crd_attn_vec_bwd(const float* t, const void* w_dgrad, int32_t B, int32_t C, int32_t Cpad, float inv_n, void* tb, float* es,
+                     crd_stream_t stream);
 /* x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])   (fp32 residual stream; Block.forward :143; dp may be NULL) */
 int crd_attn_out_residual(const float* x, const float* u, const float* S, const float* bp, const float* dp,
                           int32_t B, int32_t N, int32_t C, float* x1, crd_stream_t stream);

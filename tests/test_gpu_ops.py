@@ -362,6 +362,20 @@ def test_attention_output_path():
     ok(lb.crd_attn_xbar(P(chan), P(stats), P(gac), P(bec), B, N, C_, P(xbar), lib.stream()), "xbar")
     xn = F.group_norm(x.permute(0, 2, 1), C_ // 16, gamma, beta, 1e-5)
     assert_close(xbar.float().cpu(), xn.mean(2), "xbar", rel=4e-3, elem=1e-2)
+    # fused xbar -> proj, and its backward (packed weights: forward form [co][ci], data-gradient form [ci][co_pad])
+    wp = bf(0.2 * torch.randn(C_, C_, generator=g))
+    wf = wp.to(torch.bfloat16).cuda().contiguous()
+    pad = 8
+    wd = torch.zeros(C_, C_ + pad, dtype=torch.bfloat16, device="cuda")
+    wd[:, :C_] = wp.t().to(torch.bfloat16)
+    xbar2, u2 = torch.zeros_like(xbar), torch.zeros(B, C_, device="cuda")
+    ok(lb.crd_attn_xbar_proj(P(chan), P(stats), P(gac), P(bec), P(wf), B, N, C_, P(xbar2), P(u2), lib.stream()), "xbar_proj")
+    assert torch.equal(xbar2, xbar)
+    assert_close(u2.cpu(), xbar.float().cpu() @ wp.t(), "u = Wp xbar", rel=1e-5, elem=1e-4)
+    tb, es = torch.zeros(B, C_, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, C_, device="cuda")
+    ok(lb.crd_attn_vec_bwd(P(t), P(wd), B, C_, C_ + pad, 1.0 / N, P(tb), P(es), lib.stream()), "attn_vec_bwd")
+    assert torch.equal(tb, t.to(torch.bfloat16))
+    assert_close(es.cpu(), (tb.float().cpu() @ wp) / N, "es = Wp^T tb / N", rel=1e-5, elem=1e-4)
 
 
 @pytest.mark.parametrize("H,W,C_", [(5, 7, 16), (8, 13, 136), (3, 4, 8), (16, 26, 128), (9, 16, 40), (19, 37, 72)])

@@ -33,45 +33,17 @@ struct ConvK {
 // pixel p; `pixrow(row_local, valid, p)` does the same for a row of the whole BM x BN tile (vector store path).
 // Vector path (bf16 output, plain layout): the tile is transposed through LDS so that every thread stores -- or
 // read-modify-writes, for gradient accumulation -- 16 contiguous bytes instead of 64 scattered 2-byte elements.
-template <int TM, int TN, int WM, int WN, typename PixFn, typename PixRowFn>
+template <int TM, int TN, int WM, int WN, int HALVES = 1, typename PixFn, typename PixRowFn>
 __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][TN], int b, int l, int wm, int wn, int n0,
                                               int tile, void* smem, PixFn pix, PixRowFn pixrow) {
-  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64, LDT = BN + 8;
-  float* red = reinterpret_cast<float*>(smem) + (BM * LDT) / 2;     // behind the bf16 staging tile
+  // HALVES = 2: the staging tile holds half of the rows at a time (two passes; the waves of the other half wait), for
+  // kernels that budget their LDS for two workgroups per CU
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64, LDT = BN + 8, BMH = BM / HALVES;
+  static_assert(HALVES == 1 || (HALVES == 2 && WM % 2 == 0), "row halves are whole waves");
+  float* red = reinterpret_cast<float*>(smem) + (BMH * LDT) / 2;     // behind the bf16 staging tile
   const bool vec = a.out_mode == 0 && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
   if (vec) {
     bf16_t* T = reinterpret_cast<bf16_t*>(smem);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int cl = (wn * TN + j) * 32 + (l & 31), col = n0 + cl;
-      const bool colok = col < a.Cout;
-      float s = 0.f, ss = 0.f;
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-          bool valid;
-          int row;
-          pix(i, rr, valid, row);
-          float v = acc[i][j][r];          // bias is already in the accumulator (see the kernels' accumulator init)
-          if (a.act == 1) v = sigmoidf_(v);
-          const bf16_t q = f2bf(v);
-          T[((wm * TM + i) * 32 + rr) * LDT + cl] = q;
-          if (valid && colok) { v = bf2f(q); s += v; ss += v * v; }
-        }
-      }
-      if (a.stats) {
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
-        if ((l & 15) == 0 && l < 32) {
-          float* r = red + (((wm * WN + wn) * TN + j) * 2 + (l >> 4)) * 2;
-          r[0] = s; r[1] = ss;
-        }
-      }
-    }
-    __syncthreads();
     bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
     constexpr int GPR = BN / 8;
     // fused GroupNorm-backward reduce: a thread keeps the same 8 columns for all its rows (NT % GPR == 0)
@@ -89,14 +61,50 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
         for (int j = 0; j < 8; ++j) { rga[j] = a.red_gamma[rcol + j]; rbe[j] = a.red_beta[rcol + j]; }
       }
     }
-    for (int idx = threadIdx.x; idx < BM * GPR; idx += NT) {
-      const int rl = idx / GPR, g = idx - rl * GPR;
+#pragma unroll
+    for (int h = 0; h < HALVES; ++h) {
+    if (h > 0) __syncthreads();            // the previous half has been stored
+    if (HALVES == 1 || (wm * TM * 32) / BMH == h) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cl = (wn * TN + j) * 32 + (l & 31), col = n0 + cl;
+      const bool colok = col < a.Cout;
+      float s = 0.f, ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+          bool valid;
+          int row;
+          pix(i, rr, valid, row);
+          float v = acc[i][j][r];          // bias is already in the accumulator (see the kernels' accumulator init)
+          if (a.act == 1) v = sigmoidf_(v);
+          const bf16_t q = f2bf(v);
+          T[((wm * TM + i) * 32 + rr - h * BMH) * LDT + cl] = q;
+          if (valid && colok) { v = bf2f(q); s += v; ss += v * v; }
+        }
+      }
+      if (a.stats) {
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+        s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+        if ((l & 15) == 0 && l < 32) {
+          float* r = red + (((wm * WN + wn) * TN + j) * 2 + (l >> 4)) * 2;
+          r[0] = s; r[1] = ss;
+        }
+      }
+    }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < BMH * GPR; idx += NT) {
+      const int rh = idx / GPR, g = idx - rh * GPR, rl = rh + h * BMH;
       bool valid;
       int p;
       pixrow(rl, valid, p);
       const int col = n0 + g * 8;
       if (valid && col < a.Cout) {
-        uint4 u = *reinterpret_cast<const uint4*>(T + rl * LDT + g * 8);
+        uint4 u = *reinterpret_cast<const uint4*>(T + rh * LDT + g * 8);
         bf16_t* dst = yb + (long long)p * a.y_ld + col;
         if (a.accumulate) {
           const uint4 o = *reinterpret_cast<const uint4*>(dst);
@@ -120,6 +128,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
         }
       }
     }
+    }   // row halves
     if (redo) {
       // threads t, t + GPR, ... share a column group: fold them through LDS (the staging tile is free again)
       __syncthreads();

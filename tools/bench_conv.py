@@ -3,7 +3,9 @@ import sys, ctypes as C
 sys.path.insert(0, ".")
 import torch
 from camradepth_amd import lib
-B, H, W, Cin, Cout = 8, 256, 416, 304, 128
+import os
+B, H, W = 8, 256, 416
+Cin, Cout = int(os.environ.get("CIN", 304)), int(os.environ.get("COUT", 128))
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 L = lib.load()
@@ -28,3 +30,9 @@ e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 print(f"conv {Cin}->{Cout} 3x3 @{H}x{W} B{B}: {ms:.3f} ms, {2.0 * B * H * W * Cout * Cin * 9 / ms / 1e9:.0f} TFLOP/s")
+
+if hasattr(L, "crd_dbg_conv3_prof"):      # library built with -DCRD_CONV3_PROF
+    buf = (C.c_ulonglong * 16)()
+    L.crd_dbg_conv3_prof(buf)
+    tot, real = buf[0], buf[1]
+    print(f"  workgroup: {tot} cycles in {real / 100.0:.2f} us -> {tot / max(real, 1) / 10.0:.2f} GHz; prologue {buf[2]}  main loop {buf[3]}  epilogue {buf[4]} cycles")

@@ -20,6 +20,7 @@ struct ConvK {
   const bf16_t* red_x; int red_x_ld; long long red_x_bstride;
   const float* red_stats; const float* red_gamma; const float* red_beta; int red_gmul, red_act;
   float* red_r;
+  int col0;  // first output column of this launch (the 3x3 halo kernel covers wide layers with two tile widths)
   int dbg;   // developer experiments only (CRD_DBG env): 1 no weight-DMA wait, 2 no DMA at all, 4 no epilogue
 };
 

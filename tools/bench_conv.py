@@ -4,7 +4,7 @@ sys.path.insert(0, ".")
 import torch
 from camradepth_amd import lib
 import os
-B, H, W = 8, 256, 416
+B, H, W = int(os.environ.get("B", 8)), int(os.environ.get("H", 256)), int(os.environ.get("W", 416))
 Cin, Cout = int(os.environ.get("CIN", 304)), int(os.environ.get("COUT", 128))
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -31,8 +31,10 @@ torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 print(f"conv {Cin}->{Cout} 3x3 @{H}x{W} B{B}: {ms:.3f} ms, {2.0 * B * H * W * Cout * Cin * 9 / ms / 1e9:.0f} TFLOP/s")
 
-if hasattr(L, "crd_dbg_conv3_prof"):      # library built with -DCRD_CONV3_PROF
-    buf = (C.c_ulonglong * 16)()
+if hasattr(L, "crd_dbg_conv3_prof"):      # library built with -DCRD_CONV3_PROF (tools/build_prof.sh)
+    buf = (C.c_ulonglong * 32)()
     L.crd_dbg_conv3_prof(buf)
-    tot, real = buf[0], buf[1]
-    print(f"  workgroup: {tot} cycles in {real / 100.0:.2f} us -> {tot / max(real, 1) / 10.0:.2f} GHz; prologue {buf[2]}  main loop {buf[3]}  epilogue {buf[4]} cycles")
+    steps = 9 * ((Cin + 31) // 32)
+    names = ["dma issue", "reads k0", "mfma k0", "reads k1", "mfma k1", "vm wait", "barrier"]
+    for w in range(4):
+        print(f"  wave {w}: " + "  ".join(f"{n} {buf[w * 8 + k] / steps:5.0f}" for k, n in enumerate(names)) + "  (cycles per step)")

@@ -20,6 +20,7 @@ struct ConvK {
   const bf16_t* red_x; int red_x_ld; long long red_x_bstride;
   const float* red_stats; const float* red_gamma; const float* red_beta; int red_gmul, red_act;
   float* red_r;
+  float* chan;   // optional per-channel (sum, sumsq) of the stored output [B][Cout][2] (scalar epilogue path only)
   int col0;  // first output column of this launch (the 3x3 halo kernel covers wide layers with two tile widths)
   int dbg;   // developer experiments only (CRD_DBG env): 1 no weight-DMA wait, 2 no DMA at all, 4 no epilogue
 };
@@ -211,6 +212,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
           }
           s += v; ss += v * v;
         }
+      }
+    }
+    if (a.chan) {                               // lanes l and l^32 hold the same column: one atomic pair per column and wave
+      const float cs = s + __shfl_xor(s, 32), css = ss + __shfl_xor(ss, 32);
+      if (l < 32 && colok) {
+        float* cp = a.chan + ((long long)b * a.Cout + col) * 2;
+        atomicAdd(cp, cs);
+        atomicAdd(cp + 1, css);
       }
     }
     if (a.stats) {

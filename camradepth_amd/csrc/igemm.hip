@@ -269,6 +269,9 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   k.res = d->res; k.res_ld = d->res_ld; k.res_bstride = (long long)YH * YW * d->res_ld; k.res_scale = d->res_scale;
   k.accumulate = d->accumulate; k.stats = d->stats; k.G16 = d->Cout / 16;
   k.stats_partial = d->stats ? d->stats_partial : nullptr; k.n_tiles = 0; k.col0 = 0;
+  k.chan = d->chan_sums;
+  CRD_UNSUPPORTED(!d->chan_sums || (d->stats && (d->y_f32 || d->res || d->out_mode != 0)),
+                  "crd_conv_igemm: chan_sums needs stats and an fp32 / residual output (the scalar epilogue)");
   k.vec_ok = (d->y_coff % 8 == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0);
   k.red_x = reinterpret_cast<const bf16_t*>(d->red_x); k.red_x_ld = d->red_x_ld;
   k.red_x_bstride = (long long)YH * YW * d->red_x_ld;

@@ -80,6 +80,59 @@ __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int 
     }
 }
 
+// crd_attn_out_residual with the GroupNorm statistics of its output (the block's norm2 input) folded in:
+// x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c]);  stats[b][c/16] += (sum, sumsq) of x1.  Thread mapping and fold as in
+// k_gn_stats.
+__global__ __launch_bounds__(TPB) void k_attn_out_residual_stats(const float* x, const float* u, const float* S, const float* bp,
+                                                                 const float* dp, long long P, int C, int chunk, float* x1,
+                                                                 float* stats) {
+  extern __shared__ float sm[];  // [PL][C][2]
+  const int b = blockIdx.y;
+  Map m(C);
+  if (m.active) {
+    float s[8], ss[8], uu[8], bb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] = ss[j] = 0.f;
+    const float dps = dp ? dp[b] : 1.f;
+    load8(u, (long long)b * C + m.cg * 8, 1, uu);
+    load8(bp, m.cg * 8, 1, bb);
+    long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
+    if (p1 > P) p1 = P;
+    for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
+      float v[U][8], sv[U];
+#pragma unroll
+      for (int q = 0; q < U; ++q) {
+        long long pp = p + (long long)q * m.PL;
+        if (pp >= p1) pp = p1 - 1;
+        load8(x, ((long long)b * P + pp) * C + m.cg * 8, 1, v[q]);
+        sv[q] = S[(long long)b * P + pp];
+      }
+#pragma unroll
+      for (int q = 0; q < U; ++q)
+        if (p + (long long)q * m.PL < p1) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[q][j] += dps * bf_round(uu[j] * sv[q] + bb[j]);
+            s[j] += v[q][j]; ss[j] += v[q][j] * v[q][j];
+          }
+          store8_f32(x1, ((long long)b * P + p + (long long)q * m.PL) * C + m.cg * 8, v[q]);
+        }
+    }
+    float4* row = reinterpret_cast<float4*>(sm + (long long)m.pl * 2 * C + m.cg * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) row[j] = make_float4(s[2 * j], ss[2 * j], s[2 * j + 1], ss[2 * j + 1]);
+  }
+  __syncthreads();
+  fold_rows(sm, 2 * C, m.PL);
+  for (int g = threadIdx.x; g < (C >> 4) * 2; g += TPB) {
+    int slab = g >> 1, which = g & 1;
+    float a = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a += sm[(slab * 16 + j) * 2 + which];
+    atomicAdd(&stats[((long long)b * (C >> 4) + slab) * 2 + which], a);
+  }
+}
+
 template <int XF, int YF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
                                                   const float* stats, int gmul, const float* gamma, const float* beta,
@@ -357,6 +410,19 @@ extern "C" int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   else hipLaunchKernelGGL(k_gn_stats<0>, grid, dim3(TPB), lds_rows(C), as_stream(stream), off_ptr(x, x_f32, x_coff),
                           x_f32, x_ld, (long long)P, C, chunk, stats, chan_sums);
   CRD_LAUNCH_CHECK("crd_gn_stats");
+  return CRD_OK;
+}
+
+extern "C" int crd_attn_out_residual_stats(const float* x, const float* u, const float* S, const float* bp, const float* dp,
+                                           int32_t B, int32_t N, int32_t C, float* x1, float* stats, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && u && S && bp && x1 && stats, "crd_attn_out_residual_stats: null pointer");
+  int rc = check_common("crd_attn_out_residual_stats", C, 0, C, 1);
+  if (rc) return rc;
+  dim3 grid; int chunk;
+  grid_for(N, C, B, grid, chunk, true);
+  hipLaunchKernelGGL(k_attn_out_residual_stats, grid, dim3(TPB), lds_rows(C), as_stream(stream), x, u, S, bp, dp, (long long)N, C,
+                     chunk, x1, stats);
+  CRD_LAUNCH_CHECK("crd_attn_out_residual_stats");
   return CRD_OK;
 }
 

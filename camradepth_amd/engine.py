@@ -33,6 +33,9 @@ SIDE_STREAMS = os.environ.get("CRD_SIDE_STREAMS") is not None
 # cost more than the streaming reduce kernel they replace.  (The same fusion into the depthwise data gradient, for
 # Mlp.norm1 without activation, does pay and is always on.)
 FUSE_GN_RED = os.environ.get("CRD_FUSE_GN_RED") is not None
+# GroupNorm statistics of the residual stream produced by the kernels that write it (attn_out_residual -> norm2, fc2's
+# epilogue -> the next block's norm1) instead of crd_gn_stats launches; CRD_NO_FUSE_STATS restores the launches
+FUSE_STATS = os.environ.get("CRD_NO_FUSE_STATS") is None
 SPLIT_N = os.environ.get("CRD_NO_SPLIT_N") is None      # developer switch for the ragged-tile split of 3x3 data gradients
 W3_PARTIALS = os.environ.get("CRD_NO_W3_PARTIALS") is None   # developer switch: streaming 3x3 wgrad with atomics instead
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
@@ -220,11 +223,11 @@ class Plan:
         self.bwd_tags.append(self._tag)
 
     def conv_desc(self, x, w_t, cout, k, stride, pad, OH, OW, y, cin=None, gather=0, out_mode=0, patch_k=0, patch_c=0,
-                  bias=None, bias_bstride=0, act=0, res=None, res_scale=None, stats=None, accumulate=0, red=None):
+                  bias=None, bias_bstride=0, act=0, res=None, res_scale=None, stats=None, accumulate=0, red=None, chan=None):
         """Specification of one crd_conv_igemm call; turned into a ctypes ConvDesc in _finalise."""
         return dict(x=x, w=w_t, cout=cout, k=k, stride=stride, pad=pad, OH=OH, OW=OW, y=y, cin=cin if cin is not None else x.C,
                     gather=gather, out_mode=out_mode, patch_k=patch_k, patch_c=patch_c, bias=bias, bias_bstride=bias_bstride,
-                    act=act, res=res, res_scale=res_scale, stats=stats, accumulate=accumulate, red=red)
+                    act=act, res=res, res_scale=res_scale, stats=stats, accumulate=accumulate, red=red, chan=chan)
 
     def conv(self, lst, spec, region=None):
         w, x = spec["w"], spec["x"]
@@ -330,6 +333,7 @@ class Plan:
             res = sp["res"]
             d.res, d.res_ld, d.res_scale = P(res), (res.ld if res is not None else 0), P(sp["res_scale"])
             d.accumulate, d.stats = sp["accumulate"], P(sp["stats"])
+            d.chan_sums = P(sp.get("chan"))
             if sp.get("red") is not None:        # fused reduce phase of the GroupNorm backward this output feeds
                 rx, rstats, rgamma, rbeta, rgmul, ract, rr = sp["red"]
                 assert rx.coff == 0, "the fused reduce reads the GroupNorm input from channel 0"
@@ -461,8 +465,10 @@ class Plan:
             sc = {"DH": self.act(Cs, Hs, Ws), "DHID": self.act(hid, Hs, Ws), "DHID2": self.act(hid, Hs, Ws),
                   "DXN": self.act(Cs, Hs, Ws), "DQ": self.act(Cs, Hs, Ws), "hid": hid}
             self._defer = [] if GROUP_WGRAD else None
+            pre = None
             for i in range(cfg.depths[s]):
-                X = self.block(f"dest_encoder.block{s + 1}.{i}", X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc)
+                X, pre = self.block(f"dest_encoder.block{s + 1}.{i}", X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc,
+                                    pre=pre, want_next=i + 1 < cfg.depths[s])
                 bi += 1
             self.flush_deferred(grp)       # grp (patch embed) is the LAST backward unit of this stage
             Xb = self.act(Cs, Hs, Ws)
@@ -646,10 +652,12 @@ class Plan:
         return run
 
     # ------------------------------------------------------------------ encoder block
-    def block(self, name, X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc):
+    def block(self, name, X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc, pre=None, want_next=False):
         """Block.forward (simplified_attention.py:141-145) with the rank-one form of the max-pool attention
         (SURVEY.md Q2 / Appendix B3).  X: fp32 residual stream in; returns the fp32 stream out.  DX is the stage's
-        running fp32 gradient buffer (the same buffer flows through every block of the stage)."""
+        running fp32 gradient buffer (the same buffer flows through every block of the stage).
+        pre: (g16 sums, channel sums) of X when the previous block's fc2 epilogue produced them; want_next: have this
+        block's fc2 epilogue produce them for the next block.  Returns (stream out, sums of the stream out or None)."""
         B, N, hid, dh = self.B, Hs * Ws, Cs * ratio, Cs // heads
         scale = dh ** -0.5
         a, ml = name + ".attn", name + ".mlp1"
@@ -657,9 +665,13 @@ class Plan:
         M = (Hs // sr) * (Ws // sr)
         F_ = self.fwd
         # ---- attention branch ----
-        st1, ch1 = self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)
         XN = self.act(Cs, Hs, Ws)
-        self.gn_stats_apply(X, st1, ch1, 1, name + ".norm1", 0, None, XN)
+        if pre is not None and FUSE_STATS:
+            st1, ch1 = pre
+            self.gn_fwd(X, st1, 1, name + ".norm1", 0, None, XN)
+        else:
+            st1, ch1 = self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)
+            self.gn_stats_apply(X, st1, ch1, 1, name + ".norm1", 0, None, XN)
         cq, ck, cp = self.new_conv(a + ".q"), self.new_conv(a + ".k"), self.new_conv(a + ".proj")
         Q = self.act(Cs, Hs, Ws)
         with self.side(1):       # q projection: independent of the key path below
@@ -688,11 +700,15 @@ class Plan:
         self.keep.append(("idx", name, idx, M))
         self._emit(F_, "crd_attn_scores", [Q.t, K.t, B, N, M, heads, dh, scale, Ssum, idx])
         X1 = self.act(Cs, Hs, Ws, F32)
-        self._emit(F_, "crd_attn_out_residual", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t])
         # ---- MLP branch ----
         st2 = self.zf(B, Cs // 16, 2)
         XN2 = self.act(Cs, Hs, Ws)
-        self.gn_stats_apply(X1, st2, None, 1, name + ".norm2", 0, None, XN2)
+        if FUSE_STATS:       # norm2's statistics come out of the kernel that writes X1
+            self._emit(F_, "crd_attn_out_residual_stats", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t, st2])
+            self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
+        else:
+            self._emit(F_, "crd_attn_out_residual", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t])
+            self.gn_stats_apply(X1, st2, None, 1, name + ".norm2", 0, None, XN2)
         c1, c2 = self.new_conv(ml + ".fc1"), self.new_conv(ml + ".fc2")
         H1, H2, H3 = (self.act(hid, Hs, Ws) for _ in range(3))
         sth1, sth2 = self.zf(B, hid // 16, 2), self.zf(B, hid // 16, 2)
@@ -704,7 +720,9 @@ class Plan:
         self._emit(F_, "crd_dwconv3x3", [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1 + [None, None, None, None])
         self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
         X2 = self.act(Cs, Hs, Ws, F32)
-        self.conv(F_, self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp))
+        nxt = (self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)) if (want_next and FUSE_STATS) else None
+        self.conv(F_, self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp,
+                                     stats=nxt[0] if nxt else None, chan=nxt[1] if nxt else None))
 
         # ---- backward (executed after the later blocks'; DX holds d(X2) on entry, d(X) on exit) ----
         g = []
@@ -774,7 +792,7 @@ class Plan:
         self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1)               # DX = d(X)
         self.join(g, 1)           # the depthwise weight gradient reads DHID, which the next block overwrites
         self._push(g)
-        return X2
+        return X2, nxt
 
     # ------------------------------------------------------------------ finalisation
     def _finalise(self):

@@ -83,6 +83,9 @@ typedef struct {
   const float* red_gamma;
   const float* red_beta;
   float* red_r;
+  float* chan_sums;               /* optional, with stats and an fp32 or residual output: per-channel (sum, sumsq) of the
+                                     stored output, float [B][Cout][2], accumulated with atomics (what crd_gn_stats'
+                                     chan_sums would hold for the output tensor) */
 } crd_conv_desc;
 
 int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);
@@ -206,6 +209,10 @@ int crd_attn_vec_bwd(const float* t, const void* w_dgrad, int32_t B, int32_t C, 
 /* x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])   (fp32 residual stream; Block.forward :143; dp may be NULL) */
 int crd_attn_out_residual(const float* x, const float* u, const float* S, const float* bp, const float* dp,
                           int32_t B, int32_t N, int32_t C, float* x1, crd_stream_t stream);
+/* crd_attn_out_residual that also accumulates the g16 GroupNorm sums of x1 (what crd_gn_stats(x1) would add to `stats`,
+ * float [B][C/16][2], zeroed by the caller): Block.norm2 reads x1 next (simplified_attention.py:143-144). */
+int crd_attn_out_residual_stats(const float* x, const float* u, const float* S, const float* bp, const float* dp,
+                                int32_t B, int32_t N, int32_t C, float* x1, float* stats, crd_stream_t stream);
 /* with dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp_rows[b][c] += sum_n dy ; dS[b][n] = sum_c dy*u[b][c].
  * The bias gradient is the sum of the B rows of dbp_rows (float [B][C], zeroed by the caller): per-sample rows keep the
  * chain of contended atomics at the workgroups of one sample; crd_wgrad_unpack (replicas = B) folds them. */

@@ -40,7 +40,7 @@ def pack_w(w, cin_pad=None):
 
 def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, OH, OW, y, y_ld, y_coff, y_f32=0,
              gather_mode=0, out_mode=0, patch_k=0, patch_c=0, bias=None, act=0, res=None, res_ld=0, res_scale=None,
-             accumulate=0, stats=None, partial=None, red=None):
+             accumulate=0, stats=None, partial=None, red=None, chan=None):
     lib = _lib()
     L = lib.load()
     d = lib.ConvDesc()
@@ -56,6 +56,7 @@ def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, O
     d.res_scale = res_scale.data_ptr() if res_scale is not None else None
     d.accumulate = accumulate
     d.stats = stats.data_ptr() if stats is not None else None
+    d.chan_sums = chan.data_ptr() if chan is not None else None
     if partial is not None:
         d.stats_partial, d.stats_partial_capacity = partial.data_ptr(), partial.numel()
     if red is not None:
@@ -154,6 +155,17 @@ def test_epilogues_sigmoid_residual_accumulate():
              res_ld=Co, res_scale=scale.cuda())
     ref = res + scale.view(B, 1, 1, 1) * bf(conv).permute(0, 2, 3, 1)
     assert_close(yf.cpu(), ref, "residual", rel=2e-3, elem=6e-3)
+    # the same with the GroupNorm sums of the stored fp32 output: g16 (sum, sumsq) and per-channel (sum, sumsq)
+    if Co % 16 == 0:
+        yf2 = torch.zeros(B, H, W, Co, device="cuda")
+        st, ch = torch.zeros(B, Co // 16, 2, device="cuda"), torch.zeros(B, Co, 2, device="cuda")
+        run_conv(xpm, Ci, 0, B, H, W, Ci, wp, Co, 1, 1, 1, 0, H, W, yf2, Co, 0, y_f32=1, bias=bias.cuda(), res=res.cuda(),
+                 res_ld=Co, res_scale=scale.cuda(), stats=st, chan=ch)
+        assert torch.equal(yf2, yf)
+        yd = yf2.double().cpu().view(B, H * W, Co)
+        chr_ = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
+        assert_close(ch.cpu(), chr_, "channel sums", rel=1e-5, elem=1e-5)
+        assert_close(st.cpu(), chr_.view(B, Co // 16, 16, 2).sum(2), "g16 sums", rel=1e-5, elem=1e-5)
     # accumulate into bf16
     y0 = bf(torch.randn(B, H, W, Co, generator=g))
     y = y0.to(torch.bfloat16).cuda()

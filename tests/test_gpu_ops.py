@@ -344,6 +344,12 @@ def test_attention_output_path():
     ok(lb.crd_attn_out_residual(P(xc), P(uc), P(Sc), P(bpc), P(dpc), B, N, C_, P(x1), lib.stream()), "attn_out_residual")
     ref = x + dp.view(B, 1, 1) * bf(u.unsqueeze(1) * S.unsqueeze(2) + bp)
     assert_close(x1.cpu(), ref, "x1", rel=1e-5, elem=1e-5)
+    if C_ % 16 == 0:      # fused variant: same x1 plus the g16 sums crd_gn_stats(x1) would produce
+        x1b, st = torch.zeros(B, N, C_, device="cuda"), torch.zeros(B, C_ // 16, 2, device="cuda")
+        ok(lb.crd_attn_out_residual_stats(P(xc), P(uc), P(Sc), P(bpc), P(dpc), B, N, C_, P(x1b), P(st), lib.stream()), "attn_out_residual_stats")
+        assert torch.equal(x1b, x1)
+        xd_ = x1.double().cpu().view(B, N, C_ // 16, 16)
+        assert_close(st.cpu(), torch.stack([xd_.sum((1, 3)), (xd_ * xd_).sum((1, 3))], -1), "norm2 sums", rel=1e-5, elem=1e-5)
     dx1 = torch.randn(B, N, C_, generator=g)
     t, dbp, dS = torch.zeros(B, C_, device="cuda"), torch.zeros(B, C_, device="cuda"), torch.zeros(B, N, device="cuda")
     dx1c = dx1.cuda()

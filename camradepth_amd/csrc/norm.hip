@@ -292,7 +292,8 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
                                                       int dy_ld, long long P, int C, int chunk, const float* stats,
                                                       int gmul, const float* gamma, const float* beta, int act,
                                                       const float* mask, const float* r, float* dgamma, float* dbeta,
-                                                      void* dx, int dx_f32, int dx_ld, int dx_acc, int B) {
+                                                      void* dx, int dx_f32, int dx_ld, int dx_acc, int B, void* dx2, int dx2_ld,
+                                                      const float* scale2) {
   const int b = blockIdx.y;
   if (blockIdx.x == 0 && b == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += TPB) {
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
     ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
     mk[j] = mask ? mask[(long long)b * C + c0 + j] : 1.f;
   }
+  const float sc2 = (dx2 && scale2) ? scale2[b] : 1.f;
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > P) p1 = P;
   for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
@@ -359,6 +361,11 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
           for (int j = 0; j < 8; ++j) o[j] += w[j];
         }
         store8_bf16(dx, off, o);
+      }
+      if (dx2) {          // second copy of the finished gradient: bf16(scale2[b] * dx)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] *= sc2;
+        store8_bf16(dx2, ((long long)b * P + pp) * dx2_ld + c0, o);
       }
     }
   }
@@ -486,8 +493,10 @@ extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int3
                                 int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
                                 int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
                                 const float* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
-                                int32_t dx_coff, int32_t dx_accumulate, crd_stream_t stream) {
+                                int32_t dx_coff, int32_t dx_accumulate, void* dx2, int32_t dx2_ld, const float* scale2,
+                                crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && stats && gamma && beta && r && dx, "crd_gn_bwd_apply: null pointer");
+  CRD_CHECK_ARG(!dx2 || dx2_ld % 8 == 0, "crd_gn_bwd_apply: dx2_ld must be a multiple of 8");
   CRD_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "crd_gn_bwd_apply: dgamma and dbeta go together");
   CRD_CHECK_ARG(gmul >= 1 && (C / 16) % gmul == 0, "crd_gn_bwd_apply: bad gmul");
   CRD_CHECK_ARG(dy_ld % 8 == 0 && dy_coff % 8 == 0 && dx_ld % 8 == 0 && dx_coff % 8 == 0,
@@ -500,7 +509,7 @@ extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int3
 #define CRD_GN_BAP(XF, DF, ACT)                                                                                              \
   hipLaunchKernelGGL((k_gn_bwd_apply<XF, DF, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
                      x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C, chunk, stats, gmul, gamma, beta,  \
-                     act, mask, r, dgamma, dbeta, dxp, dx_f32, dx_ld, dx_accumulate, B)
+                     act, mask, r, dgamma, dbeta, dxp, dx_f32, dx_ld, dx_accumulate, B, dx2, dx2_ld, scale2)
   switch ((x_f32 ? 4 : 0) | (dy_f32 ? 2 : 0) | (act ? 1 : 0)) {
     case 0: CRD_GN_BAP(0, 0, 0); break;  case 1: CRD_GN_BAP(0, 0, 1); break;
     case 2: CRD_GN_BAP(0, 1, 0); break;  case 3: CRD_GN_BAP(0, 1, 1); break;

@@ -374,15 +374,19 @@ class Plan:
         self._emit(self.fwd, "crd_gn_stats", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, chan])
         self.gn_fwd(x, stats, gmul, gname, act, mask, y)
 
-    def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0, r=None):
-        """r given: the reduce phase was fused into the kernel that produced dy (only the apply phase is emitted)."""
+    def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0, r=None, dx2=None, scale2=None):
+        """r given: the reduce phase was fused into the kernel that produced dy (only the apply phase is emitted).
+        dx2: PM that also receives bf16(scale2[b] * dx)."""
         common = [x.t, x.f32, x.ld, x.coff, dy.t, dy.f32, dy.ld, dy.coff, self.B, x.P, x.C, stats, gmul,
                   self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask]
         if r is None:
             r = self.zb(self.B * x.C * 2 + self.B * (x.C // (16 * gmul)) * 2)
             self._emit(grp, "crd_gn_bwd_reduce", common + [r, None, 0])
         args = common + [r, self.g(gname + ".weight"), self.g(gname + ".bias"), dx.t, dx.f32, dx.ld, dx.coff, dx_acc]
-        self._emit(grp, "crd_gn_bwd_apply", args, region, len(args) - 1 if region else None)
+        acc_idx = len(args) - 1
+        assert dx2 is None or dx2.coff == 0
+        args += [dx2.t if dx2 is not None else None, dx2.ld if dx2 is not None else 0, scale2]
+        self._emit(grp, "crd_gn_bwd_apply", args, region, acc_idx if region else None)
 
     def conv_layer(self, name, x, k, out, mask=None, dout=None, dx=None, dx_region=None):
         """ConvLayer (utils.py:210-228): conv(no bias) -> GN(Cout/16) -> GELU [-> Dropout2d mask].
@@ -465,10 +469,10 @@ class Plan:
             sc = {"DH": self.act(Cs, Hs, Ws), "DHID": self.act(hid, Hs, Ws), "DHID2": self.act(hid, Hs, Ws),
                   "DXN": self.act(Cs, Hs, Ws), "DQ": self.act(Cs, Hs, Ws), "hid": hid}
             self._defer = [] if GROUP_WGRAD else None
-            pre = None
+            pre = dh = None
             for i in range(cfg.depths[s]):
-                X, pre = self.block(f"dest_encoder.block{s + 1}.{i}", X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc,
-                                    pre=pre, want_next=i + 1 < cfg.depths[s])
+                X, pre, dh = self.block(f"dest_encoder.block{s + 1}.{i}", X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc,
+                                        pre=pre, want_next=i + 1 < cfg.depths[s], dh_prev=dh)
                 bi += 1
             self.flush_deferred(grp)       # grp (patch embed) is the LAST backward unit of this stage
             Xb = self.act(Cs, Hs, Ws)
@@ -652,12 +656,14 @@ class Plan:
         return run
 
     # ------------------------------------------------------------------ encoder block
-    def block(self, name, X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc, pre=None, want_next=False):
+    def block(self, name, X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc, pre=None, want_next=False, dh_prev=None):
         """Block.forward (simplified_attention.py:141-145) with the rank-one form of the max-pool attention
         (SURVEY.md Q2 / Appendix B3).  X: fp32 residual stream in; returns the fp32 stream out.  DX is the stage's
         running fp32 gradient buffer (the same buffer flows through every block of the stage).
         pre: (g16 sums, channel sums) of X when the previous block's fc2 epilogue produced them; want_next: have this
-        block's fc2 epilogue produce them for the next block.  Returns (stream out, sums of the stream out or None)."""
+        block's fc2 epilogue produce them for the next block.  dh_prev: (DH, dp) of the previous block: this block's last
+        backward kernel also writes bf16(dp * d(X)) there.  Returns (stream out, sums of the stream out or None,
+        (DH, dp) of this block when a later block is to fill it)."""
         B, N, hid, dh = self.B, Hs * Ws, Cs * ratio, Cs // heads
         scale = dh ** -0.5
         a, ml = name + ".attn", name + ".mlp1"
@@ -730,7 +736,11 @@ class Plan:
         DH, DHID, DHID2, DXN, DQ = sc["DH"], sc["DHID"], sc["DHID2"], sc["DXN"], sc["DQ"]
         if self._defer is not None:      # operands of deferred weight gradients must outlive the block
             DH, DHID2, DQ = self.act(Cs, Hs, Ws), self.act(hid, Hs, Ws), self.act(Cs, Hs, Ws)
-        self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
+        dh_out = None
+        if want_next and FUSE_STATS and self._defer is not None:
+            dh_out = (DH, dp)        # d(X2) arrives in bf16 from the next block's norm1 backward
+        else:
+            self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
         self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc2.bias"))
         # fc2's data gradient also runs the reduce phase of Mlp.norm2's backward on its own output (FUSE_GN_RED)
         r2 = self.zb(B * hid * 2 + B * (hid // (16 * ratio)) * 2) if FUSE_GN_RED and hid > 160 else None
@@ -789,10 +799,11 @@ class Plan:
         else:
             self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".k.bias"))
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=1))
-        self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1)               # DX = d(X)
+        self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1,                # DX = d(X)
+                    dx2=dh_prev[0] if dh_prev else None, scale2=dh_prev[1] if dh_prev else None)
         self.join(g, 1)           # the depthwise weight gradient reads DHID, which the next block overwrites
         self._push(g)
-        return X2, nxt
+        return X2, nxt, dh_out
 
     # ------------------------------------------------------------------ finalisation
     def _finalise(self):

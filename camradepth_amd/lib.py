@@ -97,7 +97,7 @@ def load():
 _SIGS = {
     "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
-    "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiip",
+    "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiipipp",
     "crd_dwconv3x3": "piiiippipppippppppp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",
     "crd_attn_scores": "ppiiiiifppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_xbar_proj": "pppppiiippp", "crd_attn_vec_bwd": "ppiiifppp", "crd_attn_out_residual": "pppppiiipp", "crd_attn_out_residual_stats": "pppppiiippp",
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp",

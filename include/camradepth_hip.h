@@ -154,12 +154,15 @@ int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff
                       float* r, float* scratch, int64_t scratch_capacity, crd_stream_t stream);
 /* Backward, phase 2: dgamma[c] += sum_b r[b][c][1], dbeta[c] += sum_b r[b][c][0];
  * dx = (gamma*g - mean_grp(gamma*g) - xhat*mean_grp(gamma*g*xhat)) * rstd, written as bf16
- * (dx_f32=0) or ADDED into an fp32 tensor (dx_f32=1, accumulate). */
+ * (dx_f32=0) or ADDED into an fp32 tensor (dx_f32=1, accumulate).  dx2 (optional): a bf16 copy [B][P][dx2_ld] of the
+ * finished dx, scaled per sample by scale2[b] when scale2 is given (the drop-path-scaled gradient the previous block's
+ * fc2 backward consumes, simplified_attention.py:144). */
 int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
                      int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
                      int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
                      const float* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
-                     int32_t dx_coff, int32_t dx_accumulate, crd_stream_t stream);
+                     int32_t dx_coff, int32_t dx_accumulate, void* dx2, int32_t dx2_ld, const float* scale2,
+                     crd_stream_t stream);
 
 
 /* ---------------------------------------------------------------------------------------------

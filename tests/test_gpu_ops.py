@@ -191,7 +191,7 @@ def test_groupnorm_forward_backward(C_, gmul, xf32, act):
     dgam, dbet = torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
     dx = torch.zeros(B, Pn, C_, dtype=torch.bfloat16, device="cuda")
     ok(lb.crd_gn_bwd_apply(P(xd), xf32, C_, 0, P(dyd), 0, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(r),
-                           P(dgam), P(dbet), P(dx), 0, C_, 0, 0, lib.stream()), "gn_bwd_apply")
+                           P(dgam), P(dbet), P(dx), 0, C_, 0, 0, None, 0, None, lib.stream()), "gn_bwd_apply")
     assert_close(dx.float().cpu().permute(0, 2, 1), xr.grad, "gn dx", rel=6e-3, elem=2e-2)
     assert_close(dgam.cpu(), gamma.grad, "dgamma", rel=2e-3, elem=4e-3)
     assert_close(dbet.cpu(), beta.grad, "dbeta", rel=2e-3, elem=4e-3)
@@ -199,8 +199,15 @@ def test_groupnorm_forward_backward(C_, gmul, xf32, act):
     base = torch.randn(B, Pn, C_, generator=g)
     dxf = base.clone().cuda()
     ok(lb.crd_gn_bwd_apply(P(xd), xf32, C_, 0, P(dyd), 0, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(r),
-                           None, None, P(dxf), 1, C_, 0, 1, lib.stream()), "gn_bwd_apply f32")
+                           None, None, P(dxf), 1, C_, 0, 1, None, 0, None, lib.stream()), "gn_bwd_apply f32")
     assert_close(dxf.cpu() - base, xr.grad.permute(0, 2, 1), "gn dx f32 acc", rel=1e-3, elem=2e-3)
+    # ... with the scaled bf16 copy of the finished gradient
+    dxf2, dx2 = base.clone().cuda(), torch.zeros(B, Pn, C_ + 8, dtype=torch.bfloat16, device="cuda")
+    sc2 = torch.tensor([0.5 + 0.25 * i for i in range(B)]).cuda()
+    ok(lb.crd_gn_bwd_apply(P(xd), xf32, C_, 0, P(dyd), 0, C_, 0, B, Pn, C_, P(stats), gmul, P(gc), P(bc), act, P(mc), P(r),
+                           None, None, P(dxf2), 1, C_, 0, 1, P(dx2), C_ + 8, P(sc2), lib.stream()), "gn_bwd_apply f32 + copy")
+    assert torch.equal(dxf2, dxf)
+    assert torch.equal(dx2[..., :C_], (dxf * sc2.view(B, 1, 1)).to(torch.bfloat16))
 
 
 @pytest.mark.parametrize("C_,H,W", [(64, 9, 13), (512, 8, 12), (160, 5, 7), (64, 11, 45), (80, 9, 33), (256, 17, 64)])

@@ -33,7 +33,7 @@ r = torch.zeros(B * hid * 2 + B * (Cs // 16) * 2 * 8, device="cuda")
 scr = torch.zeros(1024 * 2 * 1024, device="cuda")
 timeit("gn_bwd_reduce hidden", lambda: L.crd_gn_bwd_reduce(Hn.data_ptr(), 0, hid, 0, Hd.data_ptr(), 0, hid, 0, B, N, hid, stats.data_ptr(), hid // Cs, gam.data_ptr(), bet.data_ptr(), 1, None, r.data_ptr(), scr.data_ptr(), scr.numel(), st()), 2 * hb)
 dg, db = torch.zeros(hid, device="cuda"), torch.zeros(hid, device="cuda")
-timeit("gn_bwd_apply hidden (in place)", lambda: L.crd_gn_bwd_apply(Hn.data_ptr(), 0, hid, 0, Hd.data_ptr(), 0, hid, 0, B, N, hid, stats.data_ptr(), hid // Cs, gam.data_ptr(), bet.data_ptr(), 1, None, r.data_ptr(), dg.data_ptr(), db.data_ptr(), Hd.data_ptr(), 0, hid, 0, 0, st()), 3 * hb)
+timeit("gn_bwd_apply hidden (in place)", lambda: L.crd_gn_bwd_apply(Hn.data_ptr(), 0, hid, 0, Hd.data_ptr(), 0, hid, 0, B, N, hid, stats.data_ptr(), hid // Cs, gam.data_ptr(), bet.data_ptr(), 1, None, r.data_ptr(), dg.data_ptr(), db.data_ptr(), Hd.data_ptr(), 0, hid, 0, 0, None, 0, None, st()), 3 * hb)
 w9, b9 = torch.randn(9, hid, device="cuda"), torch.randn(hid, device="cuda")
 timeit("dwconv fwd (+bias,+stats)", lambda: L.crd_dwconv3x3(Hn.data_ptr(), B, H, W, hid, w9.data_ptr(), b9.data_ptr(), 0, out.data_ptr(), stats.data_ptr(), st()), 2 * hb)
 timeit("dwconv dgrad (flip)", lambda: L.crd_dwconv3x3(Hn.data_ptr(), B, H, W, hid, w9.data_ptr(), None, 1, out.data_ptr(), None, st()), 2 * hb)

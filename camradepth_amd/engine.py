@@ -33,6 +33,8 @@ SIDE_STREAMS = os.environ.get("CRD_SIDE_STREAMS") is not None
 # cost more than the streaming reduce kernel they replace.  (The same fusion into the depthwise data gradient, for
 # Mlp.norm1 without activation, does pay and is always on.)
 FUSE_GN_RED = os.environ.get("CRD_FUSE_GN_RED") is not None
+# ... except on grids of <= this many pixels per sample, where the launch it saves outweighs the slower epilogue (25.2 -> 25.0 ms)
+FUSE_GN_RED_MAXPIX = int(os.environ.get("CRD_FUSE_GN_RED_MAXPIX", "416"))
 # GroupNorm statistics of the residual stream produced by the kernels that write it (attn_out_residual -> norm2, fc2's
 # epilogue -> the next block's norm1) instead of crd_gn_stats launches; CRD_NO_FUSE_STATS restores the launches
 FUSE_STATS = os.environ.get("CRD_NO_FUSE_STATS") is None
@@ -743,7 +745,7 @@ class Plan:
             self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
         self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc2.bias"))
         # fc2's data gradient also runs the reduce phase of Mlp.norm2's backward on its own output (FUSE_GN_RED)
-        r2 = self.zb(B * hid * 2 + B * (hid // (16 * ratio)) * 2) if FUSE_GN_RED and hid > 160 else None
+        r2 = self.zb(B * hid * 2 + B * (hid // (16 * ratio)) * 2) if hid > 160 and (FUSE_GN_RED or N <= FUSE_GN_RED_MAXPIX) else None
         red = None if r2 is None else (H2, sth2, self.p(ml + ".norm2.weight"), self.p(ml + ".norm2.bias"), ratio, 1, r2)
         self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1, red=red))
         self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID, r=r2)           # in place: d(H2)

@@ -240,7 +240,7 @@ def main():
         fam = {}
         for k, (n_, ms_, fl_) in agg.items():
             f = fam.setdefault(k.split("<")[0], [0.0, 0.0, 0.0])
-            f[0] += n_; f[1] += ms_; f[2] += fl_
+            f[0] += n_ * (1 + k.count("+")); f[1] += ms_; f[2] += fl_     # "a+b": one call, two device launches
         domf = max(fam, key=lambda k: fam[k][1])
         n, ms_tot, fl = fam[domf]
         dom = domf + "<*>"

@@ -98,14 +98,14 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
 def halo_tile(cout):
     """Tile configuration of the halo-tile 3x3 kernel (csrc/conv3x3.hip)."""
     if cout <= 32:
-        return "k_conv3x3<8,1,1,1>"
+        return "k_conv3x3<4,1,2,1>"
     if cout <= 64:
-        return "k_conv3x3<4,2,2,1>"
+        return "k_conv3x3<4,1,2,2>"
     if cout <= 96:
-        return "k_conv3x3<8,1,1,3>"
-    if 128 < cout <= 160 or 256 < cout <= 320:
-        return "k_conv3x3<8,1,1,5>"
-    return "k_conv3x3<4,2,2,2>"
+        return "k_conv3x3<4,1,2,3>"
+    if 128 < cout <= 160 or 256 < cout <= 320:      # two launches: 128-wide tiles + the remaining columns
+        return "k_conv3x3<4,1,2,4>+<4,1,2,1>" if cout - (256 if cout > 256 else 128) <= 32 else "k_conv3x3<4,1,2,4>+<4,1,2,2>"
+    return "k_conv3x3<4,1,2,4>"
 
 
 def wgrad_tile(cout):

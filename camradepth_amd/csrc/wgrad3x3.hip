@@ -38,8 +38,11 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 // unit u of row r is stored at unit u ^ f(r)  (found by exhaustive search over the access pattern; 64 banks x 4 B).
 __device__ __forceinline__ int swz128(int r) { return (r & 3) ^ ((r >> 3) & 1); }            // 128-byte rows (4 units)
 __device__ __forceinline__ int swz256(int r) { return (r & 3) | (((r >> 3) & 1) << 2); }     // 256-byte rows (8 units)
+// 192-byte rows (6 units): four consecutive rows already start 48 banks apart; only the second 16-lane group of a
+// half-wave (8 rows further, the same banks again) has to move, by one unit
+__device__ __forceinline__ int swz192(int r) { return (r >> 3) & 1; }
 template <int COT>
-__device__ __forceinline__ int swz_y(int r) { return COT == 128 ? swz256(r) : (COT == 64 ? swz128(r) : 0); }
+__device__ __forceinline__ int swz_y(int r) { return COT == 128 ? swz256(r) : (COT == 96 ? swz192(r) : (COT == 64 ? swz128(r) : 0)); }
 
 __device__ __forceinline__ s16x4 tr_read3(const bf16_t* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(p));
@@ -103,9 +106,11 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
   // dy row = YGRP wave-instructions, issued by waves 0..YGRP-1.  lane -> (pixel in group, 16-byte granule)
   const int xpix = 8 * wv + (l >> 3);            // staged pixel index 0..39 (image x = x0 - 1 + xpix)
   const int xgr = l & 7;                         // channel granule inside the chunk
-  constexpr int YPPI = 1024 / (COT * 2);         // dy pixels per wave-instruction
-  const int ypix = YPPI * wv + l / (COT / 8);
-  const int ygr = l % (COT / 8);
+  // dy row: 32 pixels x COT/8 granules, lane-linear over the YGRP wave-instructions (a 96-channel row is 12 granules:
+  // an instruction then covers 5 1/3 pixels)
+  const int ylin = 64 * wv + l;
+  const int ypix = ylin / (COT / 8);
+  const int ygr = ylin % (COT / 8);
 
   while (sr < sr_end) {
     // ---- one segment: rows [y0, y1) of strip (b, sx) ----
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
         const int ix = x0 + ypix, co = ((((ygr >> 1) ^ swz_y<COT>(ypix)) << 1) | (ygr & 1)) * 8;
         const bool ok = r < y1 && ix < a.W && co < a.Cout;
         const unsigned off = ok ? (unsigned)((((long long)(b * a.H + r) * a.W + ix) * a.dy_ld + co) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr)(sY + ((r % YS) * 32 + YPPI * wv) * COT), 16, off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr)(sY + (r % YS) * 32 * COT + 512 * wv), 16, off, 0, 0, 0);
       }
 #else
       (void)r;
@@ -264,6 +269,7 @@ int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st) {
                 "crd_conv_wgrad: dw_partials holds fewer copies than crd_conv_wgrad_splits() reports");
   if (d->Cout <= 32) return launch_w3<2, 4, 1>(k, st, d->dw_partial_capacity);
   if (d->Cout <= 64) return launch_w3<2, 4, 2>(k, st, d->dw_partial_capacity);
+  if (d->Cout <= 96) return launch_w3<2, 4, 3>(k, st, d->dw_partial_capacity);     // 96-channel dy rows: no padded MFMA tiles
   return launch_w3<4, 2, 2>(k, st, d->dw_partial_capacity);
 }
 

@@ -99,6 +99,7 @@ WG_CASES = [
     (2, 129, 136, 17, 40, 32, 3, 1, 1),
     (2, 128, 128, 9, 33, 21, 3, 1, 1),
     (3, 48, 48, 40, 32, 128, 3, 1, 1),
+    (1, 64, 64, 12, 40, 80, 3, 1, 1),        # 96-channel dy rows (192-byte LDS rows), partial
 ]
 
 

@@ -291,6 +291,19 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == 0 && d->IH == d->OH && d->IW == d->OW &&
       d->IW >= 32 && d->IH >= 8)
     return crd_conv3x3_halo(k, d->B, st, pcap);
+  {   // developer override of the tile choice below (tools/bench_small_gemm.py sweeps it)
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("CRD_IGEMM_FORCE"); force = e ? atoi(e) : 0; }
+    switch (force) {
+      case 1: return launch<2, 2, 1, 1, 4>(k, d->B, st, pcap);
+      case 2: return launch<2, 2, 2, 1, 3>(k, d->B, st, pcap);
+      case 3: return launch<2, 2, 2, 2, 2>(k, d->B, st, pcap);
+      case 4: return launch<2, 2, 1, 1, 2, 4>(k, d->B, st, pcap);
+      case 5: return launch<2, 2, 1, 1, 3>(k, d->B, st, pcap);
+      case 6: return launch<2, 2, 1, 1, 2>(k, d->B, st, pcap);
+      default: break;
+    }
+  }
   // small problems: 64x64 tiles so that the launch still covers the 256 CUs
   {
     const long long big_tiles = (long long)cdiv(k.OHW, 128) * cdiv(d->Cout, 128) * d->B;

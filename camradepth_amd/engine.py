@@ -269,7 +269,7 @@ class Plan:
         stream3 = k == 3 and stride == 1 and OW >= 32 and OH >= 8
         if stream3:
             cw.stream3_geom = (x.H, x.W, spec["cin"])
-        kname = ("k_wgrad3x3<2,4,1>" if cw.cout <= 32 else "k_wgrad3x3<2,4,2>" if cw.cout <= 64 else "k_wgrad3x3<4,2,2>") if stream3 \
+        kname = ("k_wgrad3x3<2,4,1>" if cw.cout <= 32 else "k_wgrad3x3<2,4,2>" if cw.cout <= 64 else "k_wgrad3x3<2,4,3>" if cw.cout <= 96 else "k_wgrad3x3<4,2,2>") if stream3 \
             else wgrad_tile(cw.cout)
         meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps,
                 "shape": f"wgrad Cin{spec['cin']} Cout{cw.cout} k{k} s{stride} out{OH}x{OW}"}

@@ -6,11 +6,12 @@ import torch
 from camradepth_amd import lib
 L = lib.load()
 B = 8
-SHAPES = [  # Cin, Cout, H, W, k, stride, gather_mode
-    (160, 640, 16, 26, 1, 1, 0), (640, 160, 16, 26, 1, 1, 0), (160, 160, 16, 26, 1, 1, 0), (160, 160, 16, 26, 2, 2, 0),
-    (128, 512, 32, 52, 1, 1, 0), (512, 128, 32, 52, 1, 1, 0), (128, 128, 32, 52, 4, 4, 0), (64, 256, 64, 104, 1, 1, 0),
-    (256, 64, 64, 104, 1, 1, 0), (256, 1024, 8, 13, 1, 1, 0), (1024, 256, 8, 13, 1, 1, 0), (256, 256, 8, 13, 1, 1, 0),
-    (640, 160, 16, 26, 1, 1, 1), (160, 640, 16, 26, 1, 1, 1), (512, 128, 32, 52, 1, 1, 1)]
+SHAPES = [  # Cin, Cout, H, W, k, stride, gather_mode   (the encoder's Mlp.fc1 / fc2 and their data gradients, base model)
+    (64, 512, 64, 104, 1, 1, 0), (512, 64, 64, 104, 1, 1, 0), (512, 64, 64, 104, 1, 1, 1), (64, 512, 64, 104, 1, 1, 1),
+    (128, 1024, 32, 52, 1, 1, 0), (1024, 128, 32, 52, 1, 1, 0), (1024, 128, 32, 52, 1, 1, 1), (128, 1024, 32, 52, 1, 1, 1),
+    (160, 640, 16, 26, 1, 1, 0), (640, 160, 16, 26, 1, 1, 0), (640, 160, 16, 26, 1, 1, 1), (160, 640, 16, 26, 1, 1, 1),
+    (256, 1024, 8, 13, 1, 1, 0), (1024, 256, 8, 13, 1, 1, 0), (128, 128, 32, 52, 1, 1, 0), (160, 160, 16, 26, 1, 1, 0),
+    (160, 160, 16, 26, 2, 2, 0), (128, 128, 32, 52, 4, 4, 0)]
 NSET, REPS = 12, 120
 STATS = len(sys.argv) > 1 and sys.argv[1] == "stats"
 for Cin, Cout, H, W, k, s, mode in SHAPES:

@@ -260,36 +260,40 @@ __global__ __launch_bounds__(TPB) void k_sigmoid_bwd(const bf16_t* a, bf16_t* da
 __global__ __launch_bounds__(TPB) void k_head2_fwd(const bf16_t* a, const float* w, const float* bias, int H, int W,
                                                    float* depth, bf16_t* copy, int copy_ld) {
   const int b = blockIdx.y, q = threadIdx.x & 3;
+  // the 72 weights of this lane's 8 channels: loaded once, the thread then walks over many pixels (one pixel per thread
+  // spent 8x more loads on the weights than on the data)
   float wv[9][8];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int j = 0; j < 8; ++j) wv[t][j] = bf_round(w[(q * 8 + j) * 9 + t]);
-  const long long pix = ((long long)blockIdx.x * TPB + threadIdx.x) >> 2;
-  const bool ok = pix < (long long)H * W;
-  const int py = ok ? (int)(pix / W) : 0, px = ok ? (int)(pix - (long long)py * W) : 0;
+  const float bias0 = bias[0];
   const bf16_t* ab = a + (long long)b * H * W * 32 + q * 8;
-  float acc = 0.f;
+  const int npix = H * W, stride = (gridDim.x * TPB) >> 2;
+  for (int pix = (blockIdx.x * TPB + threadIdx.x) >> 2; pix < npix; pix += stride) {     // uniform per 4-lane pixel group
+    const int py = pix / W, px = pix - py * W;
+    float acc = 0.f;
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = py + ky - 1;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = py + ky - 1;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ix = px + kx - 1;
-      if (ok && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-        float v[8];
-        load8(ab, ((long long)iy * W + ix) * 32, 0, v);
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = px + kx - 1;
+        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+          float v[8];
+          load8(ab, ((long long)iy * W + ix) * 32, 0, v);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += v[j] * wv[ky * 3 + kx][j];
+          for (int j = 0; j < 8; ++j) acc += v[j] * wv[ky * 3 + kx][j];
+        }
       }
     }
-  }
-  acc += __shfl_xor(acc, 1);
-  acc += __shfl_xor(acc, 2);
-  if (ok && q == 0) {
-    const float r = bf_round(acc + bias[0]);
-    depth[(long long)b * H * W + pix] = r;
-    if (copy) copy[((long long)b * H * W + pix) * copy_ld] = f2bf(r);
+    acc += __shfl_xor(acc, 1);
+    acc += __shfl_xor(acc, 2);
+    if (q == 0) {
+      const float r = bf_round(acc + bias0);
+      depth[(long long)b * npix + pix] = r;
+      if (copy) copy[((long long)b * npix + pix) * copy_ld] = f2bf(r);
+    }
   }
 }
 
@@ -297,36 +301,42 @@ __global__ __launch_bounds__(TPB) void k_head2_fwd(const bf16_t* a, const float*
 __global__ __launch_bounds__(TPB) void k_head2_bwd_data(const float* gd, const bf16_t* add, int add_ld, const bf16_t* a,
                                                         const float* w, int H, int W, bf16_t* dz) {
   const int b = blockIdx.y, q = threadIdx.x & 3;
-  const long long pix = ((long long)blockIdx.x * TPB + threadIdx.x) >> 2;
-  if (pix >= (long long)H * W) return;
-  const int py = (int)(pix / W), px = (int)(pix - (long long)py * W);
+  float wv[9][8];                                           // loaded once per thread, as in k_head2_fwd
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wv[t][j] = bf_round(w[(q * 8 + j) * 9 + t]);
   const float* gb = gd + (long long)b * H * W;
   const bf16_t* addb = add ? add + (long long)b * H * W * add_ld : nullptr;
-  float acc[8];
+  const int npix = H * W, stride = (gridDim.x * TPB) >> 2;
+  for (int pix = (blockIdx.x * TPB + threadIdx.x) >> 2; pix < npix; pix += stride) {
+    const int py = pix / W, px = pix - py * W;
+    float acc[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int oy = py + 1 - ky;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int oy = py + 1 - ky;
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      const int ox = px + 1 - kx;
-      if ((unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W) {
-        const long long o = (long long)oy * W + ox;
-        float dyv = gb[o];
-        if (addb) dyv += bf2f(addb[o * add_ld]);
-        dyv = bf_round(dyv);
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ox = px + 1 - kx;
+        if ((unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W) {
+          const long long o = (long long)oy * W + ox;
+          float dyv = gb[o];
+          if (addb) dyv += bf2f(addb[o * add_ld]);
+          dyv = bf_round(dyv);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc[j] += dyv * bf_round(w[(q * 8 + j) * 9 + ky * 3 + kx]);
+          for (int j = 0; j < 8; ++j) acc[j] += dyv * wv[ky * 3 + kx][j];
+        }
       }
     }
-  }
-  float av[8];
-  const long long off = ((long long)b * H * W + pix) * 32 + q * 8;
-  load8(a, off, 0, av);
+    float av[8];
+    const long long off = ((long long)b * npix + pix) * 32 + q * 8;
+    load8(a, off, 0, av);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) acc[j] *= av[j] * (1.f - av[j]);
-  store8_bf16(dz, off, acc);
+    for (int j = 0; j < 8; ++j) acc[j] *= av[j] * (1.f - av[j]);
+    store8_bf16(dz, off, acc);
+  }
 }
 
 // rows[r][c*9 + tap] += sum_p dy[p] * a[p + off(tap)][c] ; rows[r][288] += sum_p dy[p], r = workgroup % replicas.
@@ -468,6 +478,14 @@ __global__ __launch_bounds__(TPB) void k_bicubic_bwd_tile(const bf16_t* dy, int 
   }
 }
 
+// workgroups per sample of the head stencil kernels: 4 lanes per pixel, ~8+ pixels per thread on large grids
+inline int head2_blocks(int H, int W, int B) {
+  long long n = cdiv(4ll * H * W, TPB);
+  long long cap = 4096 / (B > 0 ? B : 1);
+  if (cap < 1) cap = 1;
+  return (int)(n > cap ? cap : n);
+}
+
 inline int blocks_for(long long total) {
   long long n = (total + TPB - 1) / TPB;
   if (n > 4096) n = 4096;
@@ -574,7 +592,7 @@ extern "C" int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, i
 extern "C" int crd_head_conv2_fwd(const void* a, const float* w, const float* bias, int32_t B, int32_t H, int32_t W, float* depth,
                                   void* copy, int32_t copy_ld, int32_t copy_coff, crd_stream_t stream) {
   CRD_CHECK_ARG(a && w && bias && depth, "crd_head_conv2_fwd: null pointer");
-  hipLaunchKernelGGL(k_head2_fwd, dim3((unsigned)cdiv(4ll * H * W, TPB), B), dim3(TPB), 0, as_stream(stream),
+  hipLaunchKernelGGL(k_head2_fwd, dim3((unsigned)head2_blocks(H, W, B), B), dim3(TPB), 0, as_stream(stream),
                      reinterpret_cast<const bf16_t*>(a), w, bias, H, W, depth,
                      copy ? reinterpret_cast<bf16_t*>(copy) + copy_coff : nullptr, copy_ld);
   CRD_LAUNCH_CHECK("crd_head_conv2_fwd");
@@ -587,7 +605,7 @@ extern "C" int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_
   CRD_CHECK_ARG(gd && a && w && dz && dw_rows && replicas >= 1, "crd_head_conv2_bwd: null pointer / replicas < 1");
   const bf16_t* addp = add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_head2_bwd_data, dim3((unsigned)cdiv(4ll * H * W, TPB), B), dim3(TPB), 0, st, gd, addp, add_ld,
+  hipLaunchKernelGGL(k_head2_bwd_data, dim3((unsigned)head2_blocks(H, W, B), B), dim3(TPB), 0, st, gd, addp, add_ld,
                      reinterpret_cast<const bf16_t*>(a), w, H, W, reinterpret_cast<bf16_t*>(dz));
   const int P = H * W;
   int nblk = cdiv(P, 64 * 4);

@@ -22,40 +22,54 @@ __device__ __forceinline__ void taps_of(int o, int n, int (&idx)[4], float (&w)[
   }
 }
 
+// One thread produces the 2 x 2 outputs above input pixel (k, m) for 8 channels: they share the clamped 5 x 5 input
+// neighbourhood (25 loads instead of 4 x 16), horizontal pass first (even / odd column results of the five rows), then
+// the vertical one -- the same order of operations as the one-output-per-thread form it replaces.
 __global__ __launch_bounds__(TPB) void k_bicubic(const bf16_t* x, int x_ld, int H, int W, int C, bf16_t* y, int y_ld) {
   const int b = blockIdx.y;
   const int CG = C >> 3;
-  const int OH = 2 * H, OW = 2 * W;
-  const long long total = (long long)OH * OW * CG;
+  const int OW = 2 * W;
+  const long long total = (long long)H * W * CG;
   const long long i = (long long)blockIdx.x * TPB + threadIdx.x;
   if (i >= total) return;
   const int cg = (int)(i % CG);
   const int pix = (int)(i / CG);
-  const int oy = pix / OW, ox = pix - oy * OW;
-  int iy[4], ix[4];
-  float wy[4], wx[4];
-  taps_of(oy, H, iy, wy);
-  taps_of(ox, W, ix, wx);
+  const int k = pix / W, m = pix - k * W;
   const bf16_t* xb = x + (long long)b * H * W * x_ld + cg * 8;
-  float out[8];
+  int cx[5];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) out[j] = 0.f;
+  for (int c = 0; c < 5; ++c) { const int ix = m - 2 + c; cx[c] = ix < 0 ? 0 : (ix > W - 1 ? W - 1 : ix); }
+  float he[5][8], ho[5][8];
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float row[8];
+  for (int r = 0; r < 5; ++r) {
+    int iy = k - 2 + r;
+    iy = iy < 0 ? 0 : (iy > H - 1 ? H - 1 : iy);
+    float v[5][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) row[j] = 0.f;
+    for (int c = 0; c < 5; ++c) load8(xb, ((long long)iy * W + cx[c]) * x_ld, 0, v[c]);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float v[8];
-      load8(xb, ((long long)iy[r] * W + ix[c]) * x_ld, 0, v);
+    for (int j = 0; j < 8; ++j) { he[r][j] = 0.f; ho[r][j] = 0.f; }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) row[j] += wx[c] * v[j];
-    }
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[j] += wy[r] * row[j];
+      for (int j = 0; j < 8; ++j) { he[r][j] += WE[t] * v[t][j]; ho[r][j] += WO[t] * v[t + 1][j]; }
   }
-  store8_bf16(y, ((long long)b * OH * OW + pix) * y_ld + cg * 8, out);
+  bf16_t* yb = y + ((long long)b * 2 * H * OW) * y_ld + cg * 8;
+#pragma unroll
+  for (int oy = 0; oy < 2; ++oy)
+#pragma unroll
+    for (int ox = 0; ox < 2; ++ox) {
+      float out[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[j] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float wy = oy ? WO[t] : WE[t];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] += wy * (ox ? ho[t + oy][j] : he[t + oy][j]);
+      }
+      store8_bf16(yb, ((long long)(2 * k + oy) * OW + 2 * m + ox) * y_ld, out);
+    }
 }
 
 // transpose: dx[iy][ix] (+)= sum_{oy,ox} By[oy][iy]*Bx[ox][ix]*dy[oy][ox]; candidates o in [2i-4, 2i+5]
@@ -500,7 +514,7 @@ extern "C" int crd_bicubic2x(const void* x, int32_t x_ld, int32_t x_coff, int32_
   CRD_CHECK_ARG(x && y, "crd_bicubic2x: null pointer");
   CRD_CHECK_ARG(C % 8 == 0 && x_ld % 8 == 0 && x_coff % 8 == 0 && y_ld % 8 == 0 && y_coff % 8 == 0, "crd_bicubic2x: alignment");
   const long long total = 4ll * H * W * (C / 8);
-  hipLaunchKernelGGL(k_bicubic, dim3((unsigned)cdiv(total, TPB), B), dim3(TPB), 0, as_stream(stream),
+  hipLaunchKernelGGL(k_bicubic, dim3((unsigned)cdiv(total / 4, TPB), B), dim3(TPB), 0, as_stream(stream),
                      reinterpret_cast<const bf16_t*>(x) + x_coff, x_ld, H, W, C, reinterpret_cast<bf16_t*>(y) + y_coff, y_ld);
   CRD_LAUNCH_CHECK("crd_bicubic2x");
   return CRD_OK;

@@ -649,13 +649,32 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
   // retire about one lane every few cycles): counting-sort the chunk's pixels by (head, key), then the thread that owns
   // (key m, granule cg) adds up the q rows of the pixels routed to m.
   __syncthreads();
-  if ((int)threadIdx.x < heads) {                    // exclusive offsets, one head per thread (M ~ 100 serial adds)
-    int run = threadIdx.x * chunk;                   // head h's list occupies lst[h*chunk ...]
-    for (int m = 0; m < M; ++m) {
-      const int c = cnt[threadIdx.x * M + m];
-      off[threadIdx.x * M + m] = run;
-      cnt[threadIdx.x * M + m] = run;                // fill cursor
-      run += c;
+  {   // exclusive offsets: one wave per head, a lane owns `per` consecutive keys, shuffle scan over the lanes (the serial
+      // form -- one thread per head, M dependent LDS round trips -- was ~5 us of every launch)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int per = (M + 63) >> 6;
+    for (int h = wave; h < heads; h += TPB / 64) {
+      int loc = 0;
+      for (int i = 0; i < per; ++i) {
+        const int m = lane * per + i;
+        if (m < M) loc += cnt[h * M + m];
+      }
+      int incl = loc;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(incl, o);
+        if (lane >= o) incl += v;
+      }
+      int run = h * chunk + incl - loc;              // head h's list occupies lst[h*chunk ...]
+      for (int i = 0; i < per; ++i) {
+        const int m = lane * per + i;
+        if (m < M) {
+          const int c = cnt[h * M + m];
+          off[h * M + m] = run;
+          cnt[h * M + m] = run;                      // fill cursor
+          run += c;
+        }
+      }
     }
   }
   if (threadIdx.x == 0) off[HM] = 0;
@@ -851,7 +870,16 @@ static size_t attn_bwd_lds(int chunk, int M, int heads, int C) {
 }
 // workgroups per sample of the chunked (LDS) path; 0: a chunk does not fit in LDS, the global-atomics path runs
 static int attn_bwd_blocks(int B, int N, int M, int heads, int C) {
-  int nblk = cdiv(N, 128);
+  // pixels per workgroup: 128; 32 (N <= 512) or 64 on grids that would leave most CUs without a workgroup (N = 104 / 416 /
+  // 1664 per sample gave 8 / 32 / 104 workgroups): 24.87 -> 24.53 ms per step, the extra partial copies included
+  static int small = -1, mid = -1;
+  if (small < 0) {
+    const char* e = getenv("CRD_ATTN_BWD_CHUNK"); small = e ? atoi(e) : 32;
+    e = getenv("CRD_ATTN_BWD_CHUNK2"); mid = e ? atoi(e) : 64;
+  }
+  int target = 128;
+  if ((long long)B * cdiv(N, 128) < 128) target = N <= 512 ? small : mid;
+  int nblk = cdiv(N, target);
   int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   const int chunk = cdiv(N, nblk);

@@ -853,7 +853,9 @@ extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S
                                 int32_t C, float* t, float* dbp_rows, float* dS, crd_stream_t stream) {
   CRD_CHECK_ARG(dx1 && u && S && t && dbp_rows && dS, "crd_attn_out_bwd: null pointer");
   CRD_UNSUPPORTED(C % 8 == 0 && C <= 512, "crd_attn_out_bwd: C must be a multiple of 8 and <= 512");
-  int nblk = cdiv(N, 256);
+  static int small = -1;
+  if (small < 0) { const char* e = getenv("CRD_ATTN_OUT_BWD_CHUNK"); small = e ? atoi(e) : 32; }
+  int nblk = cdiv(N, (long long)B * cdiv(N, 256) < 128 ? small : 256);     // fewer pixels per workgroup on small grids
   int cap = 1024 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   int chunk = cdiv(N, nblk);

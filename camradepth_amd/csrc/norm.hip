@@ -295,8 +295,9 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
                                                       void* dx, int dx_f32, int dx_ld, int dx_acc, int B, void* dx2, int dx2_ld,
                                                       const float* scale2) {
   const int b = blockIdx.y;
-  if (blockIdx.x == 0 && b == 0 && dgamma) {
-    for (int c = threadIdx.x; c < C; c += TPB) {
+  if (b == 0 && dgamma) {     // parameter gradients: the workgroups of sample 0 share the channels (one workgroup doing all
+                              // of them put B x C dependent loads in front of its own pixels: +5 us on the small grids)
+    for (int c = blockIdx.x * TPB + threadIdx.x; c < C; c += gridDim.x * TPB) {
       float g0 = 0.f, g1 = 0.f;
       for (int bb = 0; bb < B; ++bb) { g0 += r[((long long)bb * C + c) * 2]; g1 += r[((long long)bb * C + c) * 2 + 1]; }
       dbeta[c] += g0;

@@ -463,18 +463,18 @@ __global__ __launch_bounds__(TPB) void k_attn_xbar_proj(const float* chan, const
 
 // Backward: tb = bf16(t); es[b][ci] = inv_n * sum_co W[co][ci] * tb[b][co], with wt the proj weight in its packed bf16
 // data-gradient form [C][Cpad] (row ci, contiguous over co).
-__global__ __launch_bounds__(TPB) void k_attn_vec_bwd(const float* t, const bf16_t* wt, int C, int Cpad, float inv_n, bf16_t* tb,
-                                                      float* es) {
+struct VecBwd { const float* t; const bf16_t* wt; int C, Cpad; float inv_n; bf16_t* tb; float* es; };
+__device__ __forceinline__ void attn_vec_bwd_body(const VecBwd& v, int b) {
   __shared__ float st[1024];
-  const int b = blockIdx.x;
+  const int C = v.C;
   for (int c = threadIdx.x; c < C; c += TPB) {
-    const bf16_t q = f2bf(t[(long long)b * C + c]);
-    tb[(long long)b * C + c] = q;
+    const bf16_t q = f2bf(v.t[(long long)b * C + c]);
+    v.tb[(long long)b * C + c] = q;
     st[c] = bf2f(q);
   }
   __syncthreads();
   for (int ci = threadIdx.x; ci < C; ci += TPB) {
-    const bf16_t* wr = wt + (long long)ci * Cpad;
+    const bf16_t* wr = v.wt + (long long)ci * v.Cpad;
     float acc = 0.f;
     for (int co = 0; co < C; co += 8) {
       float wv[8];
@@ -482,9 +482,10 @@ __global__ __launch_bounds__(TPB) void k_attn_vec_bwd(const float* t, const bf16
 #pragma unroll
       for (int j = 0; j < 8; ++j) acc += wv[j] * st[co + j];
     }
-    es[(long long)b * C + ci] = acc * inv_n;
+    v.es[(long long)b * C + ci] = acc * v.inv_n;
   }
 }
+__global__ __launch_bounds__(TPB) void k_attn_vec_bwd(VecBwd v) { attn_vec_bwd_body(v, blockIdx.x); }
 
 // x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])
 __global__ __launch_bounds__(TPB) void k_attn_out_residual(const float* x, const float* u, const float* S, const float* bp,
@@ -576,11 +577,14 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
 // dq[b][n][c] = scale*dS[b][n]*k[b][idx[b][n][h(c)]][c] ; dk[b][m][c] += scale*dS[b][n]*q[b][n][c]
 __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const bf16_t* k, const float* dS, const short* idx,
                                                          long long N, int M, int heads, int d, float scale, int chunk,
-                                                         bf16_t* dq, float* dk, int use_lds, float* dk_part) {
+                                                         bf16_t* dq, float* dk, int use_lds, float* dk_part, VecBwd vec) {
   // LDS (use_lds): the workgroup's pixel chunk -- q rows [chunk][CG] (16-byte granules), g = scale*dS [chunk], and a
   // counting sort of the pixels by (head, arg-max key): count / offset / cursor [heads*M] ints, lists [heads][chunk] shorts
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
+  // one extra workgroup per sample runs the rank-one vector path of the same backward step (crd_attn_bwd: it depends on
+  // the same producer, crd_attn_out_bwd, and a launch of its own cost more than its work)
+  if (vec.t && blockIdx.x == gridDim.x - 1) { attn_vec_bwd_body(vec, b); return; }
   const int C = heads * d, CG = C >> 3;
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > N) p1 = N;
@@ -831,8 +835,8 @@ extern "C" int crd_attn_vec_bwd(const float* t, const void* w_dgrad, int32_t B, 
                                 crd_stream_t stream) {
   CRD_CHECK_ARG(t && w_dgrad && tb && es, "crd_attn_vec_bwd: null pointer");
   CRD_UNSUPPORTED(C % 8 == 0 && C <= 1024 && Cpad >= C && Cpad % 8 == 0, "crd_attn_vec_bwd: C must be a multiple of 8, <= 1024");
-  hipLaunchKernelGGL(k_attn_vec_bwd, dim3(B), dim3(TPB), 0, as_stream(stream), t, reinterpret_cast<const bf16_t*>(w_dgrad), C, Cpad,
-                     inv_n, reinterpret_cast<bf16_t*>(tb), es);
+  hipLaunchKernelGGL(k_attn_vec_bwd, dim3(B), dim3(TPB), 0, as_stream(stream),
+                     VecBwd{t, reinterpret_cast<const bf16_t*>(w_dgrad), C, Cpad, inv_n, reinterpret_cast<bf16_t*>(tb), es});
   CRD_LAUNCH_CHECK("crd_attn_vec_bwd");
   return CRD_OK;
 }
@@ -893,17 +897,17 @@ extern "C" int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int
   return attn_bwd_blocks(B, N, M, heads, heads * d);
 }
 
-extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
-                                   int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
-                                   crd_stream_t stream) {
-  CRD_CHECK_ARG(q && k && dS && idx && dq && (dk || dk_partials), "crd_attn_scores_bwd: null pointer");
-  CRD_CHECK_ARG(d % 8 == 0, "crd_attn_scores_bwd: head dim must be a multiple of 8");
+static int attn_scores_bwd_launch(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
+                                  int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
+                                  const VecBwd& vec, const char* who, crd_stream_t stream) {
+  CRD_CHECK_ARG(q && k && dS && idx && dq && (dk || dk_partials), "%s: null pointer", who);
+  CRD_CHECK_ARG(d % 8 == 0, "%s: head dim must be a multiple of 8", who);
   const int C = heads * d;
   // the chunked path (q rows of <= 128 pixels staged in LDS, counting sort by key, owner-computes dK) runs whenever the
   // chunk fits; the fallback adds every contribution to global memory with an atomic of its own
   int nblk = attn_bwd_blocks(B, N, M, heads, C);
   const int use_lds = nblk > 0;
-  CRD_CHECK_ARG(use_lds ? (dk_partials || dk) : dk != nullptr, "crd_attn_scores_bwd: this shape needs the dk accumulator");
+  CRD_CHECK_ARG(use_lds ? (dk_partials || dk) : dk != nullptr, "%s: this shape needs the dk accumulator", who);
   static bool attr_done = false;
   if (!attr_done) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_scores_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -917,12 +921,29 @@ extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS
   int chunk = cdiv(N, nblk);
   nblk = cdiv(N, chunk);
   const size_t lds = attn_bwd_lds(chunk, M, heads, C);
-  hipLaunchKernelGGL(k_attn_scores_bwd, dim3(nblk, B), dim3(TPB), use_lds ? lds : 0, as_stream(stream),
+  hipLaunchKernelGGL(k_attn_scores_bwd, dim3(nblk + (vec.t ? 1 : 0), B), dim3(TPB), use_lds ? lds : 0, as_stream(stream),
                      reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), dS, reinterpret_cast<const short*>(idx),
                      (long long)N, M, heads, d, scale, chunk, reinterpret_cast<bf16_t*>(dq), dk, use_lds,
-                     use_lds ? dk_partials : nullptr);
-  CRD_LAUNCH_CHECK("crd_attn_scores_bwd");
+                     use_lds ? dk_partials : nullptr, vec);
+  CRD_LAUNCH_CHECK(who);
   return CRD_OK;
+}
+
+extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
+                                   int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
+                                   crd_stream_t stream) {
+  return attn_scores_bwd_launch(q, k, dS, idx, B, N, M, heads, d, scale, dq, dk, dk_partials, VecBwd{}, "crd_attn_scores_bwd", stream);
+}
+
+extern "C" int crd_attn_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N, int32_t M,
+                            int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials, const float* t,
+                            const void* w_dgrad, int32_t Cpad, float inv_n, void* tb, float* es, crd_stream_t stream) {
+  CRD_CHECK_ARG(t && w_dgrad && tb && es, "crd_attn_bwd: null pointer");
+  const int C = heads * d;
+  CRD_UNSUPPORTED(C <= 1024 && Cpad >= C && Cpad % 8 == 0, "crd_attn_bwd: C must be <= 1024");
+  return attn_scores_bwd_launch(q, k, dS, idx, B, N, M, heads, d, scale, dq, dk, dk_partials,
+                                VecBwd{t, reinterpret_cast<const bf16_t*>(w_dgrad), C, Cpad, inv_n, reinterpret_cast<bf16_t*>(tb), es},
+                                "crd_attn_bwd", stream);
 }
 
 extern "C" int crd_sum_partials_bf16(const float* part, int32_t replicas, int64_t replica_stride, void* dst, int64_t n,

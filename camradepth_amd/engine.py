@@ -768,9 +768,9 @@ class Plan:
         self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
         Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
-        with self.side(2):       # rank-one vector path, needed again only as the bias of the q data gradient
-            self._emit(g, "crd_attn_vec_bwd", [T, _WPtr(cp, "w_dgrad"), B, Cs, cp.cout_pad, 1.0 / N, Tb.t, Es.t])   # Es = d(xbar)/N
-            self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
+        # rank-one vector path (Tb = bf16(T), Es = d(xbar)/N: the bias of the q data gradient) rides in the launch of the
+        # score backward: both consume attn_out_bwd's outputs.
+        vec = [T, _WPtr(cp, "w_dgrad"), cp.cout_pad, 1.0 / N, Tb.t, Es.t]
         # dK: per-workgroup partial accumulators (plain stores) folded by the bf16 conversion below; fp32-atomic
         # accumulation into one buffer only when [M][C] does not fit in LDS
         nparts = self.lib.crd_attn_scores_bwd_partials(B, N, M, heads, dh)
@@ -778,12 +778,12 @@ class Plan:
             if self.attn_parts is None or self.attn_parts.numel() < nparts * B * M * Cs:
                 self.attn_parts = self.new((nparts * B * M * Cs,), F32)     # shared scratch: produced and consumed back to back
             dK = None
-            self._emit(g, "crd_attn_scores_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, None, self.attn_parts])
+            self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, None, self.attn_parts] + vec)
         else:
             dK = self.zb(B, M, Cs)
-            self._emit(g, "crd_attn_scores_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None])
+            self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None] + vec)
+        self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
         self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".q.bias"))
-        self.join(g, 2)
         self.conv(g, self.conv_desc(DQ, ("dgrad", cq), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, bias=Es.t, bias_bstride=Cs))
         DKb = self.act(Cs, Hs // sr, Ws // sr)
         if dK is None:

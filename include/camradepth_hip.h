@@ -231,6 +231,11 @@ int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int32_t heads,
 int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
                         int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
                         crd_stream_t stream);
+/* crd_attn_scores_bwd and crd_attn_vec_bwd in ONE launch (both consume crd_attn_out_bwd's outputs; one extra workgroup per
+ * sample runs the vector path): arguments as in the two calls, C = heads * d. */
+int crd_attn_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N, int32_t M,
+                 int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials, const float* t,
+                 const void* w_dgrad, int32_t Cpad, float inv_n, void* tb, float* es, crd_stream_t stream);
 /* dst[i] = bf16(sum_{r < replicas} part[r*replica_stride + i]), i < n (n, replica_stride multiples of 8) */
 int crd_sum_partials_bf16(const float* part, int32_t replicas, int64_t replica_stride, void* dst, int64_t n,
                           crd_stream_t stream);

@@ -338,6 +338,19 @@ def test_attention_scores_and_backward(N, M, heads, d):
     dkb = torch.zeros(B, M, C_, dtype=torch.bfloat16, device="cuda")
     ok(lb.crd_sum_partials_bf16(P(parts), nparts, B * M * C_, P(dkb), B * M * C_, lib.stream()), "sum_partials")
     assert_close(dkb.float().cpu(), bf(dk_ref.reshape(B, M, C_)), "dk from partials (bf16)", rel=4e-3, elem=1e-2)
+    # fused launch: the same plus the rank-one vector path (crd_attn_vec_bwd) in one extra workgroup per sample
+    t = torch.randn(B, C_, generator=g).cuda()
+    wd = torch.zeros(C_, C_ + 8, dtype=torch.bfloat16, device="cuda")
+    wd[:, :C_] = (0.2 * torch.randn(C_, C_, generator=g)).to(torch.bfloat16)
+    tb0, es0 = torch.zeros(B, C_, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, C_, device="cuda")
+    ok(lb.crd_attn_vec_bwd(P(t), P(wd), B, C_, C_ + 8, 1.0 / N, P(tb0), P(es0), lib.stream()), "attn_vec_bwd")
+    parts3 = torch.full((nparts, B, M, C_), float("nan"), device="cuda")
+    dq3, tb1, es1 = torch.zeros_like(dq), torch.zeros_like(tb0), torch.zeros_like(es0)
+    ok(lb.crd_attn_bwd(P(qd), P(kd), P(dSc), P(idx), B, N, M, heads, d, scale, P(dq3), None, P(parts3), P(t), P(wd), C_ + 8,
+                       1.0 / N, P(tb1), P(es1), lib.stream()), "attn_bwd (fused)")
+    assert torch.equal(dq3, dq) and torch.equal(tb1, tb0) and torch.equal(es1, es0)
+    # (the order of a key's pixel list comes from LDS atomics: dK partials agree to rounding, not bit for bit)
+    assert_close(parts3.sum(0).cpu(), parts.sum(0).cpu(), "dk partials (fused launch)", rel=1e-5, elem=1e-5)
 
 
 def test_attention_output_path():

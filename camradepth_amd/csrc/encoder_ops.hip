@@ -340,6 +340,34 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
   }
 }
 
+// Rank-one value path of the attention forward (documented at k_attn_xbar_proj below); also run by one extra workgroup
+// per sample of k_attn_scores (crd_attn_fwd), hence blockDim-strided.
+struct XbarProj { const float* chan; const float* stats; const float* gamma; const float* beta; const bf16_t* w; int N, C; bf16_t* xbar; float* u; };
+__device__ __forceinline__ void attn_xbar_proj_body(const XbarProj& x, int b) {
+  __shared__ float sx[1024];
+  const int C = x.C, N = x.N, nt = blockDim.x;
+  for (int c = threadIdx.x; c < C; c += nt) {
+    float mean, rstd;
+    gn_mean_rstd(x.stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
+    const float mc = x.chan[((long long)b * C + c) * 2] / (float)N;
+    const bf16_t q = f2bf(x.gamma[c] * (mc - mean) * rstd + x.beta[c]);
+    x.xbar[(long long)b * C + c] = q;
+    sx[c] = bf2f(q);
+  }
+  __syncthreads();
+  for (int co = threadIdx.x; co < C; co += nt) {
+    const bf16_t* wr = x.w + (long long)co * C;
+    float acc = 0.f;
+    for (int ci = 0; ci < C; ci += 8) {
+      float wv[8];
+      load8(wr, ci, 0, wv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc += wv[j] * sx[ci + j];
+    }
+    x.u[(long long)b * C + co] = acc;
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Attention scores: per head h,  s[n] = max_m bf16(bf16(q_n . k_m) * scale)  (the reference's
 // autocast rounding points), S[n] = sum_h s_h[n].  MFMA operands are swapped -- A = K tile (rows =
@@ -351,9 +379,10 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
 // per-head chain of dependent loads runs in parallel across the waves instead of serially inside one (stage 4: 8 heads);
 // the heads' maxima of a query group meet in LDS.
 __global__ __launch_bounds__(1024) void k_attn_scores(const bf16_t* q, const bf16_t* k, int N, int M, int heads, int d,
-                                                      float scale, float* S, short* idx, int qg) {
+                                                      float scale, float* S, short* idx, int qg, XbarProj xp) {
   __shared__ float smax[16][32];
   const int b = blockIdx.y;
+  if (xp.chan && blockIdx.x == gridDim.x - 1) { attn_xbar_proj_body(xp, b); return; }     // crd_attn_fwd: the value path
   const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = wave % heads, g = wave / heads;
   const int n0 = (blockIdx.x * qg + g) * 32;
@@ -435,31 +464,7 @@ __global__ void k_attn_xbar(const float* chan, const float* stats, const float* 
 // conversion + [B,1,C] data-gradient "conv" + a scale: three to four dependent dispatches of a few hundred threads).
 // Forward: xbar[b][c] = bf16(mean_n GroupNorm(x)[b][n][c]) (as k_attn_xbar), u[b][co] = sum_ci W[co][ci] * xbar[b][ci]
 // with W the proj weight in its packed bf16 forward form [C][C] (bf16 products, fp32 accumulation, as the MFMA path).
-__global__ __launch_bounds__(TPB) void k_attn_xbar_proj(const float* chan, const float* stats, const float* gamma, const float* beta,
-                                                        const bf16_t* w, int N, int C, bf16_t* xbar, float* u) {
-  __shared__ float sx[1024];
-  const int b = blockIdx.x;
-  for (int c = threadIdx.x; c < C; c += TPB) {
-    float mean, rstd;
-    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
-    const float mc = chan[((long long)b * C + c) * 2] / (float)N;
-    const bf16_t q = f2bf(gamma[c] * (mc - mean) * rstd + beta[c]);
-    xbar[(long long)b * C + c] = q;
-    sx[c] = bf2f(q);
-  }
-  __syncthreads();
-  for (int co = threadIdx.x; co < C; co += TPB) {
-    const bf16_t* wr = w + (long long)co * C;
-    float acc = 0.f;
-    for (int ci = 0; ci < C; ci += 8) {
-      float wv[8];
-      load8(wr, ci, 0, wv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc += wv[j] * sx[ci + j];
-    }
-    u[(long long)b * C + co] = acc;
-  }
-}
+__global__ __launch_bounds__(TPB) void k_attn_xbar_proj(XbarProj x) { attn_xbar_proj_body(x, blockIdx.x); }
 
 // Backward: tb = bf16(t); es[b][ci] = inv_n * sum_co W[co][ci] * tb[b][co], with wt the proj weight in its packed bf16
 // data-gradient form [C][Cpad] (row ci, contiguous over co).
@@ -797,19 +802,35 @@ extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int
   return CRD_OK;
 }
 
-extern "C" int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
-                               float scale, float* S, int16_t* idx, crd_stream_t stream) {
-  CRD_CHECK_ARG(q && k && S && idx, "crd_attn_scores: null pointer");
-  CRD_UNSUPPORTED(d % 8 == 0 && d <= 64 && M < 32768, "crd_attn_scores: head dim must be a multiple of 8, <= 64 (got %d)", d);
-  CRD_UNSUPPORTED(heads >= 1 && heads <= 16, "crd_attn_scores: at most 16 heads (got %d)", heads);
+static int attn_scores_launch(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d, float scale,
+                              float* S, int16_t* idx, const XbarProj& xp, const char* who, crd_stream_t stream) {
+  CRD_CHECK_ARG(q && k && S && idx, "%s: null pointer", who);
+  CRD_UNSUPPORTED(d % 8 == 0 && d <= 64 && M < 32768, "%s: head dim must be a multiple of 8, <= 64 (got %d)", who, d);
+  CRD_UNSUPPORTED(heads >= 1 && heads <= 16, "%s: at most 16 heads (got %d)", who, heads);
   int qg = 8 / heads;                      // query groups per workgroup: ~8 waves, at most 16
   if (qg < 1) qg = 1;
   if (qg > 4) qg = 4;
-  dim3 grid(cdiv(N, 32 * qg), B);
+  dim3 grid(cdiv(N, 32 * qg) + (xp.chan ? 1 : 0), B);
   hipLaunchKernelGGL(k_attn_scores, grid, dim3(64 * heads * qg), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(q),
-                     reinterpret_cast<const bf16_t*>(k), N, M, heads, d, scale, S, idx, qg);
-  CRD_LAUNCH_CHECK("crd_attn_scores");
+                     reinterpret_cast<const bf16_t*>(k), N, M, heads, d, scale, S, idx, qg, xp);
+  CRD_LAUNCH_CHECK(who);
   return CRD_OK;
+}
+
+extern "C" int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
+                               float scale, float* S, int16_t* idx, crd_stream_t stream) {
+  return attn_scores_launch(q, k, B, N, M, heads, d, scale, S, idx, XbarProj{}, "crd_attn_scores", stream);
+}
+
+extern "C" int crd_attn_fwd(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d, float scale,
+                            float* S, int16_t* idx, const float* chan_sums, const float* stats, const float* gamma,
+                            const float* beta, const void* w_fwd, void* xbar, float* u, crd_stream_t stream) {
+  CRD_CHECK_ARG(chan_sums && stats && gamma && beta && w_fwd && xbar && u, "crd_attn_fwd: null pointer");
+  const int C = heads * d;
+  CRD_UNSUPPORTED(C % 16 == 0 && C <= 1024, "crd_attn_fwd: C must be a multiple of 16, <= 1024");
+  return attn_scores_launch(q, k, B, N, M, heads, d, scale, S, idx,
+                            XbarProj{chan_sums, stats, gamma, beta, reinterpret_cast<const bf16_t*>(w_fwd), N, C,
+                                     reinterpret_cast<bf16_t*>(xbar), u}, "crd_attn_fwd", stream);
 }
 
 extern "C" int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma, const float* beta, int32_t B,
@@ -825,8 +846,8 @@ extern "C" int crd_attn_xbar_proj(const float* chan_sums, const float* stats, co
                                   int32_t B, int32_t N, int32_t C, void* xbar, float* u, crd_stream_t stream) {
   CRD_CHECK_ARG(chan_sums && stats && gamma && beta && w_fwd && xbar && u, "crd_attn_xbar_proj: null pointer");
   CRD_UNSUPPORTED(C % 16 == 0 && C <= 1024, "crd_attn_xbar_proj: C must be a multiple of 16, <= 1024");
-  hipLaunchKernelGGL(k_attn_xbar_proj, dim3(B), dim3(TPB), 0, as_stream(stream), chan_sums, stats, gamma, beta,
-                     reinterpret_cast<const bf16_t*>(w_fwd), N, C, reinterpret_cast<bf16_t*>(xbar), u);
+  hipLaunchKernelGGL(k_attn_xbar_proj, dim3(B), dim3(TPB), 0, as_stream(stream),
+                     XbarProj{chan_sums, stats, gamma, beta, reinterpret_cast<const bf16_t*>(w_fwd), N, C, reinterpret_cast<bf16_t*>(xbar), u});
   CRD_LAUNCH_CHECK("crd_attn_xbar_proj");
   return CRD_OK;
 }

@@ -686,10 +686,7 @@ class Plan:
             self.conv(F_, self.conv_desc(XN, cq, Cs, 1, 1, 0, Hs, Ws, Q, bias=cq.bias))
         xbar = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         U = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
-        with self.side(2):       # rank-one value path: xbar = mean_n GN(x) -> proj
-            assert cp.cin_pad == Cs and cp.cout_pad == Cs
-            self._emit(F_, "crd_attn_xbar_proj", [ch1, st1, self.p(name + ".norm1.weight"), self.p(name + ".norm1.bias"),
-                                                  _WPtr(cp, "w_fwd"), B, N, Cs, xbar.t, U.t])
+        assert cp.cin_pad == Cs and cp.cout_pad == Cs
         K = self.act(Cs, Hs // sr, Ws // sr)
         if sr > 1:
             csr = self.new_conv(a + ".sr", scatter=True)
@@ -702,11 +699,12 @@ class Plan:
         else:
             self.conv(F_, self.conv_desc(XN, ck, Cs, 1, 1, 0, Hs, Ws, K, bias=ck.bias))
         self.join(F_, 1)
-        self.join(F_, 2)
         Ssum = self.new((B, N), F32)
         idx = self.new((B, N, heads), torch.int16)
         self.keep.append(("idx", name, idx, M))
-        self._emit(F_, "crd_attn_scores", [Q.t, K.t, B, N, M, heads, dh, scale, Ssum, idx])
+        # scores + the rank-one value path (xbar = mean_n GN(x), U = proj(xbar): needs norm1's sums only) in one launch
+        self._emit(F_, "crd_attn_fwd", [Q.t, K.t, B, N, M, heads, dh, scale, Ssum, idx, ch1, st1, self.p(name + ".norm1.weight"),
+                                        self.p(name + ".norm1.bias"), _WPtr(cp, "w_fwd"), xbar.t, U.t])
         X1 = self.act(Cs, Hs, Ws, F32)
         # ---- MLP branch ----
         st2 = self.zf(B, Cs // 16, 2)

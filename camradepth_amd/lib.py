@@ -99,7 +99,7 @@ _SIGS = {
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiipipp",
     "crd_dwconv3x3": "piiiippipppippppppp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",
-    "crd_attn_scores": "ppiiiiifppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_xbar_proj": "pppppiiippp", "crd_attn_vec_bwd": "ppiiifppp", "crd_attn_out_residual": "pppppiiipp", "crd_attn_out_residual_stats": "pppppiiippp",
+    "crd_attn_scores": "ppiiiiifppp", "crd_attn_fwd": "ppiiiiifpppppppppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_xbar_proj": "pppppiiippp", "crd_attn_vec_bwd": "ppiiifppp", "crd_attn_out_residual": "pppppiiipp", "crd_attn_out_residual_stats": "pppppiiippp",
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_bwd": "ppppiiiiifpppppifppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
     "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiiip", "crd_scale_f32": "pplfp",

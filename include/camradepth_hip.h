@@ -197,6 +197,11 @@ int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int
  * ------------------------------------------------------------------------------------------- */
 int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
                     float scale, float* S, int16_t* idx, crd_stream_t stream);
+/* crd_attn_scores and crd_attn_xbar_proj in ONE launch (the value path is one extra workgroup per sample; it only needs
+ * norm1's sums, so it rides along with the scores): arguments as in the two calls, C = heads * d. */
+int crd_attn_fwd(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d, float scale,
+                 float* S, int16_t* idx, const float* chan_sums, const float* stats, const float* gamma, const float* beta,
+                 const void* w_fwd, void* xbar, float* u, crd_stream_t stream);
 /* xbar[b][c] (bf16) from per-channel sums chan[b][c][2] and g16 stats of x (gmul = 1). */
 int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma, const float* beta, int32_t B,
                   int32_t N, int32_t C, void* xbar, crd_stream_t stream);

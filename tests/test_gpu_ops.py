@@ -310,6 +310,18 @@ def test_attention_scores_and_backward(N, M, heads, d):
     # argmax may differ only where two scores tie after bf16 rounding: check the chosen score is the max
     chosen = torch.gather(att, 3, idx.cpu().long().permute(0, 2, 1).unsqueeze(-1)).squeeze(-1)
     assert float((chosen - smax).abs().max()) <= 1e-2 * float(smax.abs().max())
+    if C_ % 16 == 0:      # fused launch: scores + the rank-one value path (crd_attn_xbar_proj) in one extra workgroup per sample
+        chan = torch.randn(B, C_, 2, generator=g).cuda()
+        st = torch.stack([torch.randn(B, C_ // 16, generator=g), 20.0 + torch.rand(B, C_ // 16, generator=g)], -1).cuda() * N
+        gam, bet = (1 + 0.1 * torch.randn(C_, generator=g)).cuda(), (0.1 * torch.randn(C_, generator=g)).cuda()
+        wf = (0.2 * torch.randn(C_, C_, generator=g)).to(torch.bfloat16).cuda()
+        xb0, u0 = torch.zeros(B, C_, dtype=torch.bfloat16, device="cuda"), torch.zeros(B, C_, device="cuda")
+        ok(lb.crd_attn_xbar_proj(P(chan), P(st), P(gam), P(bet), P(wf), B, N, C_, P(xb0), P(u0), lib.stream()), "xbar_proj")
+        S2, idx2, xb1, u1 = torch.zeros_like(S), torch.zeros_like(idx), torch.zeros_like(xb0), torch.zeros_like(u0)
+        ok(lb.crd_attn_fwd(P(qd), P(kd), B, N, M, heads, d, scale, P(S2), P(idx2), P(chan), P(st), P(gam), P(bet), P(wf),
+                           P(xb1), P(u1), lib.stream()), "attn_fwd (fused)")
+        assert torch.equal(S2, S) and torch.equal(idx2, idx) and torch.equal(xb1, xb0) and torch.equal(u1, u0)
+        assert bool(torch.isfinite(u0).all())
     # backward of the score path
     dS = torch.randn(B, N, generator=g)
     dq = torch.zeros(B, N, C_, dtype=torch.bfloat16, device="cuda")

@@ -141,38 +141,57 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
   Map m(C);
   if (!m.active) return;
   const int c0 = m.cg * 8;
-  float mean, rstd;
-  const int grp = (c0 >> 4) / gmul;
-  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, 1.f / ((float)P * 16.f * gmul), mean, rstd);
-  float ga[8], be[8], mk[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ga[j] = gamma[c0 + j] * rstd;
-    be[j] = beta[c0 + j] - mean * ga[j];
-    mk[j] = mask ? mask[(long long)b * C + c0 + j] : 1.f;
-  }
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > P) p1 = P;
-  for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
-    float v[U][8];
+  long long p = p0 + m.pl;
+  // Every load the first batch needs is issued before anything is waited for -- the pixels, then the parameters, then
+  // the statistics: four dependent round trips (kernel arguments, statistics, parameters, data) were most of the ~5 us
+  // a launch on a small grid takes.
+  float v[U][8];
+  auto load_batch = [&](long long q) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      long long pp = p + (long long)u * m.PL;
+      long long pp = q + (long long)u * m.PL;
       if (pp >= p1) pp = p1 - 1;
       load8t<XF>(x, ((long long)b * P + pp) * x_ld + c0, v[u]);
     }
+  };
+  if (p < p1) load_batch(p);
+  float ga[8], be[8], mk[8];
+  load8(gamma, c0, 1, ga);
+  load8(beta, c0, 1, be);
+  if (mask) load8(mask, (long long)b * C + c0, 1, mk);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mk[j] = 1.f;
+  }
+  float mean, rstd;
+  const int grp = (c0 >> 4) / gmul;
+  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, 1.f / ((float)P * 16.f * gmul), mean, rstd);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    ga[j] *= rstd;
+    be[j] -= mean * ga[j];
+  }
+  while (p < p1) {
+    float o[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float w = v[u][j] * ga[j] + be[j];
+        if (ACT == 1) w = gelu_exact(w);
+        o[u][j] = w * mk[j];
+      }
+    const long long pc = p;
+    p += (long long)U * m.PL;
+    if (p < p1) load_batch(p);                 // next batch in flight under this batch's stores
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long pp = p + (long long)u * m.PL;
+      const long long pp = pc + (long long)u * m.PL;
       if (pp < p1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float w = v[u][j] * ga[j] + be[j];
-          if (ACT == 1) w = gelu_exact(w);
-          v[u][j] = w * mk[j];
-        }
-        if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, v[u]);
-        else store8_bf16(y, ((long long)b * P + pp) * y_ld + c0, v[u]);
+        if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, o[u]);
+        else store8_bf16(y, ((long long)b * P + pp) * y_ld + c0, o[u]);
       }
     }
   }

@@ -208,27 +208,35 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
   Map m(C);
   if (m.active) {
     const int c0 = m.cg * 8;
-    float mean, rstd;
-    const int grp = (c0 >> 4) / gmul;
-    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, 1.f / ((float)P * 16.f * gmul), mean, rstd);
-    float ga[8], be[8], mk[8], s0[8], s1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
-      mk[j] = mask ? mask[(long long)b * C + c0 + j] : 1.f;
-      s0[j] = s1[j] = 0.f;
-    }
     long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
     if (p1 > P) p1 = P;
-    for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
-      float v[U][8], d[U][8];
+    long long p = p0 + m.pl;
+    // first batch, parameters and statistics all in flight before the first wait (see k_gn_apply)
+    float v[U][8], d[U][8];
+    auto load_batch = [&](long long q) {
 #pragma unroll
       for (int u = 0; u < U; ++u) {
-        long long pp = p + (long long)u * m.PL;
+        long long pp = q + (long long)u * m.PL;
         if (pp >= p1) pp = p1 - 1;
         load8t<XF>(x, ((long long)b * P + pp) * x_ld + c0, v[u]);
         load8t<DF>(dy, ((long long)b * P + pp) * dy_ld + c0, d[u]);
       }
+    };
+    if (p < p1) load_batch(p);
+    float ga[8], be[8], mk[8], s0[8], s1[8];
+    load8(gamma, c0, 1, ga);
+    load8(beta, c0, 1, be);
+    if (mask) load8(mask, (long long)b * C + c0, 1, mk);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!mask) mk[j] = 1.f;
+      s0[j] = s1[j] = 0.f;
+    }
+    float mean, rstd;
+    const int grp = (c0 >> 4) / gmul;
+    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, 1.f / ((float)P * 16.f * gmul), mean, rstd);
+    for (bool first = true; p < p1; p += (long long)U * m.PL, first = false) {
+      if (!first) load_batch(p);               // (the first batch was requested at the top)
 #pragma unroll
       for (int u = 0; u < U; ++u)
         if (p + (long long)u * m.PL < p1) {
@@ -314,6 +322,23 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
                                                       void* dx, int dx_f32, int dx_ld, int dx_acc, int B, void* dx2, int dx2_ld,
                                                       const float* scale2) {
   const int b = blockIdx.y;
+  Map m(C);
+  const int c0 = m.cg * 8;
+  long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
+  if (p1 > P) p1 = P;
+  long long p = p0 + m.pl;
+  // first batch, parameters, reduce sums and statistics all in flight before the first wait (see k_gn_apply)
+  float v[U][8], d[U][8];
+  auto load_batch = [&](long long q) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      long long pp = q + (long long)u * m.PL;
+      if (pp >= p1) pp = p1 - 1;
+      load8t<XF>(x, ((long long)b * P + pp) * x_ld + c0, v[u]);
+      load8t<DF>(dy, ((long long)b * P + pp) * dy_ld + c0, d[u]);
+    }
+  };
+  if (m.active && p < p1) load_batch(p);
   if (b == 0 && dgamma) {     // parameter gradients: the workgroups of sample 0 share the channels (one workgroup doing all
                               // of them put B x C dependent loads in front of its own pixels: +5 us on the small grids)
     for (int c = blockIdx.x * TPB + threadIdx.x; c < C; c += gridDim.x * TPB) {
@@ -323,34 +348,25 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
       dgamma[c] += g1;
     }
   }
-  Map m(C);
   if (!m.active) return;
-  const int c0 = m.cg * 8;
-  float mean, rstd;
+  float ga[8], be[8], mk[8];
+  load8(gamma, c0, 1, ga);
+  load8(beta, c0, 1, be);
+  if (mask) load8(mask, (long long)b * C + c0, 1, mk);
+  else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mk[j] = 1.f;
+  }
   const int grp = (c0 >> 4) / gmul;
   const int cpg = 16 * gmul;
   const float inv_m = 1.f / ((float)P * cpg);
-  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, inv_m, mean, rstd);
   const float* rg = r + (long long)B * C * 2 + ((long long)b * (C / cpg) + grp) * 2;
   const float S1 = rg[0] * inv_m, S2 = rg[1] * inv_m;
-  float ga[8], be[8], mk[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    ga[j] = gamma[c0 + j]; be[j] = beta[c0 + j];
-    mk[j] = mask ? mask[(long long)b * C + c0 + j] : 1.f;
-  }
+  float mean, rstd;
+  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, inv_m, mean, rstd);
   const float sc2 = (dx2 && scale2) ? scale2[b] : 1.f;
-  long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
-  if (p1 > P) p1 = P;
-  for (long long p = p0 + m.pl; p < p1; p += (long long)U * m.PL) {
-    float v[U][8], d[U][8];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      long long pp = p + (long long)u * m.PL;
-      if (pp >= p1) pp = p1 - 1;
-      load8t<XF>(x, ((long long)b * P + pp) * x_ld + c0, v[u]);
-      load8t<DF>(dy, ((long long)b * P + pp) * dy_ld + c0, d[u]);
-    }
+  for (bool first = true; p < p1; p += (long long)U * m.PL, first = false) {
+    if (!first) load_batch(p);                 // (the first batch was requested at the top of the kernel)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long long pp = p + (long long)u * m.PL;

@@ -173,25 +173,20 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
     ga[j] *= rstd;
     be[j] -= mean * ga[j];
   }
-  while (p < p1) {
-    float o[U][8];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float w = v[u][j] * ga[j] + be[j];
-        if (ACT == 1) w = gelu_exact(w);
-        o[u][j] = w * mk[j];
-      }
-    const long long pc = p;
-    p += (long long)U * m.PL;
-    if (p < p1) load_batch(p);                 // next batch in flight under this batch's stores
+  for (bool first = true; p < p1; p += (long long)U * m.PL, first = false) {
+    if (!first) load_batch(p);                 // (the first batch was requested at the top of the kernel)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const long long pp = pc + (long long)u * m.PL;
+      const long long pp = p + (long long)u * m.PL;
       if (pp < p1) {
-        if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, o[u]);
-        else store8_bf16(y, ((long long)b * P + pp) * y_ld + c0, o[u]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          float w = v[u][j] * ga[j] + be[j];
+          if (ACT == 1) w = gelu_exact(w);
+          v[u][j] = w * mk[j];
+        }
+        if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, v[u]);
+        else store8_bf16(y, ((long long)b * P + pp) * y_ld + c0, v[u]);
       }
     }
   }

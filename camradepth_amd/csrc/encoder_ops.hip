@@ -77,6 +77,10 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
   bf16_t* yb = y + (long long)b * H * W * C;
   const int t = threadIdx.x;
   const int nG = (C - c_win) >= DCW ? 8 : (C - c_win) >> 3;     // granules of this window that exist
+  const int g = t & 7, xc = (t >> 3) % TW, rg = (t >> 3) / TW;
+  const int c0 = c_win + g * 8;
+  const bool gok = g < nG;
+  float wv[9][8], bv[8];
   // ---- halo -> LDS: piece i = (halo pixel i >> 3, granule i & 7)
   {
     uint4 r[(HPX * 8 + TPB - 1) / TPB];
@@ -91,6 +95,18 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
       inimg[k] = i < HPX * 8 && g < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
       if (inimg[k]) r[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + g * 8);
     }
+    // weights, bias and the input-norm coefficients are requested while the halo is in flight (after the LDS stores they
+    // were a second dependent round trip on the small grids)
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      if (gok) load8t<1>(w9, (long long)(FLIP ? 8 - tp : tp) * C + c0, wv[tp]);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wv[tp][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bv[j] = (bias && gok) ? bias[c0 + j] : 0.f;
     float na[8], ns[8];
     innorm_coeffs(inn, b, C, (long long)H * W, c_win + (t & 7) * 8, (t & 7) < nG, na, ns);
 #pragma unroll
@@ -99,20 +115,6 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
       if (i < HPX * 8) sh[i] = (inn.stats && inimg[k]) ? innorm_apply(r[k], na, ns) : r[k];   // the zero padding stays zero
     }
   }
-  const int g = t & 7, xc = (t >> 3) % TW, rg = (t >> 3) / TW;
-  const int c0 = c_win + g * 8;
-  const bool gok = g < nG;
-  float wv[9][8], bv[8];
-#pragma unroll
-  for (int tp = 0; tp < 9; ++tp) {
-    if (gok) load8t<1>(w9, (long long)(FLIP ? 8 - tp : tp) * C + c0, wv[tp]);
-    else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) wv[tp][j] = 0.f;
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < 8; ++j) bv[j] = (bias && gok) ? bias[c0 + j] : 0.f;
   __syncthreads();
   auto lds8 = [&](int hy, int hx, float (&v)[8]) {
     const uint4 u = sh[(hy * HWD + hx) * 8 + g];
@@ -247,7 +249,6 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
     v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
   };
   float na[8], ns[8];
-  innorm_coeffs(inn, b, C, (long long)H * W, c_win + (t & 7) * 8, (t & 7) < nG, na, ns);
   for (int it = 0; it < tiles_per_wg; ++it) {
     const int tyi = ygrp * tiles_per_wg + it;
     if (tyi >= tiles_y) break;                     // uniform
@@ -275,6 +276,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
         rd[k] = make_uint4(0, 0, 0, 0);
         if (gg < nG && iy < H && ix < W) rd[k] = *reinterpret_cast<const uint4*>(db + ((long long)iy * W + ix) * C + c_win + gg * 8);
       }
+      if (it == 0) innorm_coeffs(inn, b, C, (long long)H * W, c_win + (t & 7) * 8, (t & 7) < nG, na, ns);   // under the first tile's loads
       if (it > 0) __syncthreads();                 // everyone is done with the previous tile's LDS image
 #pragma unroll
       for (int k = 0; k < NX; ++k) {

@@ -43,7 +43,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32, NT = WM * WN * 64, LDT = BN + 8, BMH = BM / HALVES;
   static_assert(HALVES == 1 || (HALVES == 2 && WM % 2 == 0), "row halves are whole waves");
   float* red = reinterpret_cast<float*>(smem) + (BMH * LDT) / 2;     // behind the bf16 staging tile
-  const bool vec = a.out_mode == 0 && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
+  const bool vec = (a.out_mode == 0 || (a.patch_c & 7) == 0) && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
   if (vec) {
     bf16_t* T = reinterpret_cast<bf16_t*>(smem);
     bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
@@ -108,6 +108,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
       if (valid && col < a.Cout) {
         uint4 u = *reinterpret_cast<const uint4*>(T + rh * LDT + g * 8);
         bf16_t* dst = yb + (long long)p * a.y_ld + col;
+        if (a.out_mode == 1) {               // patch scatter: column = (tap, channel), 8 columns stay inside one tap
+          const int tap = col / a.patch_c, pci = col - tap * a.patch_c;
+          const int pky = tap / a.patch_k, pkx = tap - pky * a.patch_k;
+          const int oy = p / a.OW, ox = p - oy * a.OW;
+          dst = yb + ((long long)(oy * a.patch_k + pky) * a.YW + (ox * a.patch_k + pkx)) * a.y_ld + pci;
+        }
         if (a.accumulate) {
           const uint4 o = *reinterpret_cast<const uint4*>(dst);
           u.x = pack_bf2(bf_lo(u.x) + bf_lo(o.x), bf_hi(u.x) + bf_hi(o.x));
@@ -254,7 +260,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
 // Waves of a workgroup that hold no output tile (split-K groups 1.. of k_igemm) must still meet the barriers of
 // conv_epilogue: one in the LDS-staged vector path, one before the statistics fold.  Keep in step with conv_epilogue.
 __device__ __forceinline__ void conv_epilogue_idle(const ConvK& a) {
-  const bool vec = a.out_mode == 0 && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
+  const bool vec = (a.out_mode == 0 || (a.patch_c & 7) == 0) && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
   if (vec) __syncthreads();
   if (vec && a.red_x) { __syncthreads(); __syncthreads(); __syncthreads(); }
   if (a.stats) __syncthreads();

@@ -279,6 +279,7 @@ int launch3(const ConvK& k0, int B, hipStream_t st, long long partial_cap, int c
   constexpr int BN = WN * TN * 32, BM = TH * TW;
   ConvK k = k0;
   k.col0 = col0;
+  k.lds_bytes = 0;                                 // (the fp32 staging epilogue is an igemm.hip path)
   if (col1 < 0) col1 = k.Cout;                     // this launch computes output columns [col0, col1)
   k.n_tiles = cdiv(k.IW, TW) * cdiv(k.IH, TH);
   if ((long long)B * k.n_tiles * k.G16 * 2 > partial_cap) k.stats_partial = nullptr;

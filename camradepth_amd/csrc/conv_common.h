@@ -15,6 +15,8 @@ struct ConvK {
   int accumulate; float* stats; int G16;
   float* stats_partial; int n_tiles;   // per-tile partial sums [B][n_tiles][G16][2] (plain stores) or nullptr -> atomics
   int vec_ok;   // y base/offset 16-byte aligned: the vectorised epilogue may be used
+  int vecf_ok;  // fp32 output (+ residual) rows are 16-byte aligned as well: LDS-staged float4 epilogue
+  int lds_bytes;   // dynamic LDS of the launch (the fp32 staging tile needs BM x (BN+4) floats)
   // Optional: reduce phase of the backward of the GroupNorm (+GELU) whose dy this launch produces (vector path only).
   // red_x = that GroupNorm's raw bf16 input [pixels][red_x_ld], batch stride red_x_bstride; r as in crd_gn_bwd_reduce.
   const bf16_t* red_x; int red_x_ld; long long red_x_bstride;
@@ -25,6 +27,13 @@ struct ConvK {
   int dbg;   // developer experiments only (CRD_DBG env): 1 no weight-DMA wait, 2 no DMA at all, 4 no epilogue
 };
 
+
+// fp32 LDS-staged epilogue (conv_epilogue's second branch) applies?  One definition for conv_epilogue and conv_epilogue_idle.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ bool conv_use_vecf(const ConvK& a) {
+  return a.vecf_ok && a.out_mode == 0 && a.y_f32 && !a.stats_partial && (NT % (BN / 4) == 0) &&
+         (size_t)BM * (BN + 4) * 4 + (size_t)NT * 8 * 4 <= (size_t)a.lds_bytes;
+}
 
 // Fused epilogue of one wave's TM x TN grid of 32x32 accumulator tiles (v_mfma_f32_32x32x16 C/D layout: lane l holds
 // column l&31 and rows (r&3) + 8*(r>>2) + 4*(l>>5)).  `pix(i, rr, valid, p)` maps accumulator row rr of row-tile i to the
@@ -170,6 +179,76 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
         }
       }
     }
+  } else if (conv_use_vecf<BM, BN, NT>(a)) {
+    // fp32 output (+ residual, + GroupNorm sums of the stored values): the tile goes through LDS as floats and leaves
+    // with 16-byte loads / stores (the per-lane 4-byte form below cost +5..11 us on the encoder's fc2 convs)
+    constexpr int LDF = BN + 4, GPR4 = BN / 4;
+    float* T = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cl = (wn * TN + j) * 32 + (l & 31);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rr = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+          float v = acc[i][j][r];
+          if (a.act == 1) v = sigmoidf_(v);
+          T[((wm * TM + i) * 32 + rr) * LDF + cl] = v;
+        }
+    }
+    __syncthreads();
+    const float rscale = (a.res && a.res_scale) ? a.res_scale[b] : 1.f;
+    float* yb = reinterpret_cast<float*>(a.y) + (long long)b * a.y_bstride;
+    const float* resb = a.res ? a.res + (long long)b * a.res_bstride : nullptr;
+    float cs[4] = {0.f, 0.f, 0.f, 0.f}, css[4] = {0.f, 0.f, 0.f, 0.f};
+    const int g4 = threadIdx.x % GPR4, col = n0 + g4 * 4;      // a thread keeps its 4 columns (NT % GPR4 == 0)
+    if (col < a.Cout) {
+      for (int rl = threadIdx.x / GPR4; rl < BM; rl += NT / GPR4) {
+        bool valid;
+        int p;
+        pixrow(rl, valid, p);
+        if (!valid) continue;
+        float4 v = *reinterpret_cast<const float4*>(T + rl * LDF + g4 * 4);
+        if (resb) {
+          const float4 q = *reinterpret_cast<const float4*>(resb + (long long)p * a.res_ld + col);
+          v.x = q.x + rscale * bf_round(v.x); v.y = q.y + rscale * bf_round(v.y);
+          v.z = q.z + rscale * bf_round(v.z); v.w = q.w + rscale * bf_round(v.w);
+        }
+        float4* dst = reinterpret_cast<float4*>(yb + (long long)p * a.y_ld + col);
+        if (a.accumulate) { const float4 o = *dst; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *dst = v;
+        cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w;
+        css[0] += v.x * v.x; css[1] += v.y * v.y; css[2] += v.z * v.z; css[3] += v.w * v.w;
+      }
+    }
+    if (a.stats) {       // fold the threads that share a column group, then one atomic per column / 16-column slab
+      __syncthreads();
+      float* fr = reinterpret_cast<float*>(smem);              // [NT][8]; the staging tile is free again
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { fr[threadIdx.x * 8 + j * 2] = cs[j]; fr[threadIdx.x * 8 + j * 2 + 1] = css[j]; }
+      __syncthreads();
+      float* fc = fr + NT * 8;                                 // [BN][2] column sums
+      if ((int)threadIdx.x < BN * 2) {
+        const int c = threadIdx.x >> 1, which = threadIdx.x & 1;
+        float v = 0.f;
+        for (int m = 0; m < NT / GPR4; ++m) v += fr[((c >> 2) + m * GPR4) * 8 + (c & 3) * 2 + which];
+        fc[threadIdx.x] = v;
+        if (a.chan && n0 + c < a.Cout) atomicAdd(&a.chan[((long long)b * a.Cout + n0 + c) * 2 + which], v);
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < (BN / 16) * 2) {
+        const int slab = threadIdx.x >> 1, which = threadIdx.x & 1;
+        const int gidx = (n0 >> 4) + slab;
+        if (gidx < a.G16) {
+          float v = 0.f;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) v += fc[(slab * 16 + j) * 2 + which];
+          atomicAdd(a.stats + ((long long)b * a.G16 + gidx) * 2 + which, v);
+        }
+      }
+    }
+    return;
   } else {
   const int col0 = n0 + wn * TN * 32;
   const float rscale = (a.res && a.res_scale) ? a.res_scale[b] : 1.f;
@@ -259,8 +338,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
 
 // Waves of a workgroup that hold no output tile (split-K groups 1.. of k_igemm) must still meet the barriers of
 // conv_epilogue: one in the LDS-staged vector path, one before the statistics fold.  Keep in step with conv_epilogue.
+template <int BM, int BN, int NT>
 __device__ __forceinline__ void conv_epilogue_idle(const ConvK& a) {
   const bool vec = (a.out_mode == 0 || (a.patch_c & 7) == 0) && !a.y_f32 && !a.res && (a.Cout & 7) == 0 && (a.y_ld & 7) == 0 && a.vec_ok;
+  if (!vec && conv_use_vecf<BM, BN, NT>(a)) {      // fp32 staging path: one barrier, three more with statistics
+    __syncthreads();
+    if (a.stats) { __syncthreads(); __syncthreads(); __syncthreads(); }
+    return;
+  }
   if (vec) __syncthreads();
   if (vec && a.red_x) { __syncthreads(); __syncthreads(); __syncthreads(); }
   if (a.stats) __syncthreads();

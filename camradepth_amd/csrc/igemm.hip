@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
         for (int r = 0; r < 16; ++r) acc[0][0][r] += src[r * 256 + t];
       }
     } else {
-      conv_epilogue_idle(a);       // same barriers as the epilogue below
+      conv_epilogue_idle<BM, BN, 256>(a);       // same barriers as the epilogue below
       return;
     }
   }
@@ -219,7 +219,9 @@ void launch_mode(const ConvK& k, dim3 grid, hipStream_t st) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, MODE, NST, KG>), grid, dim3(256 * KG), lds, st, k);
+  ConvK kk = k;
+  kk.lds_bytes = (int)lds;
+  hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, MODE, NST, KG>), grid, dim3(256 * KG), lds, st, kk);
 }
 
 template <int WM, int WN, int TM, int TN, int NST, int KG = 1>
@@ -273,6 +275,9 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   CRD_UNSUPPORTED(!d->chan_sums || (d->stats && (d->y_f32 || d->res || d->out_mode != 0)),
                   "crd_conv_igemm: chan_sums needs stats and an fp32 / residual output (the scalar epilogue)");
   k.vec_ok = (d->y_coff % 8 == 0) && ((reinterpret_cast<uintptr_t>(d->y) & 15) == 0);
+  k.vecf_ok = d->y_f32 && d->y_coff % 4 == 0 && d->y_ld % 4 == 0 && d->Cout % 4 == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
+              (!d->res || (d->res_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0));
+  k.lds_bytes = 0;
   k.red_x = reinterpret_cast<const bf16_t*>(d->red_x); k.red_x_ld = d->red_x_ld;
   k.red_x_bstride = (long long)YH * YW * d->red_x_ld;
   k.red_stats = d->red_stats; k.red_gamma = d->red_gamma; k.red_beta = d->red_beta; k.red_gmul = d->red_gmul;

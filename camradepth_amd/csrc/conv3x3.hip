@@ -24,6 +24,7 @@
 // across the two co-resident workgroups (0.20 + 0.19 + 0.25 ms of a 0.67 ms launch), i.e. ~900 TFLOP/s is this
 // structure's ceiling from HIP source.
 #include "conv_common.h"
+#include <cstdlib>
 
 using namespace crdk;
 
@@ -316,8 +317,25 @@ extern "C" int crd_dbg_conv3_prof(unsigned long long* out) {
 }
 #endif
 
+static int g_small_thr = -1;      // workgroup count below which narrower column tiles are used (crd_tune_conv3x3_small_grid)
+
+extern "C" int crd_tune_conv3x3_small_grid(int workgroups) {
+  const int old = g_small_thr < 0 ? 512 : g_small_thr;
+  g_small_thr = workgroups < 0 ? 512 : workgroups;
+  return old;
+}
+
 // Called from crd_conv_igemm for 3x3 / stride 1 / pad 1 layers on grids large enough to fill the chip.
 int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_cap) {
+  {   // grids that leave most CUs without a workgroup (the 32x52 decoder level: 64 pixel tiles): narrower column tiles
+    if (g_small_thr < 0) { const char* e = getenv("CRD_CONV3_SMALL"); g_small_thr = e ? atoi(e) : 512; }
+    const int thr = g_small_thr;
+    const long long tiles = (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * B;
+    if (tiles * cdiv(k.Cout, 128) < thr && k.Cout > 32) {
+      if (tiles * cdiv(k.Cout, 64) >= thr) return launch3<4, 1, 2, 2>(k, B, st, partial_cap);
+      return launch3<4, 1, 2, 1>(k, B, st, partial_cap);
+    }
+  }
   if (k.Cout <= 32) return launch3<4, 1, 2, 1>(k, B, st, partial_cap);
   if (k.Cout <= 64) return launch3<4, 1, 2, 2>(k, B, st, partial_cap);
   if (k.Cout <= 96) return launch3<4, 1, 2, 3>(k, B, st, partial_cap);

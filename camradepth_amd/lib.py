@@ -95,7 +95,7 @@ def load():
 
 # Signatures of include/camradepth_hip.h (all return int status). p = pointer, i = int32, l = int64, f = float
 _SIGS = {
-    "crd_conv_igemm": "pp", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
+    "crd_conv_igemm": "pp", "crd_tune_conv3x3_small_grid": "i", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiipipp",
     "crd_dwconv3x3": "piiiippipppippppppp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",

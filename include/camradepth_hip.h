@@ -89,6 +89,10 @@ typedef struct {
 } crd_conv_desc;
 
 int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);
+/* Tuning knob of the 3x3 halo kernel: launches whose 128-column tiling would give fewer than `workgroups` workgroups use
+ * 64- or 32-column tiles instead (default 512; 0 disables; < 0 restores the default).  Returns the previous value.
+ * Not needed for correctness -- the tests use it to reach every tile configuration with small inputs. */
+int crd_tune_conv3x3_small_grid(int workgroups);
 
 /* Weight gradient of the same convolutions: dw[co][tap][ci] += sum_{b,oy,ox} dy[b,oy,ox,co] *
  * x[b, oy*s-p+ky, ox*s-p+kx, ci]  (fp32 atomics; caller zeroes dw).  Optionally also

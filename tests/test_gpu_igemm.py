@@ -38,6 +38,16 @@ def pack_w(w, cin_pad=None):
     return p.cuda()
 
 
+@pytest.fixture(autouse=True, params=[0, 512], ids=["wide-tiles", "small-grid-tiles"])
+def _conv3x3_tile_choice(request):
+    """The 3x3 halo kernel picks 64 / 32-column tiles for launches of fewer than 512 workgroups -- which is every case of
+    this file.  Run everything under both settings so that the 96 / 128-column configurations stay covered."""
+    L = _lib().load()
+    old = L.crd_tune_conv3x3_small_grid(request.param)
+    yield
+    L.crd_tune_conv3x3_small_grid(old)
+
+
 def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, OH, OW, y, y_ld, y_coff, y_f32=0,
              gather_mode=0, out_mode=0, patch_k=0, patch_c=0, bias=None, act=0, res=None, res_ld=0, res_scale=None,
              accumulate=0, stats=None, partial=None, red=None, chan=None):

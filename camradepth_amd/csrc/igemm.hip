@@ -289,8 +289,12 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
     const bool halo_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IW >= 32 && d->IH >= 8;
     CRD_CHECK_ARG(d->red_stats && d->red_gamma && d->red_beta && d->red_r && d->red_gmul >= 1 && d->red_x_ld % 8 == 0 &&
                   (d->Cout / 16) % d->red_gmul == 0, "crd_conv_igemm: incomplete fused-reduce arguments");
-    CRD_UNSUPPORTED(d->Cout > 160 && d->Cout % 16 == 0 && !halo_shape && d->out_mode == 0 && !d->y_f32 && !d->res && d->y_ld % 8 == 0 &&
-                    k.vec_ok, "crd_conv_igemm: the fused GroupNorm-backward reduce needs a bf16 vector-path output with Cout > 160");
+    // the fused reduce lives in the vector epilogue and needs a tile whose threads keep their columns (256 % (BN/8) == 0):
+    // the 64 / 32 / 128-column tiles, not the 96- and 160-column ones
+    const bool small_path = d->Cout > 32 && (long long)cdiv(k.OHW, 128) * cdiv(d->Cout, 128) * d->B < 192;
+    const bool tile_ok = small_path || d->Cout <= 64 || (d->Cout > 96 && d->Cout <= 128) || d->Cout > 160;
+    CRD_UNSUPPORTED(tile_ok && d->Cout % 16 == 0 && !halo_shape && d->out_mode == 0 && !d->y_f32 && !d->res && d->y_ld % 8 == 0 &&
+                    k.vec_ok, "crd_conv_igemm: the fused GroupNorm-backward reduce needs a bf16 vector-path output and a 32/64/128-column tile");
   }
   // 3x3 / stride 1 / pad 1 on grids at least one tile wide: halo-tile kernel (conv3x3.hip)
   if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == 0 && d->IH == d->OH && d->IW == d->OW &&

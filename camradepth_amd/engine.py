@@ -791,8 +791,11 @@ class Plan:
         if sr > 1:
             self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=self.g(a + ".k.bias"))
             DKR = self.act(Cs, Hs // sr, Ws // sr)
-            self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs // sr, Ws // sr, DKR, gather=1))
-            self.gn_bwd(g, KR, stk, 1, a + ".norm", 0, None, DKR, DKR)
+            # k's data gradient also runs the reduce phase of attn.norm's backward on its own output (a launch less)
+            rk = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if FUSE_STATS else None
+            redk = None if rk is None else (KR, stk, self.p(a + ".norm.weight"), self.p(a + ".norm.bias"), 1, 0, rk)
+            self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs // sr, Ws // sr, DKR, gather=1, red=redk))
+            self.gn_bwd(g, KR, stk, 1, a + ".norm", 0, None, DKR, DKR, r=rk)
             self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=self.g(a + ".sr.bias"))
             self.conv(g, self.conv_desc(DKR, ("scatter", csr), sr * sr * Cs, 1, 1, 0, Hs // sr, Ws // sr, DXN, out_mode=1,
                                         patch_k=sr, patch_c=Cs, accumulate=1))

@@ -95,8 +95,11 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
     return "k_igemm<2,2,2,2>"
 
 
-def halo_tile(cout):
-    """Tile configuration of the halo-tile 3x3 kernel (csrc/conv3x3.hip)."""
+def halo_tile(cout, OH=1 << 20, OW=1 << 20, B=1):
+    """Tile configuration of the halo-tile 3x3 kernel (csrc/conv3x3.hip: crd_conv3x3_halo), for the bench labels."""
+    tiles = -(-OW // 32) * -(-OH // 8) * B
+    if cout > 32 and tiles * -(-cout // 128) < 512:      # under-filled grid: 64- or 32-column tiles
+        return "k_conv3x3<4,1,2,2>" if tiles * -(-cout // 64) >= 512 else "k_conv3x3<4,1,2,1>"
     if cout <= 32:
         return "k_conv3x3<4,1,2,1>"
     if cout <= 64:
@@ -254,7 +257,7 @@ class Plan:
                 self.conv(lst, sub, None if region is None else region[:-2] + (region[-2] + c0, region[-2] + c1))
             return None
         flops = spec.get("flops_override", flops)
-        kname = halo_tile(spec["cout"]) if halo else igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B)
+        kname = halo_tile(spec["cout"], spec["OH"], spec["OW"], self.B) if halo else igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B)
         meta = {"kernel": kname, "flops": flops,
                 "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
                          f"out{spec['OH']}x{spec['OW']}"}

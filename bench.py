@@ -173,6 +173,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--inference", action="store_true",
+                    help="SURVEY 8f N4: eval-mode forward only, replayed from one HIP graph (e.g. --batch 1 --height 416 --width 800)")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -196,6 +198,14 @@ def main():
 
     sup = a.variant == "supervised_seg"
     model = CamRaDepth(input_channels=7, supervised_seg=sup, seed=0).cuda()      # same init on every rank
+    if a.inference:       # the reference's own "runtime" figure (Trainer.test(), runner.py:417-420), without its missing device sync
+        batch = synth.make_batch(a.batch, a.height, a.width, seed=1234)
+        r = forward_only(model, batch, a.batch, a.height, a.width, a.variant, reps=max(a.steps, 10))
+        print(json.dumps({"metric": "inference frames/sec (eval forward, HIP graph)", "value": r["images_per_s"], "unit": "images/s",
+                          "n_gpus": 1, "ms_per_forward": r["ms"], "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"CamRaDepth {a.variant} eval forward, {a.batch}x7x{a.height}x{a.width}"},
+                          "mfma_frac": r["mfma_frac"]}), flush=True)
+        return
     model.train()
     total_sched = max(a.steps + a.warmup + 8, 64)
     ts = TrainStep(model, a.batch, a.height, a.width, lr=6e-5, schedule=one_cycle(total_sched, 6e-5),

@@ -220,13 +220,15 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
   if (do_bias) atomicAdd(a.dbias + t, bsum);
 }
 
-// row splits (workgroups along x) and strip rows per workgroup
-int plan_rows(long long total_rows, int Cin, int& rows_per_wg) {
+// row splits (workgroups along x) and strip rows per workgroup.  cap > 0 (the number of partial copies the caller
+// provides): at most that many row splits -- how a caller leaves CUs to kernels running next to this one.
+int plan_rows(long long total_rows, int Cin, int& rows_per_wg, int cap = 0) {
   const int chunks = cdiv(Cin, XLD);
   // one workgroup per CU in total: every row split adds Cout x 9 x Cin fp32 atomics (37 M per launch at 512 workgroups,
   // ~0.2 ms at the ~170 G/s the L2s sustain), which a second workgroup per CU does not win back (30.0 vs 30.3 ms/step)
   int wgs = 256 / chunks;
   if (wgs < 1) wgs = 1;
+  if (cap > 0 && wgs > cap) wgs = cap;
   if (wgs > total_rows / 8) wgs = (int)(total_rows / 8 > 0 ? total_rows / 8 : 1);
   rows_per_wg = (int)((total_rows + wgs - 1) / wgs);
   return (int)((total_rows + rows_per_wg - 1) / rows_per_wg);
@@ -238,8 +240,7 @@ int launch_w3(const Wg3K& k0, hipStream_t st, int partial_capacity) {
   constexpr int COT = WCO * TCO * 16;
   const size_t lds = (size_t)(XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
   const int chunks = cdiv(k.Cin, XLD);
-  const int wgs = plan_rows(k.total_rows, k.Cin, k.rows_per_wg);
-  if (wgs > partial_capacity) k.dw_part = nullptr;
+  const int wgs = plan_rows(k.total_rows, k.Cin, k.rows_per_wg, k.dw_part ? partial_capacity : 0);
   static bool attr_done = false;
   if (!attr_done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -265,8 +266,7 @@ int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st) {
   k.dy_bytes = (long long)d->B * d->IH * d->IW * d->dy_ld * 2;
   k.dw = d->dw; k.dbias = d->dbias;
   k.dw_part = d->dw_partials;
-  CRD_CHECK_ARG(d->dw_partials == nullptr || d->dw_partial_capacity >= plan_rows(k.total_rows, k.Cin, k.rows_per_wg),
-                "crd_conv_wgrad: dw_partials holds fewer copies than crd_conv_wgrad_splits() reports");
+  CRD_CHECK_ARG(d->dw_partials == nullptr || d->dw_partial_capacity >= 1, "crd_conv_wgrad: dw_partials needs a capacity >= 1");
   if (d->Cout <= 32) return launch_w3<2, 4, 1>(k, st, d->dw_partial_capacity);
   if (d->Cout <= 64) return launch_w3<2, 4, 2>(k, st, d->dw_partial_capacity);
   if (d->Cout <= 96) return launch_w3<2, 4, 3>(k, st, d->dw_partial_capacity);     // 96-channel dy rows: no padded MFMA tiles
@@ -275,5 +275,5 @@ int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st) {
 
 int crd_wgrad3x3_splits(const crd_wgrad_desc* d) {
   int rows = 0;
-  return plan_rows((long long)d->B * cdiv(d->IW, 32) * d->IH, d->Cin, rows);
+  return plan_rows((long long)d->B * cdiv(d->IW, 32) * d->IH, d->Cin, rows, d->dw_partial_capacity > 0 ? d->dw_partial_capacity : 0);
 }

@@ -38,6 +38,13 @@ FUSE_GN_RED_MAXPIX = int(os.environ.get("CRD_FUSE_GN_RED_MAXPIX", "416"))
 # GroupNorm statistics of the residual stream produced by the kernels that write it (attn_out_residual -> norm2, fc2's
 # epilogue -> the next block's norm1) instead of crd_gn_stats launches; CRD_NO_FUSE_STATS restores the launches
 FUSE_STATS = os.environ.get("CRD_NO_FUSE_STATS") is None
+# The decoder's weight gradients (2.9 ms of MFMA work nothing in the backward pass waits for) can leave the chain: the
+# single-GPU graph step replays them as a graph of their own on a second stream while the encoder's latency-bound backward
+# runs (trainer.py; CRD_NO_LATE_WGRAD keeps program order).  W3_LATE_WGS: workgroups their streaming kernels may use in
+# that mode, so that the encoder's kernels still find free CUs (256: 22.1 ms, 160: 20.7, 128: 20.9, 64: 22.3).
+LATE_WGRAD = os.environ.get("CRD_NO_LATE_WGRAD") is None
+W3_LATE_WGS = int(os.environ.get("CRD_W3_LATE_WGS", "160"))
+LATE = 3            # Op.stream id of those ops
 SPLIT_N = os.environ.get("CRD_NO_SPLIT_N") is None      # developer switch for the ragged-tile split of 3x3 data gradients
 W3_PARTIALS = os.environ.get("CRD_NO_W3_PARTIALS") is None   # developer switch: streaming 3x3 wgrad with atomics instead
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
@@ -157,6 +164,7 @@ class Plan:
         self._defer = None
         self._cur_stream = 0
         self._side_streams = None
+        self.split_late = False            # trainer: ops of stream LATE are skipped by backward() and run by run_late()
         self.attn_parts = None
         self.buffers = []
         self._build()
@@ -279,7 +287,8 @@ class Plan:
         if self._defer is not None and not stream3:
             self._defer.append((spec, meta))      # runs in the segment's grouped launch (see flush_deferred)
             return
-        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta, stream=self._cur_stream))
+        stream = LATE if (self._tag == "dec" and self._cur_stream == 0) else self._cur_stream
+        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta, stream=stream))
 
     def flush_deferred(self, lst):
         """Emit ONE grouped weight-gradient launch for every wgrad deferred since `self._defer = []` (the small GEMMs
@@ -856,6 +865,9 @@ class Plan:
                 probe = L.WgradDesc()
                 probe.B, probe.IH, probe.IW, probe.OH, probe.OW = self.B, cw.stream3_geom[0], cw.stream3_geom[1], cw.stream3_geom[0], cw.stream3_geom[1]
                 probe.Cin, probe.Cout, probe.KH, probe.KW, probe.stride, probe.pad = cw.stream3_geom[2], cw.cout, 3, 3, 1, 1
+                wcap = getattr(self.model, "w3_total_wgs", None)      # set by TrainStep in late-wgrad mode
+                if wcap:
+                    probe.dw_partial_capacity = max(1, wcap // -(-cw.stream3_geom[2] // 64))
                 cw.dw_S = int(self.lib.crd_conv_wgrad_splits(C.byref(probe)))
             if cw.dw_S > 0:
                 cw.dw_parts = self.new((cw.dw_S, cw.cout, cw.taps, cw.cin_pad), F32)
@@ -1006,7 +1018,10 @@ class Plan:
                     del open_[op.stream]
                 continue
             sh = st
-            if op.stream:
+            if op.stream == LATE:
+                if self.split_late:
+                    continue                       # runs in run_late()
+            elif op.stream:
                 if op.stream not in open_:         # open the branch here: it sees everything enqueued on main so far
                     if self._side_streams is None:
                         self._side_streams = [torch.cuda.Stream(), torch.cuda.Stream()]
@@ -1053,10 +1068,25 @@ class Plan:
             if tags is not None and tag not in tags:
                 continue
             self.run_ops(self.bwd[a:b])
-            if tag in self.unpack_ranges:
+            if tag in self.unpack_ranges and not (tag == "dec" and self.split_late):
                 lo, hi, mx = self.unpack_ranges[tag]
                 L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1,
                                                   L.stream()), "crd_wgrad_unpack")
+
+    def run_late(self):
+        """The decoder's weight gradients and the un-packing of the decoder segment's gradients (split_late), on the
+        current stream."""
+        st = L.stream()
+        for tag, a, b in self.bwd_segments:
+            if tag != "dec":
+                continue
+            for op in self.bwd[a:b]:
+                if op.fn is not None and op.stream == LATE:
+                    rc = op.fn(*op.args, st)
+                    if rc != 0:
+                        raise L.CrdError(f"{op.name} failed ({rc}): {self.lib.crd_last_error().decode()}")
+        lo, hi, mx = self.unpack_ranges["dec"]
+        L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1, st), "crd_wgrad_unpack")
 
 
 class _WPtr:

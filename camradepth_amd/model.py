@@ -227,7 +227,7 @@ class CamRaDepth(nn.Module):
                              "(there is no CPU fallback; see oracle/ for the test-only CPU restatement)")
         if not self._flat_ok():
             self._reflatten()
-        key = (x.shape[0], x.shape[2], x.shape[3], self.training)
+        key = (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None))
         plan = self._plans.get(key)
         if plan is None:
             self._ensure_grad_views()
@@ -242,7 +242,7 @@ class CamRaDepth(nn.Module):
         outs = _Bridge.apply(self._anchor, x, self, masks)
         final, half, quarter = outs[0], outs[1], outs[2]
         seg = outs[3] if len(outs) > 3 else None
-        plan = self._plans[(x.shape[0], x.shape[2], x.shape[3], self.training)]
+        plan = self._plans[(x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None))]
         unsup = plan.unsup_map.clone() if plan.unsup_map is not None else None
         return {"depth": {"intermediate_depths": (None, None, quarter, half), "final_depth": final},
                 "seg": {"final_seg": seg, "intermediate_seg": None, "unsup_map": unsup}}

@@ -90,6 +90,14 @@ class TrainStep:
         self.dev = model.flat.device
         self.lib = L.load()
         x = torch.zeros((B, model.cfg.input_channels, H, W), device=self.dev)
+        self.sync = GradSync(model, group)
+        self.world = self.sync.world
+        self.dist_active = self.sync.active
+        # single-GPU graph step: the decoder's weight gradients run as a second graph next to the encoder's backward, with
+        # fewer workgroups (the plan sizes their partial-copy buffers accordingly)
+        from .engine import LATE_WGRAD, W3_LATE_WGS
+        self.late_wgrad = bool(LATE_WGRAD and use_graph and not self.dist_active)
+        model.w3_total_wgs = W3_LATE_WGS if self.late_wgrad else None
         self.plan = model._plan_for(x)
         model._ensure_grad_views()
         self.sup = model.cfg.supervised_seg
@@ -98,9 +106,6 @@ class TrainStep:
                    "seg": torch.zeros((B, H, W), dtype=torch.int64, device=self.dev)}
         self.acc = torch.zeros(16, device=self.dev)     # 4 x (sum, count, sum sq, -) for full/half/quarter/ce
         self.update_interval = update_interval
-        self.sync = GradSync(model, group)
-        self.world = self.sync.world
-        self.dist_active = self.sync.active
         # optimizer state over the flat buffers
         n = model.flat.numel()
         self.m, self.v, self.pg = (torch.zeros(n, device=self.dev) for _ in range(3))
@@ -185,6 +190,26 @@ class TrainStep:
         # undo the warm-up's parameter update side effects on the optimizer state
         for t in (self.m, self.v, self.pg, self.egn, self.nsq, self.fac):
             t.zero_()
+        if self.late_wgrad:
+            # [forward, loss, decoder backward] | [decoder weight gradients  ||  encoder backward] | optimizer: graph
+            # branches of ONE captured graph do not run concurrently on this stack, two graphs on two streams do
+            segs = self._segments()
+            self.plan.split_late = True
+            ga, gl, gb, go = (torch.cuda.CUDAGraph() for _ in range(4))
+            with torch.cuda.graph(ga):
+                segs[0][0](); segs[1][0]()
+            self.late_stream = torch.cuda.Stream()
+            self.late_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.graph(gl, stream=self.late_stream):
+                self.plan.run_late()
+            torch.cuda.current_stream().wait_stream(self.late_stream)
+            with torch.cuda.graph(gb):
+                for fn, _ in segs[2:-1]:
+                    fn()
+            with torch.cuda.graph(go):
+                segs[-1][0]()
+            self.graphs = [(("late", ga, gl, gb, go), None)]
+            return
         if not self.dist_active:      # no collective between the segments: the whole step is one graph (five fewer launches)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -223,7 +248,17 @@ class TrainStep:
         runs = self.graphs if self.use_graph else [(None, a) for _, a in self._segments()]
         fns = None if self.use_graph else [f for f, _ in self._segments()]
         for i, (g, after) in enumerate(runs):
-            if g is not None:
+            if isinstance(g, tuple):           # ("late", ga, gl, gb, go): see _capture
+                _, ga, gl, gb, go = g
+                main = torch.cuda.current_stream()
+                ga.replay()
+                self.late_stream.wait_stream(main)
+                with torch.cuda.stream(self.late_stream):
+                    gl.replay()
+                gb.replay()
+                main.wait_stream(self.late_stream)
+                go.replay()
+            elif g is not None:
                 g.replay()
             else:
                 fns[i]()

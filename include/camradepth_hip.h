@@ -107,11 +107,15 @@ typedef struct {
                          [S][Cout][9][Cin], contents don't-care.  Every pixel-range split stores its weight-gradient
                          block into its own copy with plain stores and dw is NOT touched: the gradient is the sum of the
                          S copies (crd_wgrad_unpack, replicas = S).  NULL: the splits add into dw with fp32 atomics. */
-  int32_t dw_partial_capacity;   /* copies dw_partials can hold (>= S) */
+  int32_t dw_partial_capacity;   /* copies dw_partials holds.  It also CAPS the number of splits (= workgroups per channel
+                                    chunk): the kernel uses min(natural split count, capacity) splits and writes exactly
+                                    crd_conv_wgrad_splits(d) copies -- a caller that runs other kernels next to this one
+                                    passes a small capacity to leave them CUs */
 } crd_wgrad_desc;
 
 int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream);
-/* Number of pixel-range splits the 3x3 streaming kernel uses for this problem, 0 if the generic kernel handles it. */
+/* Number of pixel-range splits the 3x3 streaming kernel uses for this problem (honouring d->dw_partial_capacity > 0 as
+ * a cap), 0 if the generic kernel handles it. */
 int crd_conv_wgrad_splits(const crd_wgrad_desc* d);
 
 /* Grouped weight gradients: the ~190 small wgrads of the encoder blocks (autograd's per-layer conv2d_backward weight

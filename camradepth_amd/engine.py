@@ -287,7 +287,7 @@ class Plan:
         if self._defer is not None and not stream3:
             self._defer.append((spec, meta))      # runs in the segment's grouped launch (see flush_deferred)
             return
-        stream = LATE if (self._tag == "dec" and self._cur_stream == 0) else self._cur_stream
+        stream = LATE if self._cur_stream == 0 else self._cur_stream     # nothing in the backward pass waits for a weight gradient
         lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta, stream=stream))
 
     def flush_deferred(self, lst):
@@ -297,7 +297,8 @@ class Plan:
         if not items:
             return
         meta = {"kernel": "k_wgrad_grouped", "flops": sum(m["flops"] for _, m in items), "shape": f"{len(items)} wgrads"}
-        lst.append(Op(self.lib.crd_conv_wgrad_grouped, [{"wg_group": [sp for sp, _ in items]}], "crd_conv_wgrad_grouped", meta=meta))
+        lst.append(Op(self.lib.crd_conv_wgrad_grouped, [{"wg_group": [sp for sp, _ in items]}], "crd_conv_wgrad_grouped", meta=meta,
+                      stream=LATE))
 
     def _make_group(self, specs):
         descs = (L.WgradDesc * len(specs))()
@@ -746,8 +747,9 @@ class Plan:
         g = []
         gen = ("blk", bi)
         DH, DHID, DHID2, DXN, DQ = sc["DH"], sc["DHID"], sc["DHID2"], sc["DXN"], sc["DQ"]
-        if self._defer is not None:      # operands of deferred weight gradients must outlive the block
+        if self._defer is not None:      # operands of deferred / late weight gradients must outlive the block
             DH, DHID2, DQ = self.act(Cs, Hs, Ws), self.act(hid, Hs, Ws), self.act(Cs, Hs, Ws)
+            DHID = self.act(hid, Hs, Ws)
         dh_out = None
         if want_next and FUSE_STATS and self._defer is not None:
             dh_out = (DH, dp)        # d(X2) arrives in bf16 from the next block's norm1 backward
@@ -761,8 +763,9 @@ class Plan:
         self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID, r=r2)           # in place: d(H2)
         dw10 = self.zb(DW_REPLICAS, 10, hid)      # [copy][9 taps + bias][channel]; the unpack kernel sums the copies
         self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
-        with self.side(1):       # off the chain: nothing below reads dw10 before the segment's unpack
-            self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
+        late = self._defer is not None   # off the chain: nothing reads dw10 before the segment's unpack, DHID is this block's own
+        op = self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
+        op.stream = LATE if late else op.stream
         # d(H1N), with the reduce phase of Mlp.norm1's backward fused in (it needs exactly this output and H1)
         r1 = self.zb(B * hid * 2 + B * (hid // 16) * 2)
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None,
@@ -816,7 +819,6 @@ class Plan:
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=1))
         self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1,                # DX = d(X)
                     dx2=dh_prev[0] if dh_prev else None, scale2=dh_prev[1] if dh_prev else None)
-        self.join(g, 1)           # the depthwise weight gradient reads DHID, which the next block overwrites
         self._push(g)
         return X2, nxt, dh_out
 
@@ -1068,25 +1070,28 @@ class Plan:
             if tags is not None and tag not in tags:
                 continue
             self.run_ops(self.bwd[a:b])
-            if tag in self.unpack_ranges and not (tag == "dec" and self.split_late):
+            if tag in self.unpack_ranges and not self.split_late:
                 lo, hi, mx = self.unpack_ranges[tag]
                 L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1,
                                                   L.stream()), "crd_wgrad_unpack")
 
-    def run_late(self):
-        """The decoder's weight gradients and the un-packing of the decoder segment's gradients (split_late), on the
-        current stream."""
+    def run_late(self, tags):
+        """split_late: the weight-gradient ops (stream LATE) of the segments in `tags` and the un-packing of those segments'
+        gradients, on the current stream.  Their inputs are forward activations and per-layer / per-block gradient buffers
+        that nothing overwrites before the next step."""
         st = L.stream()
         for tag, a, b in self.bwd_segments:
-            if tag != "dec":
+            if tag not in tags:
                 continue
             for op in self.bwd[a:b]:
                 if op.fn is not None and op.stream == LATE:
                     rc = op.fn(*op.args, st)
                     if rc != 0:
                         raise L.CrdError(f"{op.name} failed ({rc}): {self.lib.crd_last_error().decode()}")
-        lo, hi, mx = self.unpack_ranges["dec"]
-        L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1, st), "crd_wgrad_unpack")
+            if tag in self.unpack_ranges:
+                lo, hi, mx = self.unpack_ranges[tag]
+                L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1, st),
+                        "crd_wgrad_unpack")
 
 
 class _WPtr:

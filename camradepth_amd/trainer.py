@@ -195,20 +195,30 @@ class TrainStep:
             # branches of ONE captured graph do not run concurrently on this stack, two graphs on two streams do
             segs = self._segments()
             self.plan.split_late = True
-            ga, gl, gb, go = (torch.cuda.CUDAGraph() for _ in range(4))
+            self.late_stream = torch.cuda.Stream()
+            main = torch.cuda.current_stream()
+            chain = []                                       # [(main graph, late graph or None)]
+            keys = [k for _, k in segs[1:-1]]
+            ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
                 segs[0][0](); segs[1][0]()
-            self.late_stream = torch.cuda.Stream()
-            self.late_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.graph(gl, stream=self.late_stream):
-                self.plan.run_late()
-            torch.cuda.current_stream().wait_stream(self.late_stream)
-            with torch.cuda.graph(gb):
-                for fn, _ in segs[2:-1]:
+            mains = [ga]
+            for fn, _ in segs[2:-1]:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
                     fn()
+                mains.append(g)
+            for g, key in zip(mains, keys):
+                gl = torch.cuda.CUDAGraph()
+                self.late_stream.wait_stream(main)
+                with torch.cuda.graph(gl, stream=self.late_stream):
+                    self.plan.run_late(key)
+                main.wait_stream(self.late_stream)
+                chain.append((g, gl))
+            go = torch.cuda.CUDAGraph()
             with torch.cuda.graph(go):
                 segs[-1][0]()
-            self.graphs = [(("late", ga, gl, gb, go), None)]
+            self.graphs = [(("late", chain, go), None)]
             return
         if not self.dist_active:      # no collective between the segments: the whole step is one graph (five fewer launches)
             g = torch.cuda.CUDAGraph()
@@ -248,14 +258,14 @@ class TrainStep:
         runs = self.graphs if self.use_graph else [(None, a) for _, a in self._segments()]
         fns = None if self.use_graph else [f for f, _ in self._segments()]
         for i, (g, after) in enumerate(runs):
-            if isinstance(g, tuple):           # ("late", ga, gl, gb, go): see _capture
-                _, ga, gl, gb, go = g
+            if isinstance(g, tuple):           # ("late", [(main graph, late graph)], optimizer graph): see _capture
+                _, chain, go = g
                 main = torch.cuda.current_stream()
-                ga.replay()
-                self.late_stream.wait_stream(main)
-                with torch.cuda.stream(self.late_stream):
-                    gl.replay()
-                gb.replay()
+                for gm, gl in chain:
+                    gm.replay()
+                    self.late_stream.wait_stream(main)
+                    with torch.cuda.stream(self.late_stream):
+                        gl.replay()
                 main.wait_stream(self.late_stream)
                 go.replay()
             elif g is not None:

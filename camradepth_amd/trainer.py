@@ -93,10 +93,11 @@ class TrainStep:
         self.sync = GradSync(model, group)
         self.world = self.sync.world
         self.dist_active = self.sync.active
-        # single-GPU graph step: the decoder's weight gradients run as a second graph next to the encoder's backward, with
-        # fewer workgroups (the plan sizes their partial-copy buffers accordingly)
+        # graph step: the weight gradients of every backward segment run as graphs of their own on a second stream, next to the
+        # following segment's latency-bound chain; the decoder's streaming kernels with fewer workgroups (the plan sizes their
+        # partial-copy buffers accordingly)
         from .engine import LATE_WGRAD, W3_LATE_WGS
-        self.late_wgrad = bool(LATE_WGRAD and use_graph and not self.dist_active)
+        self.late_wgrad = bool(LATE_WGRAD and use_graph)
         model.w3_total_wgs = W3_LATE_WGS if self.late_wgrad else None
         self.plan = model._plan_for(x)
         model._ensure_grad_views()
@@ -191,34 +192,41 @@ class TrainStep:
         for t in (self.m, self.v, self.pg, self.egn, self.nsq, self.fac):
             t.zero_()
         if self.late_wgrad:
-            # [forward, loss, decoder backward] | [decoder weight gradients  ||  encoder backward] | optimizer: graph
-            # branches of ONE captured graph do not run concurrently on this stack, two graphs on two streams do
+            # main stream:  [forward, loss] [decoder backward] [enc3+enc2 backward] [enc1] [enc0]            [optimizer]
+            # late stream:                                    [decoder weight grads][enc3+enc2 ...]  ...  [enc0 ...]
+            # (branches of ONE captured graph do not run concurrently on this stack; separate graphs on two streams do).
+            # Multi-GPU: the loss all-reduce follows the first graph, and each bucket's gradient all-reduce is enqueued
+            # behind its late graph.
             segs = self._segments()
             self.plan.split_late = True
             self.late_stream = torch.cuda.Stream()
             main = torch.cuda.current_stream()
-            chain = []                                       # [(main graph, late graph or None)]
             keys = [k for _, k in segs[1:-1]]
-            ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                segs[0][0](); segs[1][0]()
-            mains = [ga]
-            for fn, _ in segs[2:-1]:
+            g0 = None
+            mains = []
+            if self.dist_active:
+                g0 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g0):
+                    segs[0][0]()
+            for i, (fn, _) in enumerate(segs[1:-1]):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
+                    if i == 0 and g0 is None:
+                        segs[0][0]()
                     fn()
                 mains.append(g)
+            chain = []                                       # [(main graph, late graph, bucket key)]
             for g, key in zip(mains, keys):
                 gl = torch.cuda.CUDAGraph()
                 self.late_stream.wait_stream(main)
                 with torch.cuda.graph(gl, stream=self.late_stream):
                     self.plan.run_late(key)
                 main.wait_stream(self.late_stream)
-                chain.append((g, gl))
+                chain.append((g, gl, key))
             go = torch.cuda.CUDAGraph()
             with torch.cuda.graph(go):
                 segs[-1][0]()
-            self.graphs = [(("late", chain, go), None)]
+            self.graphs = [(("late", g0, chain, go), None)]
             return
         if not self.dist_active:      # no collective between the segments: the whole step is one graph (five fewer launches)
             g = torch.cuda.CUDAGraph()
@@ -258,15 +266,22 @@ class TrainStep:
         runs = self.graphs if self.use_graph else [(None, a) for _, a in self._segments()]
         fns = None if self.use_graph else [f for f, _ in self._segments()]
         for i, (g, after) in enumerate(runs):
-            if isinstance(g, tuple):           # ("late", [(main graph, late graph)], optimizer graph): see _capture
-                _, chain, go = g
+            if isinstance(g, tuple):           # ("late", first graph, [(main graph, late graph, bucket)], optimizer graph)
+                _, g0, chain, go = g
                 main = torch.cuda.current_stream()
-                for gm, gl in chain:
+                if g0 is not None:
+                    g0.replay()
+                    dist.all_reduce(self.acc, group=self.sync.group)      # global loss denominators before the backward
+                for gm, gl, key in chain:
                     gm.replay()
                     self.late_stream.wait_stream(main)
                     with torch.cuda.stream(self.late_stream):
                         gl.replay()
+                        if self.dist_active:
+                            self.sync.launch(key)      # this bucket's all-reduce, behind the graph that finishes its gradients
                 main.wait_stream(self.late_stream)
+                if self.dist_active:
+                    self.sync.wait()
                 go.replay()
             elif g is not None:
                 g.replay()

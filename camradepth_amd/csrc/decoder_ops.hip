@@ -613,24 +613,43 @@ extern "C" int crd_head_conv2_fwd(const void* a, const float* w, const float* bi
   return CRD_OK;
 }
 
+static int head2_bwd_launch(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
+                            int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas, int parts,
+                            const char* who, crd_stream_t stream) {
+  CRD_CHECK_ARG(gd && a && (!(parts & 1) || (w && dz)) && (!(parts & 2) || (dw_rows && replicas >= 1)), "%s: null pointer / replicas < 1", who);
+  const bf16_t* addp = add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr;
+  hipStream_t st = as_stream(stream);
+  if (parts & 1)
+    hipLaunchKernelGGL(k_head2_bwd_data, dim3((unsigned)head2_blocks(H, W, B), B), dim3(TPB), 0, st, gd, addp, add_ld,
+                       reinterpret_cast<const bf16_t*>(a), w, H, W, reinterpret_cast<bf16_t*>(dz));
+  if (parts & 2) {
+    const int P = H * W;
+    int nblk = cdiv(P, 64 * 4);
+    int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
+    if (nblk > cap) nblk = cap;
+    const int chunk = cdiv(P, nblk);
+    nblk = cdiv(P, chunk);
+    hipLaunchKernelGGL(k_head2_wgrad, dim3(nblk, B), dim3(TPB), 0, st, gd, addp, add_ld, reinterpret_cast<const bf16_t*>(a), H, W, chunk,
+                       dw_rows, replicas);
+  }
+  CRD_LAUNCH_CHECK(who);
+  return CRD_OK;
+}
+
 extern "C" int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
                                   int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas,
                                   crd_stream_t stream) {
-  CRD_CHECK_ARG(gd && a && w && dz && dw_rows && replicas >= 1, "crd_head_conv2_bwd: null pointer / replicas < 1");
-  const bf16_t* addp = add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr;
-  hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(k_head2_bwd_data, dim3((unsigned)head2_blocks(H, W, B), B), dim3(TPB), 0, st, gd, addp, add_ld,
-                     reinterpret_cast<const bf16_t*>(a), w, H, W, reinterpret_cast<bf16_t*>(dz));
-  const int P = H * W;
-  int nblk = cdiv(P, 64 * 4);
-  int cap = 2048 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
-  if (nblk > cap) nblk = cap;
-  const int chunk = cdiv(P, nblk);
-  nblk = cdiv(P, chunk);
-  hipLaunchKernelGGL(k_head2_wgrad, dim3(nblk, B), dim3(TPB), 0, st, gd, addp, add_ld, reinterpret_cast<const bf16_t*>(a), H, W, chunk,
-                     dw_rows, replicas);
-  CRD_LAUNCH_CHECK("crd_head_conv2_bwd");
-  return CRD_OK;
+  return head2_bwd_launch(gd, add, add_ld, add_coff, a, w, B, H, W, dz, dw_rows, replicas, 3, "crd_head_conv2_bwd", stream);
+}
+
+extern "C" int crd_head_conv2_bwd_data(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a,
+                                       const float* w, int32_t B, int32_t H, int32_t W, void* dz, crd_stream_t stream) {
+  return head2_bwd_launch(gd, add, add_ld, add_coff, a, w, B, H, W, dz, nullptr, 0, 1, "crd_head_conv2_bwd_data", stream);
+}
+
+extern "C" int crd_head_conv2_wgrad(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, int32_t B,
+                                    int32_t H, int32_t W, float* dw_rows, int32_t replicas, crd_stream_t stream) {
+  return head2_bwd_launch(gd, add, add_ld, add_coff, a, nullptr, B, H, W, nullptr, dw_rows, replicas, 2, "crd_head_conv2_wgrad", stream);
 }
 
 extern "C" int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream) {

@@ -588,7 +588,8 @@ class Plan:
             rows = self.zb(HEAD_ROWS, 289)            # copies of [dw (288) | dbias]; the unpack kernel sums them
             self.row_grads.append((name + ".conv_2.weight", 288, rows, HEAD_ROWS, self._tag, 0, 289))
             self.row_grads.append((name + ".conv_2.bias", 1, rows, HEAD_ROWS, self._tag, 288, 289))
-            self._emit(grp, "crd_head_conv2_bwd", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t, rows, HEAD_ROWS])
+            self._emit(grp, "crd_head_conv2_bwd_data", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t])
+            self._emit(grp, "crd_head_conv2_wgrad", [gd.t, add[0], add[1], add[2], A.t, B, Hj, Wj, rows, HEAD_ROWS]).stream = LATE
             self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_1.bias"))
             self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
                       region=("ds", id(dsrc), 0, 128))

@@ -103,7 +103,7 @@ _SIGS = {
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_bwd": "ppppiiiiifpppppifppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
     "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiiip", "crd_scale_f32": "pplfp",
-    "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp", "crd_head_conv2_fwd": "pppiiippiip", "crd_head_conv2_bwd": "ppiippiiippip",
+    "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp", "crd_head_conv2_fwd": "pppiiippiip", "crd_head_conv2_bwd": "ppiippiiippip", "crd_head_conv2_bwd_data": "ppiippiiipp", "crd_head_conv2_wgrad": "ppiipiiipip",
     "crd_weight_pack": "pilp", "crd_wgrad_unpack": "pilip",
     "crd_assemble_input": "pppiiifpp", "crd_gt_pyramid": "piiifppppp",
     "crd_masked_l1_fwd": "pplpp", "crd_test_metrics": "ppilffpp", "crd_masked_l1_bwd": "pplppfpp", "crd_ce_fwd": "ppiilpp",

@@ -296,6 +296,12 @@ int crd_head_conv2_fwd(const void* a, const float* w, const float* bias, int32_t
  * fp32 atomics over the rows and the gradient is the sum of the rows (crd_wgrad_unpack, replicas = rows). */
 int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
                        int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas, crd_stream_t stream);
+/* The two halves of crd_head_conv2_bwd as calls of their own (the weight-gradient half is not on the backward pass's
+ * dependency chain: the graph step replays it on its late stream). */
+int crd_head_conv2_bwd_data(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
+                            int32_t B, int32_t H, int32_t W, void* dz, crd_stream_t stream);
+int crd_head_conv2_wgrad(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, int32_t B, int32_t H,
+                         int32_t W, float* dw_rows, int32_t replicas, crd_stream_t stream);
 /* da <- da * a * (1-a)   (bf16, n elements, n % 8 == 0): backward of the sigmoid in Depth_Activation */
 int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream);
 

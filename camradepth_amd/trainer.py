@@ -123,6 +123,16 @@ class TrainStep:
         self.b2s = torch.tensor(b2s, dtype=torch.int32, device=self.dev)
         self.b2c = torch.tensor(b2c, dtype=torch.int32, device=self.dev)
         self.nt, self.nblk = nt, len(b2s)
+        # per gradient bucket: its tensors' slice of the block tables and an `active` mask (the optimizer of a bucket can run
+        # as soon as that bucket's gradients are final -- on the late stream, behind their un-packing)
+        self.opt_parts = {}
+        for key, (lo, hi) in self.sync.ranges.items():
+            ts_ = [t for t, (a, _) in enumerate(seg) if lo <= a < hi]
+            blks = [i for i, t in enumerate(b2s) if lo <= seg[t][0] < hi]
+            assert ts_ == list(range(ts_[0], ts_[-1] + 1)) and blks == list(range(blks[0], blks[-1] + 1))
+            mask = torch.zeros(nt, dtype=torch.uint8)
+            mask[ts_[0]:ts_[-1] + 1] = 1
+            self.opt_parts[key] = (blks[0], len(blks), mask.to(self.dev))
         self.hp = torch.zeros(8, device=self.dev)
         self.hp_ring = [torch.zeros(8).pin_memory() for _ in range(64)]
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -156,12 +166,15 @@ class TrainStep:
                                               self.H * self.W, self.acc.data_ptr() + 48, None, LOSS_W[3] * scale,
                                               p.seg_grad_in.data_ptr(), st()), "crd_ce_focal_bwd")
 
-    def _optimizer(self):
+    def _optimizer(self, key=None):
+        """key: only the tensors of that gradient bucket (block-table slice + `active` mask)."""
         m = self.model
+        b0, nb, mask = (0, self.nblk, None) if key is None else self.opt_parts[key]
         L.check(self.lib.crd_diffgradnorm_step(m.flat.data_ptr(), m.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                                self.pg.data_ptr(), self.egn.data_ptr(), self.nsq.data_ptr(), self.fac.data_ptr(),
-                                               self.seg.data_ptr(), self.b2s.data_ptr(), self.b2c.data_ptr(), self.nt, self.nblk,
-                                               None, 0.0, 0.0, 0.0, 0.0, 0.0, 1, self.hp.data_ptr(), L.stream()),
+                                               self.seg.data_ptr(), self.b2s.data_ptr() + 4 * b0, self.b2c.data_ptr() + 4 * b0,
+                                               self.nt, nb, None if mask is None else mask.data_ptr(),
+                                               0.0, 0.0, 0.0, 0.0, 0.0, 1, self.hp.data_ptr(), L.stream()),
                 "crd_diffgradnorm_step")
 
     def _segments(self):
@@ -221,11 +234,15 @@ class TrainStep:
                 self.late_stream.wait_stream(main)
                 with torch.cuda.graph(gl, stream=self.late_stream):
                     self.plan.run_late(key)
+                    if not self.dist_active:       # this bucket's gradients are final: its optimizer slice follows at once
+                        self._optimizer(key)
                 main.wait_stream(self.late_stream)
                 chain.append((g, gl, key))
-            go = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(go):
-                segs[-1][0]()
+            go = None
+            if self.dist_active:                   # multi-GPU: the optimizer waits for the all-reduces
+                go = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(go):
+                    segs[-1][0]()
             self.graphs = [(("late", g0, chain, go), None)]
             return
         if not self.dist_active:      # no collective between the segments: the whole step is one graph (five fewer launches)
@@ -282,7 +299,8 @@ class TrainStep:
                 main.wait_stream(self.late_stream)
                 if self.dist_active:
                     self.sync.wait()
-                go.replay()
+                if go is not None:
+                    go.replay()
             elif g is not None:
                 g.replay()
             else:

@@ -143,6 +143,63 @@ def test_conv_wgrad(case):
         got2 = parts[:S].sum(0).cpu()[:, :, :Ci].reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
         assert_close(got2, w.grad, f"wgrad partials {case}", rel=2e-3, elem=4e-3)
         assert_close(db.cpu(), bias.grad, f"dbias partials {case}", rel=2e-3, elem=4e-3)
+        # a smaller capacity caps the number of splits (how the two-stream step leaves CUs to the kernels running next to it)
+        cap = max(1, S // 2)
+        parts2 = torch.full((cap + 1, Co, k * k, Cp), float("nan"), device="cuda")
+        d.dw_partials, d.dw_partial_capacity = P(parts2), cap
+        S2 = lb.crd_conv_wgrad_splits(C.byref(d))
+        assert 1 <= S2 <= cap
+        db.zero_()
+        ok(lb.crd_conv_wgrad(C.byref(d), lib.stream()), "crd_conv_wgrad capped partials")
+        assert bool(torch.isnan(parts2[S2:]).all()) and not bool(torch.isnan(parts2[:S2]).any())
+        got3 = parts2[:S2].sum(0).cpu()[:, :, :Ci].reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
+        assert_close(got3, w.grad, f"wgrad capped partials {case}", rel=2e-3, elem=4e-3)
+        assert_close(db.cpu(), bias.grad, f"dbias capped partials {case}", rel=2e-3, elem=4e-3)
+
+
+@pytest.mark.parametrize("H,W,with_add", [(9, 13, False), (16, 40, True)])
+def test_head_conv2_forward_backward(H, W, with_add):
+    """Depth_Activation.conv_2 (utils.py:283,288): 3x3, 32 -> 1, as a stencil-reduce; backward fused with the sigmoid
+    backward of conv_1's output; the data / weight-gradient halves also as calls of their own."""
+    lib, lb = L()
+    g = torch.Generator().manual_seed(21)
+    B = 2
+    a = bf(torch.sigmoid(torch.randn(B, 32, H, W, generator=g)))
+    w = 0.2 * torch.randn(1, 32, 3, 3, generator=g)
+    bias = torch.tensor([0.1])
+    apm = to_pm(a)                                                        # [B, H*W, 32] bf16
+    wd, bd = w.reshape(-1).contiguous().cuda(), bias.cuda()
+    depth = torch.zeros(B, H * W, device="cuda")
+    ok(lb.crd_head_conv2_fwd(P(apm), P(wd), P(bd), B, H, W, P(depth), None, 0, 0, lib.stream()), "head_conv2_fwd")
+    ref = bf(F.conv2d(a, bf(w), padding=1) + bias)
+    assert_close(depth.cpu().view(B, 1, H, W), ref, "depth", rel=4e-3, elem=1e-2)
+    # backward
+    gd = torch.randn(B, H * W, generator=g)
+    add = bf(torch.randn(B, H * W, 8, generator=g)) if with_add else None
+    dy = bf(gd + (add[..., 3] if with_add else 0.0)).view(B, 1, H, W)
+    aa = a.clone().requires_grad_(True)
+    ww = bf(w).clone().requires_grad_(True)
+    bb = bias.clone().requires_grad_(True)
+    F.conv2d(aa, ww, bb, padding=1).backward(dy)
+    dz_ref = aa.grad * a * (1 - a)
+    gdd = gd.cuda()
+    addd = add.to(torch.bfloat16).cuda() if with_add else None
+    rows = torch.zeros(4, 289, device="cuda")
+    dz = torch.zeros(B, H * W, 32, dtype=torch.bfloat16, device="cuda")
+    ok(lb.crd_head_conv2_bwd(P(gdd), P(addd), 8 if with_add else 0, 3 if with_add else 0, P(apm), P(wd), B, H, W, P(dz), P(rows), 4,
+                             lib.stream()), "head_conv2_bwd")
+    assert_close(dz.float().cpu().view(B, H, W, 32).permute(0, 3, 1, 2), dz_ref, "dz", rel=6e-3, elem=2e-2)
+    r = rows.sum(0).cpu()
+    assert_close(r[:288].view(32, 9), ww.grad.view(32, 9), "conv_2 dw", rel=2e-3, elem=4e-3)
+    assert_close(r[288:], bb.grad, "conv_2 dbias", rel=2e-3, elem=4e-3)
+    # the two halves on their own
+    rows2, dz2 = torch.zeros_like(rows), torch.zeros_like(dz)
+    ok(lb.crd_head_conv2_bwd_data(P(gdd), P(addd), 8 if with_add else 0, 3 if with_add else 0, P(apm), P(wd), B, H, W, P(dz2),
+                                  lib.stream()), "head_conv2_bwd_data")
+    ok(lb.crd_head_conv2_wgrad(P(gdd), P(addd), 8 if with_add else 0, 3 if with_add else 0, P(apm), B, H, W, P(rows2), 4, lib.stream()),
+       "head_conv2_wgrad")
+    assert torch.equal(dz2, dz)
+    assert_close(rows2.sum(0).cpu(), r, "rows (wgrad half)", rel=1e-5, elem=1e-5)
 
 
 @pytest.mark.parametrize("C_,gmul,xf32,act", [(64, 1, 1, 0), (96, 1, 0, 1), (512, 8, 0, 1), (160, 1, 1, 0), (640, 4, 0, 1),

@@ -183,6 +183,33 @@ def test_epilogues_sigmoid_residual_accumulate():
     assert_close(y.float().cpu(), y0 + F.conv2d(x, w).permute(0, 2, 3, 1), "accumulate")
 
 
+@pytest.mark.parametrize("Ci,Co,H,W,acc", [(640, 160, 16, 26, 0), (1024, 256, 8, 13, 0), (160, 160, 9, 7, 1), (128, 96, 12, 20, 0)])
+def test_fp32_residual_epilogue_with_sums(Ci, Co, H, W, acc):
+    """LDS-staged float4 epilogue: fp32 output = res + scale[b] * bf16(conv) (+ previous contents), GroupNorm sums of the
+    stored values per 16-channel slab and per channel -- on the split-K (deep K, small grid) and plain small-tile kernels,
+    with a partial last column tile."""
+    B = 2
+    g = torch.Generator().manual_seed(31)
+    x = bf(torch.randn(B, Ci, H, W, generator=g))
+    w = bf(torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5)
+    bias = torch.randn(Co, generator=g) * 0.1
+    conv = F.conv2d(x, w, bias)
+    xpm, wp = to_pm(x), pack_w(w)
+    res = torch.randn(B, H, W, Co, generator=g)
+    scale = torch.tensor([0.5, 1.25])
+    y0 = torch.randn(B, H, W, Co, generator=g) if acc else torch.zeros(B, H, W, Co)
+    yf = y0.clone().cuda()
+    st, ch = torch.zeros(B, Co // 16, 2, device="cuda"), torch.zeros(B, Co, 2, device="cuda")
+    run_conv(xpm, Ci, 0, B, H, W, Ci, wp, Co, 1, 1, 1, 0, H, W, yf, Co, 0, y_f32=1, bias=bias.cuda(), res=res.cuda(),
+             res_ld=Co, res_scale=scale.cuda(), accumulate=acc, stats=st, chan=ch)
+    ref = res + scale.view(B, 1, 1, 1) * bf(conv).permute(0, 2, 3, 1) + y0
+    assert_close(yf.cpu(), ref, "fp32 residual output", rel=2e-3, elem=6e-3)
+    yd = yf.double().cpu().view(B, H * W, Co)
+    chr_ = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
+    assert_close(ch.cpu(), chr_, "channel sums", rel=1e-5, elem=1e-5)
+    assert_close(st.cpu(), chr_.view(B, Co // 16, 16, 2).sum(2), "g16 sums", rel=1e-5, elem=1e-5)
+
+
 DGRAD_CASES = [
     # B, Cin, H, W, Cout, k, stride, pad   (forward conv geometry; we test its data gradient)
     (2, 136, 11, 13, 96, 3, 1, 1),

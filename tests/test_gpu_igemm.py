@@ -287,6 +287,11 @@ def test_conv_dgrad_patch_scatter(k, C):
     dx = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda")
     run_conv(dypm, C, 0, B, PH, PW, C, ws, k * k * C, 1, 1, 1, 0, PH, PW, dx, C, 0, out_mode=1, patch_k=k, patch_c=C)
     assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, f"scatter k={k}")
+    # accumulate into an existing bf16 gradient (how the sr path adds into d(XN)) -- the 16-byte read-modify-write epilogue
+    base = bf(torch.randn(B, H, W, C, generator=g))
+    dx2 = base.to(torch.bfloat16).cuda()
+    run_conv(dypm, C, 0, B, PH, PW, C, ws, k * k * C, 1, 1, 1, 0, PH, PW, dx2, C, 0, out_mode=1, patch_k=k, patch_c=C, accumulate=1)
+    assert_close(dx2.float().cpu(), base + dx.float().cpu(), f"scatter accumulate k={k}", rel=4e-3, elem=1e-2)
 
 
 def test_bad_arguments_are_reported():

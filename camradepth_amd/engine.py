@@ -167,6 +167,11 @@ class Plan:
         self.split_late = False            # trainer: ops of stream LATE are skipped by backward() and run by run_late()
         self.attn_parts = None
         self.buffers = []
+        # parameters with requires_grad=False (the reference's optimizer skips `grad is None`, diffGradNorm.py:54-55):
+        # their weight-gradient launches are not recorded and whatever fused kernels still produce for them lands in a
+        # scratch buffer instead of the flat gradient
+        self.frozen = frozenset(n for n in model._names if not model._param(n).requires_grad)
+        self._dump = {}
         self._build()
 
     # ------------------------------------------------------------------ allocation helpers
@@ -275,6 +280,8 @@ class Plan:
         return op
 
     def wgrad(self, lst, x, dy, cw, k, stride, pad, OH, OW, dbias=None, cin=None):
+        if cw.frozen:                 # no trainable parameter behind this launch
+            return
         spec = dict(wg=True, x=x, dy=dy, cw=cw, k=k, stride=stride, pad=pad, OH=OH, OW=OW, dbias=dbias,
                     cin=cin if cin is not None else x.C)
         stream3 = k == 3 and stride == 1 and OW >= 32 and OH >= 8
@@ -282,7 +289,7 @@ class Plan:
             cw.stream3_geom = (x.H, x.W, spec["cin"])
         kname = ("k_wgrad3x3<2,4,1>" if cw.cout <= 32 else "k_wgrad3x3<2,4,2>" if cw.cout <= 64 else "k_wgrad3x3<2,4,3>" if cw.cout <= 96 else "k_wgrad3x3<4,2,2>") if stream3 \
             else wgrad_tile(cw.cout)
-        meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps,
+        meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps, "param": cw.name,
                 "shape": f"wgrad Cin{spec['cin']} Cout{cw.cout} k{k} s{stride} out{OH}x{OW}"}
         if self._defer is not None and not stream3:
             self._defer.append((spec, meta))      # runs in the segment's grouped launch (see flush_deferred)
@@ -296,7 +303,8 @@ class Plan:
         items, self._defer = self._defer, None
         if not items:
             return
-        meta = {"kernel": "k_wgrad_grouped", "flops": sum(m["flops"] for _, m in items), "shape": f"{len(items)} wgrads"}
+        meta = {"kernel": "k_wgrad_grouped", "flops": sum(m["flops"] for _, m in items), "shape": f"{len(items)} wgrads",
+                "params": [m["param"] for _, m in items]}
         lst.append(Op(self.lib.crd_conv_wgrad_grouped, [{"wg_group": [sp for sp, _ in items]}], "crd_conv_wgrad_grouped", meta=meta,
                       stream=LATE))
 
@@ -364,7 +372,15 @@ class Plan:
         return self.model.param_view(name)
 
     def g(self, name):
+        if name in self.frozen:
+            if name not in self._dump:
+                self._dump[name] = self.new(tuple(self.model._param(name).shape), F32)
+            return self._dump[name]
         return self.model.grad_view(name)
+
+    def is_frozen(self, *names):
+        """True when every existing parameter among `names` is frozen."""
+        return all(n in self.frozen for n in names if self.model.has_param(n))
 
     def new_conv(self, name, cmap=None, need_dgrad=True, scatter=False):
         w = self.p(name + ".weight")
@@ -372,6 +388,7 @@ class Plan:
         k = w.shape[2] if w.dim() == 4 else 1
         bias = self.p(name + ".bias") if self.model.has_param(name + ".bias") else None
         cw = ConvW(name, cout, cin_ref, k, cmap, bias, need_dgrad, scatter)
+        cw.frozen = self.is_frozen(name + ".weight", name + ".bias")
         cw.tag = self._tag
         self.convs.append(cw)
         return cw
@@ -589,7 +606,8 @@ class Plan:
             self.row_grads.append((name + ".conv_2.weight", 288, rows, HEAD_ROWS, self._tag, 0, 289))
             self.row_grads.append((name + ".conv_2.bias", 1, rows, HEAD_ROWS, self._tag, 288, 289))
             self._emit(grp, "crd_head_conv2_bwd_data", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t])
-            self._emit(grp, "crd_head_conv2_wgrad", [gd.t, add[0], add[1], add[2], A.t, B, Hj, Wj, rows, HEAD_ROWS]).stream = LATE
+            if not self.is_frozen(name + ".conv_2.weight", name + ".conv_2.bias"):
+                self._emit(grp, "crd_head_conv2_wgrad", [gd.t, add[0], add[1], add[2], A.t, B, Hj, Wj, rows, HEAD_ROWS]).stream = LATE
             self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_1.bias"))
             self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
                       region=("ds", id(dsrc), 0, 128))
@@ -765,8 +783,9 @@ class Plan:
         dw10 = self.zb(DW_REPLICAS, 10, hid)      # [copy][9 taps + bias][channel]; the unpack kernel sums the copies
         self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
         late = self._defer is not None   # off the chain: nothing reads dw10 before the segment's unpack, DHID is this block's own
-        op = self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
-        op.stream = LATE if late else op.stream
+        if not self.is_frozen(ml + ".dwconv.dwconv.weight", ml + ".dwconv.dwconv.bias"):
+            op = self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
+            op.stream = LATE if late else op.stream
         # d(H1N), with the reduce phase of Mlp.norm1's backward fused in (it needs exactly this output and H1)
         r1 = self.zb(B * hid * 2 + B * (hid // 16) * 2)
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None,
@@ -864,6 +883,8 @@ class Plan:
             # weight-gradient destination: direct into the flat gradient for identity layouts, else scratch + unpack.
             # The streaming 3x3 kernel splits the pixels S ways; each split stores its block into its own copy (no
             # atomics, nothing to zero) and the segment's unpack kernel sums the copies.
+            if cw.frozen:                  # no weight-gradient launch was recorded: nothing to accumulate or un-pack
+                continue
             if cw.stream3_geom is not None and W3_PARTIALS:
                 probe = L.WgradDesc()
                 probe.B, probe.IH, probe.IW, probe.OH, probe.OW = self.B, cw.stream3_geom[0], cw.stream3_geom[1], cw.stream3_geom[0], cw.stream3_geom[1]
@@ -1054,10 +1075,13 @@ class Plan:
                 self.d2_masks.copy_(torch.stack([t.to(self.dev, F32) for t in masks["dropout2d"]]))
             else:
                 nblk, n_drop = self.dp_masks.shape[0], self.d2_masks.shape[0]
+                # one RNG stream per data-parallel rank: the reference's single process draws independent masks for
+                # every sample of the gathered batch (CamRaDepth.py:96, simplified_attention.py:123); rank 0 keeps `seed`
+                seed = (self.model.seed + getattr(self.model, "rng_rank", 0) * 0x632BE59BD9B4E019) & 0xFFFFFFFFFFFFFFFF
                 L.check(self.lib.crd_dropout_masks(self.dp_masks.data_ptr(), self.dp_keep.data_ptr(), nblk, self.B,
-                                                   self.model.seed, self.rng_counter.data_ptr(), st), "crd_dropout_masks")
+                                                   seed, self.rng_counter.data_ptr(), st), "crd_dropout_masks")
                 L.check(self.lib.crd_dropout_masks(self.d2_masks.data_ptr(), self.d2_keep.data_ptr(), n_drop * self.B,
-                                                   MID_CHANNELS, self.model.seed + 1, self.rng_counter.data_ptr(), st),
+                                                   MID_CHANNELS, (seed + 1) & 0xFFFFFFFFFFFFFFFF, self.rng_counter.data_ptr(), st),
                         "crd_dropout_masks")
         self.run_ops(self.fwd)
 

@@ -92,6 +92,7 @@ class CamRaDepth(nn.Module):
         self.img_size = tuple(img_size)
         self.supervised_seg, self.unsupervised_seg = bool(supervised_seg), bool(unsupervised_seg)
         self.seed = int(seed)
+        self.rng_rank = 0            # data-parallel rank: selects the Dropout2d / DropPath stream (set by TrainStep)
         self._specs = param_specs(self.cfg)
         self._names = [n for n, _ in self._specs]
         self._index = {n: i for i, n in enumerate(self._names)}
@@ -187,6 +188,9 @@ class CamRaDepth(nn.Module):
         fg = self.flat_grad
         for name, o in zip(self._names, self._offsets):
             p = self._param(name)
+            if not p.requires_grad:          # frozen: `grad is None`, which the optimizer skips (diffGradNorm.py:54-55)
+                p.grad = None
+                continue
             if p.grad is None or p.grad.data_ptr() != fg.data_ptr() + 4 * o:
                 if p.grad is None:
                     fg[o:o + p.numel()].zero_()
@@ -227,13 +231,17 @@ class CamRaDepth(nn.Module):
                              "(there is no CPU fallback; see oracle/ for the test-only CPU restatement)")
         if not self._flat_ok():
             self._reflatten()
-        key = (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None))
+        key = self._plan_key(x)
         plan = self._plans.get(key)
         if plan is None:
             self._ensure_grad_views()
             plan = Plan(self, x.shape[0], x.shape[2], x.shape[3], self.training)
             self._plans[key] = plan
         return plan
+
+    def _plan_key(self, x):
+        frozen = tuple(i for i, n in enumerate(self._names) if not self._param(n).requires_grad)
+        return (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None), frozen)
 
     def forward(self, x, masks=None):
         """Returns the reference's nested dict (CamRaDepth.py:169-170).  `masks` optionally injects the
@@ -242,7 +250,7 @@ class CamRaDepth(nn.Module):
         outs = _Bridge.apply(self._anchor, x, self, masks)
         final, half, quarter = outs[0], outs[1], outs[2]
         seg = outs[3] if len(outs) > 3 else None
-        plan = self._plans[(x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None))]
+        plan = self._plans[self._plan_key(x)]
         unsup = plan.unsup_map.clone() if plan.unsup_map is not None else None
         return {"depth": {"intermediate_depths": (None, None, quarter, half), "final_depth": final},
                 "seg": {"final_seg": seg, "intermediate_seg": None, "unsup_map": unsup}}

@@ -90,14 +90,18 @@ class diffGradNorm(Optimizer):
         for group, st in zip(self.param_groups, self._groups):
             ps, offs = st["ps"], st["offs"]
             # gradient source: in place when the grads are views of one buffer parallel to the params
-            g0 = ps[0].grad
             act_host = [p.grad is not None for p in ps]
             if not any(act_host):
                 continue
-            parallel = g0 is not None and all(
-                p.grad is not None and (p.grad.data_ptr() - g0.data_ptr()) == 4 * (o - offs[0]) for p, o in zip(ps, offs))
+            i0 = act_host.index(True)
+            g0 = ps[i0].grad
+            # frozen parameters (grad None) are skipped through the `active` mask; the others' grads are used in place
+            parallel = all(p.grad is None or (p.grad.data_ptr() - g0.data_ptr()) == 4 * (o - offs[i0]) for p, o in zip(ps, offs))
             if parallel:
-                gptr = g0.data_ptr() - 4 * offs[0]
+                gptr = g0.data_ptr() - 4 * offs[i0]
+                if act_host != st.get("act_host"):
+                    st["active"].copy_(torch.tensor(act_host, dtype=torch.uint8))
+                    st["act_host"] = act_host
             else:
                 fg = st["flat_g"]
                 for p, o in zip(ps, offs):
@@ -105,17 +109,19 @@ class diffGradNorm(Optimizer):
                         fg[o:o + p.numel()].copy_(p.grad.reshape(-1))
                 gptr = fg.data_ptr()
                 st["active"].copy_(torch.tensor(act_host, dtype=torch.uint8))
+                st["act_host"] = None
             st["step"] += 1
             beta1, beta2 = group["betas"]
             pbase = st["flat_p"].data_ptr() if st["flat_p"] is not None else st["base"]
             L.check(lb.crd_diffgradnorm_step(pbase, gptr, st["m"].data_ptr(), st["v"].data_ptr(), st["pg"].data_ptr(),
                                              st["egn"].data_ptr(), st["nsq"].data_ptr(), st["fac"].data_ptr(),
                                              st["seg"].data_ptr(), st["b2s"].data_ptr(), st["b2c"].data_ptr(), len(ps),
-                                             st["nblk"], None if parallel else st["active"].data_ptr(), float(group["lr"]),
+                                             st["nblk"], None if all(act_host) else st["active"].data_ptr(), float(group["lr"]),
                                              float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
                                              st["step"], None, L.stream()), "crd_diffgradnorm_step")
-            for p in ps:
-                self.state[p]["step"] = st["step"]
+            for p, a_ in zip(ps, act_host):
+                if a_:
+                    self.state[p]["step"] += 1
         return loss
 
     def load_state_dict(self, state_dict):

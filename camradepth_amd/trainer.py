@@ -83,9 +83,18 @@ class GradSync:
 
 
 class TrainStep:
+    """One training ITERATION per step() call (runner.py:179-270).  With update_interval = k the gradients of k
+    iterations accumulate in the flat gradient buffer (zeroed on the first, runner.py:175,266), the gradient all-reduce
+    and diffGradNorm run on the k-th (runner.py:222,264), each loss is divided by k (runner.py:218).  The schedule
+    entry used by an optimizer step follows the reference's scheduler lag: `scheduler.step()` is only called from the
+    (k+1)-th iteration of an epoch on (runner.py:269-270); start_epoch() marks the epoch boundary.  Parameters with
+    requires_grad=False are frozen: no weight-gradient launch is recorded for them and the optimizer skips them
+    (diffGradNorm.py:54-55)."""
+
     def __init__(self, model, B, H, W, lr=6e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, update_interval=1,
                  use_graph=True, schedule=None, group=None):
         assert model.training, "TrainStep drives the training path: call model.train() first"
+        assert update_interval >= 1
         self.model, self.B, self.H, self.W = model, B, H, W
         self.dev = model.flat.device
         self.lib = L.load()
@@ -93,6 +102,7 @@ class TrainStep:
         self.sync = GradSync(model, group)
         self.world = self.sync.world
         self.dist_active = self.sync.active
+        model.rng_rank = dist.get_rank(group) if dist.is_initialized() else 0
         # graph step: the weight gradients of every backward segment run as graphs of their own on a second stream, next to the
         # following segment's latency-bound chain; the decoder's streaming kernels with fewer workgroups (the plan sizes their
         # partial-copy buffers accordingly)
@@ -123,6 +133,9 @@ class TrainStep:
         self.b2s = torch.tensor(b2s, dtype=torch.int32, device=self.dev)
         self.b2c = torch.tensor(b2c, dtype=torch.int32, device=self.dev)
         self.nt, self.nblk = nt, len(b2s)
+        trainable = torch.tensor([1 if model._param(n_).requires_grad else 0 for n_ in model._names], dtype=torch.uint8)
+        self.frozen_names = [n_ for n_ in model._names if not model._param(n_).requires_grad]
+        self.trainable_mask = trainable.to(self.dev) if self.frozen_names else None
         # per gradient bucket: its tensors' slice of the block tables and an `active` mask (the optimizer of a bucket can run
         # as soon as that bucket's gradients are final -- on the late stream, behind their un-packing)
         self.opt_parts = {}
@@ -132,18 +145,30 @@ class TrainStep:
             assert ts_ == list(range(ts_[0], ts_[-1] + 1)) and blks == list(range(blks[0], blks[-1] + 1))
             mask = torch.zeros(nt, dtype=torch.uint8)
             mask[ts_[0]:ts_[-1] + 1] = 1
-            self.opt_parts[key] = (blks[0], len(blks), mask.to(self.dev))
+            self.opt_parts[key] = (blks[0], len(blks), (mask & trainable).to(self.dev))
         self.hp = torch.zeros(8, device=self.dev)
         self.hp_ring = [torch.zeros(8).pin_memory() for _ in range(64)]
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
-        self.schedule, self.step_count = schedule, 0
+        self.schedule = schedule
+        self.iter_count = 0          # iterations (micro-batches) seen
+        self.epoch_iter = 0          # ... in the current epoch (scheduler lag, runner.py:269)
+        self.sched_steps = 0         # scheduler.step() calls so far = index into `schedule`
+        self.step_count = 0          # optimizer steps taken
         self.use_graph = use_graph
         self.graphs = None
+        self._zero, self._opt = True, True
+        self._window_open, self._window_pos = False, 0
+
+    def start_epoch(self):
+        """Epoch boundary of the reference loop: the batch index restarts (scheduler lag) and pending accumulated
+        gradients were flushed by step(last_of_epoch=True)."""
+        self.epoch_iter = 0
 
     # ------------------------------------------------------------------ pieces of one step
     def _forward_and_loss_partials(self):
         p, st = self.plan, L.stream
-        self.model.flat_grad.zero_()
+        if self._zero:
+            self.model.flat_grad.zero_()
         self.acc.zero_()
         p.forward()
         for i, (j, key) in enumerate(((5, "full"), (4, "half"), (3, "quarter"))):
@@ -169,7 +194,7 @@ class TrainStep:
     def _optimizer(self, key=None):
         """key: only the tensors of that gradient bucket (block-table slice + `active` mask)."""
         m = self.model
-        b0, nb, mask = (0, self.nblk, None) if key is None else self.opt_parts[key]
+        b0, nb, mask = (0, self.nblk, self.trainable_mask) if key is None else self.opt_parts[key]
         L.check(self.lib.crd_diffgradnorm_step(m.flat.data_ptr(), m.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
                                                self.pg.data_ptr(), self.egn.data_ptr(), self.nsq.data_ptr(), self.fac.data_ptr(),
                                                self.seg.data_ptr(), self.b2s.data_ptr() + 4 * b0, self.b2c.data_ptr() + 4 * b0,
@@ -178,7 +203,8 @@ class TrainStep:
                 "crd_diffgradnorm_step")
 
     def _segments(self):
-        """The step as a list of (callable, bucket-to-launch-after | None | 'loss')."""
+        """The iteration as a list of (callable, bucket-to-launch-after | None | 'loss'), for the current
+        (self._zero, self._opt): zero the gradients first / all-reduce and run the optimizer last."""
         segs = [(self._forward_and_loss_partials, "loss")]
         first = True
         for key in GradSync.ORDER:
@@ -186,42 +212,62 @@ class TrainStep:
                 if first:
                     self._loss_backward()
                 self.plan.backward(tags=key)
-            segs.append((run, key))
+            segs.append((run, key if self._opt else None))
             first = False
-        segs.append((self._optimizer, None))
+        if self._opt:
+            segs.append((self._optimizer, None))
         return segs
 
+    def _variants(self):
+        k = self.update_interval
+        if k == 1:
+            return [(True, True)]
+        return [(True, False)] + ([(False, False)] if k > 2 else []) + [(False, True)]
+
     def _capture(self):
-        self.graphs = []
-        # warm up eagerly once on a side stream (allocator, lazy module loading) before capture
+        """Captures one set of graphs per (zero gradients, optimizer) variant the accumulation schedule needs.  Capturing
+        executes nothing; one eager warm-up iteration runs first (allocator, lazy module loading) and every buffer it
+        changes is restored afterwards."""
+        saved = [t.clone() for t in (self.model.flat, self.m, self.v, self.pg, self.egn, self.nsq, self.fac, self.model.flat_grad)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
+        self._zero, self._opt = True, True
         with torch.cuda.stream(s):
             for fn, _ in self._segments():
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        # undo the warm-up's parameter update side effects on the optimizer state
-        for t in (self.m, self.v, self.pg, self.egn, self.nsq, self.fac):
-            t.zero_()
+        self.graphs = {}
+        if self.late_wgrad:
+            self.plan.split_late = True
+            self.late_stream = torch.cuda.Stream()
+        for zero, opt in self._variants():
+            self._zero, self._opt = zero, opt
+            self.graphs[(zero, opt)] = self._capture_variant()
+        torch.cuda.synchronize()
+        for t, sv in zip((self.model.flat, self.m, self.v, self.pg, self.egn, self.nsq, self.fac, self.model.flat_grad), saved):
+            t.copy_(sv)
+
+    def _capture_variant(self):
+        graphs = []
+        opt = self._opt
         if self.late_wgrad:
             # main stream:  [forward, loss] [decoder backward] [enc3+enc2 backward] [enc1] [enc0]            [optimizer]
             # late stream:                                    [decoder weight grads][enc3+enc2 ...]  ...  [enc0 ...]
             # (branches of ONE captured graph do not run concurrently on this stack; separate graphs on two streams do).
             # Multi-GPU: the loss all-reduce follows the first graph, and each bucket's gradient all-reduce is enqueued
-            # behind its late graph.
+            # behind its late graph (last iteration of an accumulation window only).
             segs = self._segments()
-            self.plan.split_late = True
-            self.late_stream = torch.cuda.Stream()
             main = torch.cuda.current_stream()
-            keys = [k for _, k in segs[1:-1]]
+            bsegs = segs[1:-1] if opt else segs[1:]
+            keys = list(GradSync.ORDER)
             g0 = None
             mains = []
             if self.dist_active:
                 g0 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g0):
                     segs[0][0]()
-            for i, (fn, _) in enumerate(segs[1:-1]):
+            for i, (fn, _) in enumerate(bsegs):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     if i == 0 and g0 is None:
@@ -234,29 +280,28 @@ class TrainStep:
                 self.late_stream.wait_stream(main)
                 with torch.cuda.graph(gl, stream=self.late_stream):
                     self.plan.run_late(key)
-                    if not self.dist_active:       # this bucket's gradients are final: its optimizer slice follows at once
+                    if opt and not self.dist_active:    # this bucket's gradients are final: its optimizer slice follows at once
                         self._optimizer(key)
                 main.wait_stream(self.late_stream)
                 chain.append((g, gl, key))
             go = None
-            if self.dist_active:                   # multi-GPU: the optimizer waits for the all-reduces
+            if self.dist_active and opt:           # multi-GPU: the optimizer waits for the all-reduces
                 go = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(go):
                     segs[-1][0]()
-            self.graphs = [(("late", g0, chain, go), None)]
-            return
+            return [(("late", g0, chain, go), None)]
         if not self.dist_active:      # no collective between the segments: the whole step is one graph (five fewer launches)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 for fn, _ in self._segments():
                     fn()
-            self.graphs.append((g, None))
-            return
+            return [(g, None)]
         for fn, after in self._segments():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 fn()
-            self.graphs.append((g, after))
+            graphs.append((g, after))
+        return graphs
 
     def set_batch(self, batch):
         self.plan.x_in.copy_(batch["image"], non_blocking=True)
@@ -266,21 +311,30 @@ class TrainStep:
         if "seg" in batch:
             self.gt["seg"].copy_(batch["seg"], non_blocking=True)
 
-    def step(self):
-        """One optimizer step on the batch currently in the static input buffers (set_batch)."""
-        self.step_count += 1
-        lr, b1 = (self.schedule[min(self.step_count - 1, len(self.schedule) - 1)] if self.schedule else (self.lr, self.betas[0]))
-        b2 = self.betas[1]
-        bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
-        hp_host = self.hp_ring[self.step_count % len(self.hp_ring)]   # ring: the async copy may still be pending
-        hp_host[0], hp_host[1], hp_host[2], hp_host[3] = b1, b2, self.eps, self.wd
-        hp_host[4] = lr * math.sqrt(bc2) / (bc1 + 1e-8)
-        self.hp.copy_(hp_host, non_blocking=True)
+    def step(self, last_of_epoch=False):
+        """One iteration on the batch currently in the static input buffers (set_batch): forward, losses, backward into
+        the accumulating gradient buffer and -- on every update_interval-th iteration or the last of an epoch
+        (runner.py:222) -- gradient all-reduce + optimizer step.  Returns True when the optimizer ran."""
+        k = self.update_interval
+        zero = not self._window_open             # first iteration of an accumulation window: zero the gradients
+        pos = self._window_pos if self._window_open else 0
+        opt = (pos + 1 == k) or last_of_epoch
+        self._zero, self._opt = zero, opt
+        if opt:
+            self.step_count += 1
+            lr, b1 = (self.schedule[min(self.sched_steps, len(self.schedule) - 1)] if self.schedule else (self.lr, self.betas[0]))
+            b2 = self.betas[1]
+            bc1, bc2 = 1.0 - b1 ** self.step_count, 1.0 - b2 ** self.step_count
+            hp_host = self.hp_ring[self.step_count % len(self.hp_ring)]   # ring: the async copy may still be pending
+            hp_host[0], hp_host[1], hp_host[2], hp_host[3] = b1, b2, self.eps, self.wd
+            hp_host[4] = lr * math.sqrt(bc2) / (bc1 + 1e-8)
+            self.hp.copy_(hp_host, non_blocking=True)
         if self.use_graph and self.graphs is None:
-            params = self.model.flat.clone()
             self._capture()
-            self.model.flat.copy_(params)          # capture warm-up must not count as a training step
-        runs = self.graphs if self.use_graph else [(None, a) for _, a in self._segments()]
+            self._zero, self._opt = zero, opt
+        if self.use_graph and (zero, opt) not in self.graphs:      # e.g. a flush right after an update (last_of_epoch)
+            self.graphs[(zero, opt)] = self._capture_variant()
+        runs = self.graphs[(zero, opt)] if self.use_graph else [(None, a) for _, a in self._segments()]
         fns = None if self.use_graph else [f for f, _ in self._segments()]
         for i, (g, after) in enumerate(runs):
             if isinstance(g, tuple):           # ("late", first graph, [(main graph, late graph, bucket)], optimizer graph)
@@ -294,10 +348,10 @@ class TrainStep:
                     self.late_stream.wait_stream(main)
                     with torch.cuda.stream(self.late_stream):
                         gl.replay()
-                        if self.dist_active:
+                        if self.dist_active and opt:
                             self.sync.launch(key)      # this bucket's all-reduce, behind the graph that finishes its gradients
                 main.wait_stream(self.late_stream)
-                if self.dist_active:
+                if self.dist_active and opt:
                     self.sync.wait()
                 if go is not None:
                     go.replay()
@@ -310,11 +364,18 @@ class TrainStep:
                     dist.all_reduce(self.acc, group=self.sync.group)
             elif after is not None and self.dist_active:
                 self.sync.launch(after)
-                if i == len(runs) - 2:
+                if after == GradSync.ORDER[-1]:
                     self.sync.wait()
+        # bookkeeping of the reference loop
+        self.iter_count += 1
+        self.epoch_iter += 1
+        self._window_open, self._window_pos = (not opt), (pos + 1)
+        if self.epoch_iter > k:                # "to prevent a scheduler step before the optimizer step" (runner.py:269-270)
+            self.sched_steps += 1
+        return opt
 
     def losses(self):
-        """Host view of the last step's loss terms (synchronises)."""
+        """Host view of the last iteration's loss terms (synchronises)."""
         a = self.acc.cpu()
         full, half, quarter = (float(a[4 * i] / a[4 * i + 1]) for i in range(3))
         rmse = math.sqrt(float(a[2] / a[1]))

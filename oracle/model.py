@@ -68,6 +68,7 @@ def attention_maxpool(sd, name, x, H, W, heads, sr, quant=None, taps=None):
     attn, idx = torch.max(attn, -1)                                       # [B, heads, N]
     if taps is not None:
         taps[name + ".rowmax"] = attn
+        taps[name + ".argmax"] = idx            # [B, heads, N]: the key torch.max routes the gradient to
     out = _q(_q(attn.transpose(-2, -1), quant) @ _q(v, quant), quant)     # [B, N, C]
     out = out.transpose(-2, -1)
     return _conv1d(out, sd[name + ".proj.weight"], sd[name + ".proj.bias"], quant)

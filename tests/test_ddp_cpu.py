@@ -67,6 +67,72 @@ def test_gradsync_and_global_loss_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _worker_step(rank, world, port, q):
+    """TrainStep.step()'s control flow (accumulation windows, loss all-reduce every iteration, bucket all-reduces and
+    optimizer only on the closing iteration) with the HIP segments replaced by CPU stand-ins."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from camradepth_amd.model import CamRaDepth
+        from camradepth_amd.trainer import GradSync, TrainStep
+        m = CamRaDepth(input_channels=7, depths=(1, 1, 1, 1))
+        m._ensure_grad_views()
+        ts = object.__new__(TrainStep)
+        ts.model, ts.sync = m, GradSync(m)
+        ts.dist_active, ts.world, ts.update_interval, ts.use_graph, ts.graphs = True, world, 2, False, None
+        ts.schedule, ts.lr, ts.betas, ts.eps, ts.wd = None, 1e-3, (0.9, 0.999), 1e-8, 0.0
+        ts.iter_count = ts.epoch_iter = ts.sched_steps = ts.step_count = 0
+        ts._window_open, ts._window_pos, ts._zero, ts._opt = False, 0, True, True
+        ts.hp, ts.hp_ring, ts.acc = torch.zeros(8), [torch.zeros(8) for _ in range(4)], torch.zeros(16)
+        seen, accs = [], []
+
+        def fwd():
+            if ts._zero:
+                m.flat_grad.zero_()
+            ts.acc.zero_()
+            ts.acc[0] += rank + 1.0
+            ts.acc[1] += 1.0
+
+        def bwd(key):
+            lo, hi = ts.sync.ranges[key]
+            m.flat_grad[lo:hi] += (rank + 1.0) * (ts.iter_count + 1)
+
+        def optim():
+            seen.append(m.flat_grad.clone())
+
+        def segments():
+            segs = [(fwd, "loss")] + [((lambda k=k: bwd(k)), k if ts._opt else None) for k in GradSync.ORDER]
+            return segs + ([(optim, None)] if ts._opt else [])
+        ts._segments = segments
+        ran = []
+        for it in range(5):
+            ran.append(ts.step(last_of_epoch=(it == 4)))
+            accs.append(float(ts.acc[0] / ts.acc[1]))
+        ok = ran == [False, True, False, True, True] and ts.step_count == 3
+        ok = ok and accs == [sum(r + 1.0 for r in range(world)) / world] * 5            # global mean on every iteration
+        ranks = sum(r + 1.0 for r in range(world))
+        for got, its in zip(seen, ((1, 2), (3, 4), (5,))):                               # SUM over ranks of the window's iterations
+            ok = ok and torch.allclose(got, torch.full_like(got, ranks * sum(its)))
+        ok = ok and not ts.sync.pending
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_train_step_control_flow_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_step, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_one_cycle_schedule_matches_torch():
     from camradepth_amd.trainer import one_cycle
     p = torch.nn.Parameter(torch.zeros(1))

@@ -73,14 +73,28 @@ def per_kernel_timing(ts, reps=3):
     return {k: (v[0] / reps, v[1] / reps, v[2] / reps) for k, v in agg.items()}
 
 
+def csrc_sha():
+    """sha256 over the HIP sources: the PMC traffic file is only valid for the kernels it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "camradepth_amd", "csrc", "*.hip")) + glob.glob(os.path.join(REPO, "camradepth_amd", "csrc", "*.h"))):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json, made by
-    tools/pmc_traffic.py: FETCH_SIZE doubled per the gfx950 correction, + WRITE_SIZE).  The passes profile this same
-    workload (B = 8, 256x416); returns None for other shapes or when the file is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, made by
+    tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes of this same command: FETCH_SIZE doubled per the gfx950
+    correction, + WRITE_SIZE).  Counters cannot be read from inside the timed process, so the file carries the sha of the
+    kernel sources it was measured on; a stale file (different sha), another workload or a missing file gives None."""
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
-    ks = json.load(open(path))["kernels"]
+    data = json.load(open(path))
+    if data.get("csrc_sha") != csrc_sha():
+        return None
+    ks = data["kernels"]
     stem = kernel.replace("<*>", "<").rstrip(">").replace(" ", "")
     n = tot = 0.0
     for name, v in ks.items():
@@ -93,26 +107,18 @@ def pmc_traffic(kernel):
 
 def forward_only(model, batch, B, H, W, variant, reps=20):
     """Eval-mode forward (forward-only roofline fraction), replayed from one HIP graph."""
-    model.eval()
-    x = batch["image"].cuda()
-    plan = model._plan_for(x)
-    plan.x_in.copy_(x)
-    s = torch.cuda.Stream()
-    s.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(s):
-        plan.forward()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
-            plan.forward()
+    from camradepth_amd.inference import InferenceGraph
+    ig = InferenceGraph(model, B, H, W)
+    ig.run(batch["image"].cuda())
+    with torch.cuda.stream(ig.stream):
         for _ in range(3):
-            g.replay()
+            ig.replay()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(reps):
-            g.replay()
+            ig.replay()
         e1.record()
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     model.train()
     ms = e0.elapsed_time(e1) / reps
     ips = B / (ms * 1e-3)
@@ -121,9 +127,11 @@ def forward_only(model, batch, B, H, W, variant, reps=20):
             "mfma_frac": round(ips * FWD_GFLOP[variant] * scale / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
 
-def cpu_baseline(variant, seconds_budget=25.0):
-    """The CPU oracle (oracle/, a port of the reference verified against it) timed on this box's host cores."""
-    import numpy as np  # noqa: F401
+def cpu_baseline(variant, B_gpu=8, H=256, W=416):
+    """The CPU oracle (oracle/, a port of the reference verified against it) timed on this box's host cores on a
+    bounded sample of the same workload: one warm-up + timed fp32 train steps (forward, losses, backward, diffGradNorm)
+    at batch 2 and at the GPU's batch, and forward-only passes.  `value` is the train-step rate at the
+    GPU's batch; the other legs are listed beside it."""
     from camradepth_amd import synth
     from camradepth_amd.config import ModelConfig
     from camradepth_amd.params import param_specs
@@ -136,11 +144,8 @@ def cpu_baseline(variant, seconds_budget=25.0):
     cfg = ModelConfig.variant(variant)
     sd = {k: v.clone().requires_grad_(True) for k, v in synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0).items()}
     states = {k: oo.new_state(v.detach()) for k, v in sd.items()}
-    B = 2
-    batch = synth.make_batch(B, 256, 416, seed=1234)
-    masks = synth.make_masks(cfg, B, seed=4321)
 
-    def step():
+    def train(batch, masks):
         for v in sd.values():
             v.grad = None
         out = om.forward(sd, batch["image"], cfg, masks=masks)
@@ -150,15 +155,31 @@ def cpu_baseline(variant, seconds_budget=25.0):
             for k, v in sd.items():
                 if v.grad is not None:
                     oo.step_tensor(v, v.grad, states[k], 6e-5, 0.9, 0.999)
-    step()
-    t0, n = time.time(), 0
-    while n < 1 or (time.time() - t0 < seconds_budget and n < 8):
-        step()
-        n += 1
-    dt = (time.time() - t0) / n
-    return {"value": round(B / dt, 3), "unit": "images/s", "cores": threads, "kind": "port",
-            "sample": f"{n} fp32 train steps (fwd+loss+bwd+diffGradNorm) of the CPU oracle, batch {B}, 7x256x416, "
-                      f"{threads} torch threads of {cores} host cores"}
+
+    def fwd(batch):
+        with torch.no_grad():
+            om.forward(sd, batch["image"], cfg)
+
+    def timed(fn, n):
+        t0 = time.time()
+        for _ in range(n):
+            fn()
+        return (time.time() - t0) / n
+    legs = {}
+    b2 = synth.make_batch(2, H, W, seed=1234)
+    m2 = synth.make_masks(cfg, 2, seed=4321)
+    train(b2, m2)                                    # warm-up (thread pool, oneDNN primitive cache)
+    legs["train_b2"] = round(2 / timed(lambda: train(b2, m2), 2), 3)
+    legs["forward_b2"] = round(2 / timed(lambda: fwd(b2), 2), 3)
+    bB = synth.make_batch(B_gpu, H, W, seed=1234)
+    mB = synth.make_masks(cfg, B_gpu, seed=4321)
+    dt = timed(lambda: train(bB, mB), 1)
+    legs[f"train_b{B_gpu}"] = round(B_gpu / dt, 3)
+    legs[f"forward_b{B_gpu}"] = round(B_gpu / timed(lambda: fwd(bB), 1), 3)
+    return {"value": legs[f"train_b{B_gpu}"], "unit": "images/s", "cores": threads, "kind": "port", "legs_images_per_s": legs,
+            "sample": f"fp32 CPU oracle, {variant}, 7x{H}x{W}: 1 train step (fwd+loss+bwd+diffGradNorm) at batch {B_gpu} [= value], "
+                      f"2 train steps at batch 2, forward-only 2x batch 2 and 1x batch {B_gpu}; {threads} torch threads of {cores} "
+                      f"host cores"}
 
 
 def main():
@@ -170,6 +191,9 @@ def main():
     ap.add_argument("--variant", default="base", choices=["base", "supervised_seg"])
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=416)
+    ap.add_argument("--freeze-seg", action="store_true",
+                    help="config C4: transfer learning with the segmentation branch frozen (seg_* parameters requires_grad=False)")
+    ap.add_argument("--update-interval", type=int, default=1, help="gradient accumulation (runner.py:218-222)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -207,9 +231,13 @@ def main():
                           "mfma_frac": r["mfma_frac"]}), flush=True)
         return
     model.train()
+    if a.freeze_seg:
+        for n, p in model.named_parameters():
+            if n.startswith("seg_"):
+                p.requires_grad_(False)
     total_sched = max(a.steps + a.warmup + 8, 64)
     ts = TrainStep(model, a.batch, a.height, a.width, lr=6e-5, schedule=one_cycle(total_sched, 6e-5),
-                   use_graph=not a.no_graph)
+                   use_graph=not a.no_graph, update_interval=a.update_interval)
     batch = synth.make_batch(a.batch, a.height, a.width, seed=1234 + rank)
     ts.set_batch({k: v.cuda() for k, v in batch.items()})
 
@@ -236,8 +264,10 @@ def main():
     out = {"metric": "training images/sec at 256x416 bf16", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": f"CamRaDepth {a.variant} (image+radar) train step, {a.batch}x7x{a.height}x{a.width} per GPU, "
-                                  f"bf16 MFMA / fp32 accumulate, diffGradNorm + OneCycleLR, Dropout2d/DropPath on",
+           "config": {"workload": f"CamRaDepth {a.variant}{' (seg branch frozen)' if a.freeze_seg else ''} (image+radar) train "
+                                  f"{'iteration' if a.update_interval > 1 else 'step'}, {a.batch}x7x{a.height}x{a.width} per GPU, "
+                                  f"bf16 MFMA / fp32 accumulate, diffGradNorm + OneCycleLR, Dropout2d/DropPath on"
+                                  + (f", gradients accumulated over {a.update_interval} iterations" if a.update_interval > 1 else ""),
                       "global_batch": a.batch * world, "parallelism": f"dp{world}", "hip_graph": not a.no_graph},
            "loss": round(losses["loss"], 6), "rmse_norm": round(losses["rmse"], 6)}
     scale = (a.height * a.width) / (256 * 416)
@@ -267,7 +297,8 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(a.variant)
+        small = a.height * a.width <= 256 * 416        # bounded: at larger frames only the batch-2-sized legs fit the time budget
+        out["cpu_baseline"] = cpu_baseline(a.variant, a.batch if small else 1, a.height, a.width)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1 or force_dist:

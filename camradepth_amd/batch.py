@@ -31,3 +31,31 @@ def assemble_batch(img_u8, radar, rad_vel, gt_depth, max_depth=100.0, levels=3):
     out = {"image": x}
     out.update(dict(zip(names, maps)))
     return out
+
+
+def resize_image_nearest(img_u8, size):
+    """cv2.resize(image, size[::-1], interpolation=cv2.INTER_NEAREST) of dataloader.py:227 for a uint8 cuda batch
+    [B,H,W,C]; size = (H_out, W_out) like args.image_dimension."""
+    if not img_u8.is_cuda or img_u8.dtype != torch.uint8:
+        raise L.CrdError("resize_image_nearest takes a uint8 cuda tensor [B,H,W,C] (no CPU fallback)")
+    B, H, W, Cc = img_u8.shape
+    out = torch.empty(B, size[0], size[1], Cc, dtype=torch.uint8, device=img_u8.device)
+    L.check(L.load().crd_resize_nearest_u8(img_u8.contiguous().data_ptr(), B, H, W, Cc, out.data_ptr(), size[0], size[1], L.stream()),
+            "crd_resize_nearest_u8")
+    return out
+
+
+def seg_targets(mseg_u8, rows=416, sizes=((416, 800), (208, 400))):
+    """The two segmentation targets of dataloader.py:262-267 from uint8 cuda label maps [B,H,W]: the first `rows` rows,
+    nearest-resized to each size (skimage order 0), as int64 -- {'final_seg', 'intermediate_seg'} of the batch dict."""
+    if not mseg_u8.is_cuda or mseg_u8.dtype != torch.uint8:
+        raise L.CrdError("seg_targets takes a uint8 cuda tensor [B,H,W] (no CPU fallback)")
+    B, H, W = mseg_u8.shape
+    src = mseg_u8.contiguous()
+    outs = []
+    for (h, w) in sizes:
+        o = torch.empty(B, h, w, dtype=torch.int64, device=src.device)
+        L.check(L.load().crd_resize_labels_nearest(src.data_ptr(), B, H, W, rows, o.data_ptr(), h, w, L.stream()),
+                "crd_resize_labels_nearest")
+        outs.append(o)
+    return dict(zip(("final_seg", "intermediate_seg"), outs))

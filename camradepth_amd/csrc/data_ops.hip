@@ -62,6 +62,41 @@ __global__ __launch_bounds__(TPB) void k_gt_minpool(const float* src, int H, int
   }
 }
 
+// cv2.resize(img, (DW, DH), interpolation=cv2.INTER_NEAREST) on interleaved uint8 pixels (dataloader.py:227): source
+// column = min(floor(dx * ifx), SW - 1) with ifx = 1 / (DW / SW) in double, rows alike (OpenCV resizeNN).
+__global__ __launch_bounds__(TPB) void k_resize_nearest_u8(const unsigned char* src, int SH, int SW, int C, unsigned char* dst,
+                                                           int DH, int DW) {
+  const int b = blockIdx.y;
+  const double ifx = 1.0 / ((double)DW / (double)SW), ify = 1.0 / ((double)DH / (double)SH);
+  const long long total = (long long)DH * DW;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int dy = (int)(i / DW), dx = (int)(i - (long long)dy * DW);
+    int sy = (int)floor(dy * ify), sx = (int)floor(dx * ifx);
+    sy = sy < SH - 1 ? sy : SH - 1;
+    sx = sx < SW - 1 ? sx : SW - 1;
+    const unsigned char* s = src + (((long long)b * SH + sy) * SW + sx) * C;
+    unsigned char* d = dst + ((long long)b * total + i) * C;
+    for (int c = 0; c < C; ++c) d[c] = s[c];
+  }
+}
+
+// skimage.transform.resize(mseg[:rows], (DH, DW), order=0, preserve_range=True, anti_aliasing=False) (dataloader.py:262-267;
+// scikit-image 0.19.3 = scipy.ndimage.zoom(order=0, grid_mode=True)): source index = floor(((o + 0.5) * (S / D) - 0.5) + 0.5)
+// in double.  uint8 label maps in, int64 labels out (what the loss consumes, runner.py:189-190).
+__global__ __launch_bounds__(TPB) void k_resize_labels(const unsigned char* src, int SH_full, int SH, int SW, long long* dst,
+                                                       int DH, int DW) {
+  const int b = blockIdx.y;
+  const double zy = (double)SH / (double)DH, zx = (double)SW / (double)DW;
+  const long long total = (long long)DH * DW;
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < total; i += (long long)gridDim.x * TPB) {
+    const int dy = (int)(i / DW), dx = (int)(i - (long long)dy * DW);
+    int sy = (int)floor(((dy + 0.5) * zy - 0.5) + 0.5), sx = (int)floor(((dx + 0.5) * zx - 0.5) + 0.5);
+    sy = sy < 0 ? 0 : (sy < SH ? sy : SH - 1);
+    sx = sx < 0 ? 0 : (sx < SW ? sx : SW - 1);
+    dst[(long long)b * total + i] = src[((long long)b * SH_full + sy) * SW + sx];
+  }
+}
+
 inline int blocks_for(long long total, int cap = 1024) {
   long long n = (total + TPB - 1) / TPB;
   if (n > cap) n = cap;
@@ -96,5 +131,23 @@ extern "C" int crd_gt_pyramid(const float* depth, int32_t B, int32_t H, int32_t 
     src = lv[i]; h = oh; w = ow;
   }
   CRD_LAUNCH_CHECK("crd_gt_pyramid");
+  return CRD_OK;
+}
+
+extern "C" int crd_resize_nearest_u8(const void* src, int32_t B, int32_t SH, int32_t SW, int32_t C, void* dst, int32_t DH, int32_t DW,
+                                     crd_stream_t stream) {
+  CRD_CHECK_ARG(src && dst && B > 0 && SH > 0 && SW > 0 && C > 0 && DH > 0 && DW > 0, "crd_resize_nearest_u8: bad argument");
+  hipLaunchKernelGGL(k_resize_nearest_u8, dim3(blocks_for((long long)DH * DW), B), dim3(TPB), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned char*>(src), SH, SW, C, reinterpret_cast<unsigned char*>(dst), DH, DW);
+  CRD_LAUNCH_CHECK("crd_resize_nearest_u8");
+  return CRD_OK;
+}
+
+extern "C" int crd_resize_labels_nearest(const void* src_u8, int32_t B, int32_t SH, int32_t SW, int32_t rows, int64_t* dst, int32_t DH,
+                                         int32_t DW, crd_stream_t stream) {
+  CRD_CHECK_ARG(src_u8 && dst && B > 0 && SH > 0 && SW > 0 && rows > 0 && DH > 0 && DW > 0, "crd_resize_labels_nearest: bad argument");
+  hipLaunchKernelGGL(k_resize_labels, dim3(blocks_for((long long)DH * DW), B), dim3(TPB), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned char*>(src_u8), SH, rows < SH ? rows : SH, SW, reinterpret_cast<long long*>(dst), DH, DW);
+  CRD_LAUNCH_CHECK("crd_resize_labels_nearest");
   return CRD_OK;
 }

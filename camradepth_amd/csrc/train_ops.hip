@@ -64,6 +64,34 @@ __global__ __launch_bounds__(TPB) void k_test_metrics(const float* pred, const f
   }
 }
 
+// Confusion matrix of one frame for the Jaccard index of Trainer.test (runner.py:432-436): prediction = arg-max over the C
+// logits of a pixel (NCHW fp32, first maximal class), confmat[f][target][pred] += 1; labels outside [0, C) are counted in
+// oor[f] and skipped (torchmetrics 0.10.2 raises on them, which the reference catches: that frame's IoU stays NaN).
+__global__ __launch_bounds__(TPB) void k_seg_confusion(const float* logits, const long long* labels, int C, long long HW,
+                                                       unsigned long long* confmat, unsigned long long* oor) {
+  extern __shared__ unsigned int hist[];      // C * C + 1
+  const int f = blockIdx.y;
+  for (int i = threadIdx.x; i <= C * C; i += TPB) hist[i] = 0;
+  __syncthreads();
+  const float* lg = logits + (long long)f * C * HW;
+  const long long* lb = labels + (long long)f * HW;
+  for (long long p = (long long)blockIdx.x * TPB + threadIdx.x; p < HW; p += (long long)gridDim.x * TPB) {
+    const long long t = lb[p];
+    if (t < 0 || t >= C) { atomicAdd(&hist[C * C], 1u); continue; }
+    float best = lg[p];
+    int arg = 0;
+    for (int c = 1; c < C; ++c) {
+      const float v = lg[(long long)c * HW + p];
+      if (v > best) { best = v; arg = c; }
+    }
+    atomicAdd(&hist[(int)t * C + arg], 1u);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < C * C; i += TPB)
+    if (hist[i]) atomicAdd(&confmat[(long long)f * C * C + i], (unsigned long long)hist[i]);
+  if (threadIdx.x == 0 && hist[C * C]) atomicAdd(&oor[f], (unsigned long long)hist[C * C]);
+}
+
 __global__ __launch_bounds__(TPB) void k_masked_l1_bwd(const float* pred, const float* target, long long n, const float* acc,
                                                        const float* gout, float gmul, float* dpred) {
   const float g = gmul * (gout ? gout[0] : 1.f) / acc[1];
@@ -285,6 +313,16 @@ extern "C" int crd_test_metrics(const float* pred, const float* gt, int32_t fram
   hipLaunchKernelGGL(k_test_metrics, dim3(blocks_for(n, 64), frames), dim3(TPB), 0, as_stream(stream), pred, gt, (long long)n,
                      max_depth, max_distance, acc);
   CRD_LAUNCH_CHECK("crd_test_metrics");
+  return CRD_OK;
+}
+
+extern "C" int crd_seg_confusion(const float* logits, const int64_t* labels, int32_t frames, int32_t C, int64_t HW, int64_t* confmat,
+                                 int64_t* out_of_range, crd_stream_t stream) {
+  CRD_CHECK_ARG(logits && labels && confmat && out_of_range && frames > 0 && C > 0 && C <= 64 && HW > 0, "crd_seg_confusion: bad argument");
+  hipLaunchKernelGGL(k_seg_confusion, dim3(blocks_for(HW, 128), frames), dim3(TPB), (C * C + 1) * sizeof(unsigned int), as_stream(stream),
+                     logits, reinterpret_cast<const long long*>(labels), C, (long long)HW,
+                     reinterpret_cast<unsigned long long*>(confmat), reinterpret_cast<unsigned long long*>(out_of_range));
+  CRD_LAUNCH_CHECK("crd_seg_confusion");
   return CRD_OK;
 }
 

@@ -1,0 +1,45 @@
+"""Eval-mode forward replayed from one HIP graph: the reference's own "runtime" metric (the timed forward of
+Trainer.test, src/main/runner.py:417-420) without per-kernel launch cost.  SURVEY 8f N4."""
+import torch
+
+from . import lib as L
+
+
+class InferenceGraph:
+    """model.eval() forward on static buffers for a fixed (B, H, W), captured once.  run(x) copies x into the plan's input
+    buffer, replays the graph and returns the reference's nested output dict (CamRaDepth.py:169-170); the returned tensors
+    are views of static output buffers, valid until the next run()."""
+
+    def __init__(self, model, B, H, W):
+        if model.flat is None or not model.flat.is_cuda:
+            raise L.CrdError("InferenceGraph needs the model on an MI355X (no CPU fallback)")
+        was_training = model.training
+        model.eval()
+        self.model, self.B, self.H, self.W = model, B, H, W
+        x = torch.zeros((B, model.cfg.input_channels, H, W), device=model.flat.device)
+        self.plan = model._plan_for(x)
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.plan.forward()                     # warm-up outside the capture (lazy module loading)
+            torch.cuda.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.plan.forward()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        model.train(was_training)
+
+    def replay(self):
+        self.graph.replay()
+
+    def run(self, x):
+        p = self.plan
+        p.x_in.copy_(x.to(torch.float32))
+        self.graph.replay()
+        B, H, W = self.B, self.H, self.W
+        final = p.out_depth[5].t.view(B, 1, H, W)
+        half = p.out_depth[4].t.view(B, 1, H // 2, W // 2)
+        quarter = p.out_depth[3].t.view(B, 1, H // 4, W // 4)
+        seg = p.seg_out if p.seg_logits is not None else None
+        return {"depth": {"intermediate_depths": (None, None, quarter, half), "final_depth": final},
+                "seg": {"final_seg": seg, "intermediate_seg": None, "unsup_map": p.unsup_map}}

@@ -106,6 +106,7 @@ _SIGS = {
     "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp", "crd_head_conv2_fwd": "pppiiippiip", "crd_head_conv2_bwd": "ppiippiiippip", "crd_head_conv2_bwd_data": "ppiippiiipp", "crd_head_conv2_wgrad": "ppiipiiipip",
     "crd_weight_pack": "pilp", "crd_wgrad_unpack": "pilip",
     "crd_assemble_input": "pppiiifpp", "crd_gt_pyramid": "piiifppppp",
+    "crd_resize_nearest_u8": "piiiipiip", "crd_resize_labels_nearest": "piiiipiip", "crd_seg_confusion": "ppiilppp",
     "crd_masked_l1_fwd": "pplpp", "crd_test_metrics": "ppilffpp", "crd_masked_l1_bwd": "pplppfpp", "crd_ce_fwd": "ppiilpp",
     "crd_ce_focal_bwd": "ppiilppfpp",
     "crd_diffgradnorm_step": "pppppppppppiipfffffipp",

@@ -41,3 +41,50 @@ class DepthMetrics:
         if not ms:
             return None
         return {k: sum(m[k] for m in ms) / len(ms) for k in ("MAE", "RMSE", "REL")}
+
+
+class SegIoU:
+    """The segmentation metric of Trainer.test (runner.py:432-436,508): per frame
+    `JaccardIndex(num_classes, ignore_index=255)(pred_seg, gt_seg)` of torchmetrics 0.10.2 -- macro average over all
+    num_classes classes of intersection / union from the confusion matrix of arg-max predictions, a class absent from both
+    scoring 0 -- averaged over frames with np.nanmean.  Label 255 is NOT ignored by that call: ignore_index >= num_classes
+    removes no class and torchmetrics raises ValueError on a target label >= num_classes, which the reference catches
+    (runner.py:437-438), leaving that frame's IoU NaN.  One kernel builds the per-frame confusion matrices."""
+
+    def __init__(self, num_classes=21):
+        self.C = int(num_classes)
+        self.mats, self.oor = [], []
+
+    def update(self, logits, labels):
+        """logits fp32 cuda [B,C,H,W], labels int64 cuda [B,H,W]."""
+        if not logits.is_cuda:
+            raise L.CrdError("SegIoU runs on the GPU (no CPU fallback; see oracle.losses.seg_iou for the CPU check)")
+        logits = logits.detach().contiguous().float()
+        labels = labels.detach().contiguous().to(torch.int64)
+        B, C = logits.shape[0], logits.shape[1]
+        assert C == self.C
+        hw = logits.numel() // (B * C)
+        mat = torch.zeros(B, C, C, dtype=torch.int64, device=logits.device)
+        oor = torch.zeros(B, dtype=torch.int64, device=logits.device)
+        L.check(L.load().crd_seg_confusion(logits.data_ptr(), labels.data_ptr(), B, C, hw, mat.data_ptr(), oor.data_ptr(), L.stream()),
+                "crd_seg_confusion")
+        self.mats.append(mat)
+        self.oor.append(oor)
+
+    def per_frame(self):
+        mats, oor = torch.cat(self.mats).cpu().double(), torch.cat(self.oor).cpu()
+        out = []
+        for m, bad in zip(mats, oor.tolist()):
+            if bad:
+                out.append(float("nan"))
+                continue
+            inter = torch.diag(m)
+            union = m.sum(0) + m.sum(1) - inter
+            scores = torch.where(union > 0, inter / union.clamp(min=1), torch.zeros_like(inter))
+            out.append(float(scores.mean()))
+        return out
+
+    def result(self):
+        """np.nanmean over the frames (NaN when every frame is NaN)."""
+        vals = [v for v in self.per_frame() if not math.isnan(v)]
+        return sum(vals) / len(vals) if vals else float("nan")

@@ -351,6 +351,16 @@ int crd_assemble_input(const void* img_u8, const float* radar, const float* rad_
  * quarter, eighth = successive zero-ignoring 3x3 / stride 2 / pad 1 min-pools (:213-222); lower levels may be NULL. */
 int crd_gt_pyramid(const float* depth, int32_t B, int32_t H, int32_t W, float max_depth, float* full, float* half,
                    float* quarter, float* eighth, crd_stream_t stream);
+/* cv2.resize(image, (DW, DH), interpolation=cv2.INTER_NEAREST) of dataloader.py:227 on interleaved uint8 pixels
+ * [B][SH][SW][C] -> [B][DH][DW][C]: source column = min(floor(dx * (1 / (DW / SW))), SW - 1) in double, rows alike. */
+int crd_resize_nearest_u8(const void* src, int32_t B, int32_t SH, int32_t SW, int32_t C, void* dst, int32_t DH, int32_t DW,
+                          crd_stream_t stream);
+/* The segmentation targets of dataloader.py:262-267: skimage.transform.resize(mseg[:rows], (DH, DW), order=0,
+ * preserve_range=True, anti_aliasing=False) (scikit-image 0.19.3 -> scipy.ndimage.zoom(order=0, grid_mode=True)): source
+ * index = floor(((o + 0.5) * (S / D) - 0.5) + 0.5) in double.  uint8 [B][SH][SW] label maps in, of which the first
+ * `rows` rows are used; int64 [B][DH][DW] labels out (the dtype runner.py:189-190 casts to). */
+int crd_resize_labels_nearest(const void* src_u8, int32_t B, int32_t SH, int32_t SW, int32_t rows, int64_t* dst, int32_t DH,
+                              int32_t DW, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Losses (src/utils/loss_funcs.py:14-46,77-91; combination src/main/runner.py:197-218).
@@ -363,6 +373,12 @@ int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, float* 
  * MAE = acc0/acc3, RMSE = sqrt(acc1/acc3), REL = acc2/acc3; frames with acc3 == 0 are skipped by the reference) */
 int crd_test_metrics(const float* pred, const float* gt, int32_t frames, int64_t n, float max_depth, float max_distance,
                      float* acc, crd_stream_t stream);
+/* Per-frame confusion matrices for the Jaccard index of Trainer.test (runner.py:432-436, torchmetrics 0.10.2
+ * JaccardIndex(num_classes=C, ignore_index=255)): prediction = arg-max over the C fp32 logits [frames][C][HW],
+ * confmat[f][target][pred] += 1 (int64 [frames][C][C], caller zeroes); labels outside [0, C) are skipped and counted
+ * in out_of_range[f] (torchmetrics raises ValueError on them, which the reference catches: that frame's IoU is NaN). */
+int crd_seg_confusion(const float* logits, const int64_t* labels, int32_t frames, int32_t C, int64_t HW, int64_t* confmat,
+                      int64_t* out_of_range, crd_stream_t stream);
 /* dpred = gmul * gout[0] * clamp(pred-target,-1,1) / acc[1] on target>0, else 0   (gout may be NULL = 1) */
 int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const float* acc, const float* gout,
                       float gmul, float* dpred, crd_stream_t stream);

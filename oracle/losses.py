@@ -59,3 +59,22 @@ def test_metrics(pred_full, gt_full, max_depth=100.0, max_distance=100.0):
     rel = torch.abs(err) / gt[idx]
     return {"MAE": err.abs().mean().item(), "RMSE": torch.sqrt((err ** 2).mean()).item(),
             "REL": (rel.sum() / len(rel)).item()}
+
+
+def seg_iou(logits, target, num_classes=21):
+    """The per-frame IoU of Trainer.test (reference: src/main/runner.py:432-438): torchmetrics 0.10.2
+    `JaccardIndex(num_classes, ignore_index=255)(pred_seg, gt_seg)`.  PARITY UNPINNED: torchmetrics is not installed in
+    the build container; this restates its published algorithm (functional/classification/jaccard.py,
+    `_jaccard_from_confmat`): confusion matrix of arg-max predictions, per-class intersection / union with a class absent
+    from both scoring absent_score = 0, macro mean over all classes; ignore_index = 255 >= num_classes removes no class,
+    and a target label >= num_classes raises ValueError in the input checks, which the reference catches -> NaN."""
+    t = target.reshape(-1)
+    if int(t.max()) >= num_classes or int(t.min()) < 0:
+        return float("nan")
+    pred = logits.argmax(1).reshape(-1)
+    conf = torch.bincount(t * num_classes + pred, minlength=num_classes * num_classes).reshape(num_classes, num_classes).double()
+    inter = torch.diag(conf)
+    union = conf.sum(0) + conf.sum(1) - inter
+    scores = inter / union
+    scores[union == 0] = 0.0
+    return float(scores.mean())

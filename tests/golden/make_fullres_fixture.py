@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Golden output of the REAL reference at config C4's resolution (SURVEY 8 note: 900x1600 must be padded to 928x1600 --
+the reference itself fails at 900 rows in torch.cat, src/utils/utils.py:254).  Build container only (needs
+/root/reference).  supervised_seg model, eval forward of one 7x928x1600 frame; the fixture holds strided samples of the
+outputs and whole-tensor checksums:
+
+    python tests/golden/make_fullres_fixture.py      ->  tests/golden/forward928x1600_supervised_seg.npz
+"""
+import importlib.util
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+
+
+def main():
+    import numpy as np
+    import torch
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(HERE, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    mg.install_shims()
+    torch.set_num_threads(8)
+    tmp = tempfile.mkdtemp()
+    sys.argv = ["x", "--split", f"{REF}/src/data/new_split.npy", "--model", "supervised_seg", "--output_dir", tmp]
+    sys.path.insert(0, f"{REF}/src")
+    sys.path.insert(0, REPO)
+    from models.CamRaDepth import CamRaDepth            # reference
+    from utils.loss_funcs import MaskedMSELoss          # reference
+    from camradepth_amd import synth
+    model = CamRaDepth(input_channels=7)
+    model.load_state_dict(synth.fill_state_dict({k: tuple(v.shape) for k, v in model.state_dict().items()}, seed=0), strict=True)
+    model.eval()
+    b = synth.make_batch(1, 928, 1600, seed=1234)
+    with torch.no_grad():
+        enc, _ = model.dest_encoder(b["image"])
+        out = model(b["image"])
+    fd, inter = out["depth"]["final_depth"], out["depth"]["intermediate_depths"]
+    st = {"final_depth_s4": fd[0, 0, ::4, ::4].numpy().copy(), "depth_half_s4": inter[3][0, 0, ::4, ::4].numpy().copy(),
+          "depth_quarter_s2": inter[2][0, 0, ::2, ::2].numpy().copy(),
+          "final_stats": np.array([float(fd.mean()), float(fd.norm())]),
+          "seg_argmax_s4": out["seg"]["final_seg"][0].argmax(0)[::4, ::4].numpy().astype(np.uint8),
+          "seg_stats": np.array([float(out["seg"]["final_seg"].mean()), float(out["seg"]["final_seg"].norm())]),
+          "rmse": np.array([float(torch.sqrt(MaskedMSELoss()(fd, b["gt_full"])))])}
+    for i, e in enumerate(enc):
+        st[f"enc{i + 1}_stats"] = np.array([float(e.mean()), float(e.norm())])
+    np.savez_compressed(os.path.join(HERE, "forward928x1600_supervised_seg.npz"), **st)
+    print({k: (v.shape if v.ndim else float(v)) for k, v in st.items()})
+
+
+if __name__ == "__main__":
+    main()

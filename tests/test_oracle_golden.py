@@ -187,3 +187,33 @@ def test_losses_and_metrics():
     np.testing.assert_allclose(float(olosses.masked_focal(logits, b["seg"])), g["focal"], rtol=1e-6)
     m = olosses.test_metrics(pred[0], b["gt_full"][0])
     np.testing.assert_allclose([m["MAE"], m["RMSE"], m["REL"]], g["metrics"], rtol=1e-5)
+
+
+def test_label_resize_oracle_matches_scipy_zoom():
+    """oracle.data.resize_labels against scipy.ndimage.zoom(order=0, grid_mode=True), the routine scikit-image 0.19.3's
+    resize(order=0, anti_aliasing=False) calls (dataloader.py:262-267)."""
+    import scipy.ndimage as ndi
+    from oracle import data as od
+    rs = np.random.RandomState(0)
+    for (SH, SW), (DH, DW) in [((450, 800), (416, 800)), ((450, 800), (208, 400)), ((37, 53), (16, 20)), ((20, 31), (33, 50)),
+                              ((416, 800), (256, 416))]:
+        m = rs.randint(0, 22, size=(SH, SW)).astype(np.uint8)
+        rows = min(416, SH)
+        src = m[:rows].astype(np.float64)
+        ref = ndi.zoom(src, [DH / src.shape[0], DW / src.shape[1]], order=0, mode="reflect", grid_mode=True)
+        assert ref.shape == (DH, DW)
+        assert np.array_equal(od.resize_labels(m, (DH, DW), rows=416), ref.astype(np.int64))
+
+
+def test_seg_iou_oracle_properties():
+    from oracle import losses as ol
+    rs = np.random.RandomState(1)
+    t = torch.from_numpy(rs.randint(0, 21, size=(1, 12, 20)).astype(np.int64))
+    perfect = torch.nn.functional.one_hot(t, 21).permute(0, 3, 1, 2).float()
+    assert ol.seg_iou(perfect, t) == pytest.approx(len(torch.unique(t)) / 21.0)      # absent classes score 0
+    t2 = t.clone()
+    t2[0, 0, 0] = 255
+    assert np.isnan(ol.seg_iou(perfect, t2))                                         # the reference's caught ValueError
+    # two classes, hand-computed: target [0,0,1,1], pred [0,1,1,1] -> IoU0 = 1/2, IoU1 = 2/3
+    lg = torch.tensor([[[[1.0, 0.0, 0.0, 0.0]], [[0.0, 1.0, 1.0, 1.0]]]])
+    assert ol.seg_iou(lg, torch.tensor([[[0, 0, 1, 1]]]), num_classes=2) == pytest.approx((0.5 + 2 / 3) / 2)

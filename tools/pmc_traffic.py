@@ -28,5 +28,8 @@ for k in sorted(set(f) | set(w), key=lambda k: -(2 * f.get(k, [0, 0])[1] + w.get
 for k, v in list(out.items())[:25]:
     print(f"{v['hbm_bytes_per_launch'] / 1e6:10.2f} MB/launch  fetch {v['fetch_bytes_per_launch'] / 1e6:9.2f}  write {v['write_bytes_per_launch'] / 1e6:9.2f}  x{v['launches']:5d}  {k}")
 if len(sys.argv) > 3:
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), eager bench.py --steps 2 --warmup 1; FETCH_SIZE doubled per the gfx950 correction",
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    from bench import csrc_sha
+    json.dump({"csrc_sha": csrc_sha(), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), eager bench.py --steps 2 --warmup 1; FETCH_SIZE doubled per the gfx950 correction",
                "kernels": out}, open(sys.argv[3], "w"), indent=1)

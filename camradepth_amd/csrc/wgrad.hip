@@ -261,6 +261,9 @@ int fill(const crd_wgrad_desc* d, WgK& k) {
   k.x_bytes = (long long)d->B * d->IH * d->IW * d->x_ld * 2;
   k.dy_bytes = k.P * d->dy_ld * 2;
   k.dbias = d->dbias; k.dbg = 0;
+  return CRD_OK;
+}
+int check_generic(const WgK& k) {   // the generic split-K kernel addresses the whole batch with 32-bit byte offsets
   CRD_UNSUPPORTED(k.x_bytes < (1ll << 31) && k.dy_bytes < (1ll << 31), "crd_conv_wgrad: tensor too large for 32-bit byte offsets");
   return CRD_OK;
 }
@@ -290,6 +293,7 @@ extern "C" int crd_wgrad_group_build(const crd_wgrad_desc* descs, int32_t n, voi
     for (int i = 0; i < n; ++i) {
       WgK k;
       int rc = fill(&descs[i], k);
+      if (rc == CRD_OK) rc = check_generic(k);
       if (rc != CRD_OK) return rc;
       const int c = cfg_of(k.Cout);
       const int tn = cdiv(k.Ktot, 128), tm = cdiv(k.Cout, CFG_BM[c]);
@@ -337,6 +341,7 @@ extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
   // 3x3 / stride 1 / pad 1 on grids at least one 32-pixel strip wide: streaming halo-row kernel (wgrad3x3.hip)
   if (uses_stream3(d)) return crd_wgrad3x3_stream(d, st);
   CRD_CHECK_ARG(d->dw_partials == nullptr, "crd_conv_wgrad: dw_partials is only supported where crd_conv_wgrad_splits() > 0");
+  { int rc = check_generic(k); if (rc != CRD_OK) return rc; }
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
   if (d->Cout <= 32) return launch<1, 4, 2, 2>(k, st);
   if (d->Cout <= 64) return launch<1, 4, 4, 2>(k, st);

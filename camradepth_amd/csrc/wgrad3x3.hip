@@ -66,8 +66,6 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
   const int chunk = blockIdx.y;
   const int c0 = chunk * XLD;
   const unsigned OOB = 0x80000000u;
-  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)a.dy, 0, (int)a.dy_bytes, 0x00020000);
 
   f32x4 acc[9][TCO][NT];
 #pragma unroll
@@ -119,15 +117,21 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
     long long seg_end = (strip + 1) * a.H;
     if (seg_end > sr_end) seg_end = sr_end;
     const int y1 = y0 + (int)(seg_end - sr);
-    const int b = (int)(strip / a.strips_x), sx = (int)(strip - (long long)b * a.strips_x);
+    const int b = __builtin_amdgcn_readfirstlane((int)(strip / a.strips_x));
+    const int sx = (int)(strip - (long long)b * a.strips_x);
     const int x0 = sx * 32;
+    // one buffer descriptor per image: byte offsets stay below 2^31 whatever the batch (4 x 928 x 1600 x 304 channels is 3.6 GB)
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.H * a.W * a.x_ld), 0,
+                                                                        (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (long long)b * a.H * a.W * a.dy_ld), 0,
+                                                                        (int)a.dy_bytes, 0x00020000);
 
     auto issue_x = [&](int h) {                  // input row h (image coords) -> ring slot (h + 1) % XS
 #if defined(__HIP_DEVICE_COMPILE__)
       if (wv < 5) {
         const int ix = x0 - 1 + xpix, ch = c0 + ((((xgr >> 1) ^ swz128(xpix)) << 1) | (xgr & 1)) * 8;
         const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && xpix < 34 && ch < a.Cin;
-        const unsigned off = ok ? (unsigned)((((long long)(b * a.H + h) * a.W + ix) * a.x_ld + ch) * 2) : OOB;
+        const unsigned off = ok ? (unsigned)((((long long)h * a.W + ix) * a.x_ld + ch) * 2) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sX + (((h + 1) % XS) * XPX + 8 * wv) * XLD), 16, off, 0, 0, 0);
       }
 #else
@@ -139,7 +143,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
       if (wv < YGRP) {
         const int ix = x0 + ypix, co = ((((ygr >> 1) ^ swz_y<COT>(ypix)) << 1) | (ygr & 1)) * 8;
         const bool ok = r < y1 && ix < a.W && co < a.Cout;
-        const unsigned off = ok ? (unsigned)((((long long)(b * a.H + r) * a.W + ix) * a.dy_ld + co) * 2) : OOB;
+        const unsigned off = ok ? (unsigned)((((long long)r * a.W + ix) * a.dy_ld + co) * 2) : OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr)(sY + (r % YS) * 32 * COT + 512 * wv), 16, off, 0, 0, 0);
       }
 #else
@@ -262,8 +266,9 @@ int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st) {
   k.strips_x = cdiv(d->IW, 32);
   k.total_rows = (long long)d->B * k.strips_x * d->IH;
   k.rows_per_wg = 0;
-  k.x_bytes = (long long)d->B * d->IH * d->IW * d->x_ld * 2;
-  k.dy_bytes = (long long)d->B * d->IH * d->IW * d->dy_ld * 2;
+  k.x_bytes = (long long)d->IH * d->IW * d->x_ld * 2;          // per image (the kernel builds one descriptor per image)
+  k.dy_bytes = (long long)d->IH * d->IW * d->dy_ld * 2;
+  CRD_UNSUPPORTED(k.x_bytes < (1ll << 31) && k.dy_bytes < (1ll << 31), "crd_conv_wgrad: image too large for 32-bit byte offsets");
   k.dw = d->dw; k.dbias = d->dbias;
   k.dw_part = d->dw_partials;
   CRD_CHECK_ARG(d->dw_partials == nullptr || d->dw_partial_capacity >= 1, "crd_conv_wgrad: dw_partials needs a capacity >= 1");

@@ -35,6 +35,11 @@ class ConvDesc(C.Structure):
     ]
 
 
+class GnInput(C.Structure):
+    _fields_ = [("x_f32", C.c_int32), ("gmul", C.c_int32), ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("act", C.c_int32), ("xn_ld", C.c_int32), ("xn", C.c_void_p)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_ld", C.c_int32), ("x_coff", C.c_int32),
@@ -95,7 +100,7 @@ def load():
 
 # Signatures of include/camradepth_hip.h (all return int status). p = pointer, i = int32, l = int64, f = float
 _SIGS = {
-    "crd_conv_igemm": "pp", "crd_tune_conv3x3_small_grid": "i", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
+    "crd_conv_igemm": "pp", "crd_gn_conv": "ppp", "crd_tune_conv3x3_small_grid": "i", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiipipp",
     "crd_dwconv3x3": "piiiippipppippppppp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",

@@ -89,6 +89,28 @@ typedef struct {
 } crd_conv_desc;
 
 int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);
+
+/* The same convolution with a GroupNorm (+ exact GELU) applied to its INPUT while the A operand is loaded:
+ *   y = epilogue( W * act( GroupNorm(x) ) ),   GroupNorm(x)[b,p,c] = (x - mean[b,g]) * rstd[b,g] * gamma[c] + beta[c]
+ * -- nn.GroupNorm followed by Conv1d / Conv2d in Block / Attention_MaxPool / Mlp (simplified_attention.py:34-43 Mlp.norm2 +
+ * GELU + fc2, :96-100 attn.sr behind Block.norm1 and attn.k behind attn.norm, :142-145 fc1 behind Block.norm2) without
+ * the pass that would store the normalised tensor first.  d->x is the RAW tensor (fp32 when x_f32, else bf16); statistics
+ * as raw sums per 16-channel slab, float [B][Cin/16][2] (what crd_gn_stats / a producer's `stats` epilogue leave), a
+ * group being `gmul` consecutive slabs.  xn != NULL: act(GroupNorm(x)) is also stored as bf16 [B][IH*IW][xn_ld] (the
+ * operand a later weight-gradient call needs).  Pointwise (1x1) and non-overlapping patch convolutions only
+ * (KH == KW == stride, pad 0, gather_mode 0, out_mode 0); every epilogue option of crd_conv_desc except red_x and
+ * stats_partial. */
+typedef struct {
+  int32_t x_f32;            /* d->x holds fp32 (1) or bf16 (0) */
+  int32_t gmul;             /* 16-channel slabs per group */
+  const float* stats;       /* [B][Cin/16][2] */
+  const float* gamma;       /* [Cin] */
+  const float* beta;        /* [Cin] */
+  int32_t act;              /* 0 none, 1 exact GELU (after the affine) */
+  int32_t xn_ld;
+  void* xn;                 /* optional bf16 output */
+} crd_gn_input;
+int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stream);
 /* Tuning knob of the 3x3 halo kernel: launches whose 128-column tiling would give fewer than `workgroups` workgroups use
  * 64- or 32-column tiles instead (default 512; 0 disables; < 0 restores the default).  Returns the previous value.
  * Not needed for correctness -- the tests use it to reach every tile configuration with small inputs. */

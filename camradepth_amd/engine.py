@@ -42,6 +42,12 @@ FUSE_STATS = os.environ.get("CRD_NO_FUSE_STATS") is None
 # single-GPU graph step replays them as a graph of their own on a second stream while the encoder's latency-bound backward
 # runs (trainer.py; CRD_NO_LATE_WGRAD keeps program order).  W3_LATE_WGS: workgroups their streaming kernels may use in
 # that mode, so that the encoder's kernels still find free CUs (256: 22.1 ms, 160: 20.7, 128: 20.9, 64: 22.3).
+# GroupNorm(+GELU)-apply folded into the A-operand load of the consuming pointwise / patch GEMM (crd_gn_conv) instead of a
+# crd_gn_apply launch + pass per GroupNorm of an encoder block.  CRD_GN_CONV=1 turns it on (read when a plan is built)
+def gn_conv_default():
+    return os.environ.get("CRD_GN_CONV", "0") != "0"
+
+
 LATE_WGRAD = os.environ.get("CRD_NO_LATE_WGRAD") is None
 W3_LATE_WGS = int(os.environ.get("CRD_W3_LATE_WGS", "160"))
 LATE = 3            # Op.stream id of those ops
@@ -170,6 +176,9 @@ class Plan:
         # parameters with requires_grad=False (the reference's optimizer skips `grad is None`, diffGradNorm.py:54-55):
         # their weight-gradient launches are not recorded and whatever fused kernels still produce for them lands in a
         # scratch buffer instead of the flat gradient
+        self.gn_conv_on = gn_conv_default()
+        # need_grad False (plan built under torch.no_grad()): tensors only a backward pass reads are not written
+        self.need_grad = bool(getattr(model, "_need_grad", True))
         self.frozen = frozenset(n for n in model._names if not model._param(n).requires_grad)
         self._dump = {}
         self._build()
@@ -279,6 +288,21 @@ class Plan:
         lst.append(op)
         return op
 
+    def gn_conv(self, lst, spec, stats, gmul, gname, act, xn):
+        """spec as for conv() with x the RAW (un-normalised) tensor: the GroupNorm `gname` (+ GELU when act) is applied while
+        the GEMM loads its A operand (crd_gn_conv); xn: PM that also receives the normalised bf16 tensor, or None."""
+        w, x = spec["w"], spec["x"]
+        assert x.coff == 0 and (xn is None or xn.coff == 0)
+        flops = 2.0 * self.B * spec["OH"] * spec["OW"] * spec["cout"] * w.cin_ref * w.taps
+        kname = ("k_gngemm_res" if w.cin_ref * w.taps <= 256 else "k_gngemm_str") + ("<64x64>" if spec["cout"] <= 64 else "<64x128>")
+        meta = {"kernel": kname, "flops": flops,
+                "shape": f"gn+fwd Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} out{spec['OH']}x{spec['OW']}"}
+        gn = dict(gn_in=True, x_f32=x.f32, gmul=gmul, stats=stats, gamma=self.p(gname + ".weight"), beta=self.p(gname + ".bias"),
+                  act=act, xn=xn)
+        op = Op(self.lib.crd_gn_conv, [spec, gn], "crd_gn_conv", None, None, meta, stream=self._cur_stream)
+        lst.append(op)
+        return op
+
     def wgrad(self, lst, x, dy, cw, k, stride, pad, OH, OW, dbias=None, cin=None):
         if cw.frozen:                 # no trainable parameter behind this launch
             return
@@ -328,6 +352,13 @@ class Plan:
             if isinstance(v, PM):
                 return v.t.data_ptr()
             return v.data_ptr()
+        if sp.get("gn_in"):
+            n = L.GnInput()
+            n.x_f32, n.gmul, n.act = sp["x_f32"], sp["gmul"], sp["act"]
+            n.stats, n.gamma, n.beta = P(sp["stats"]), P(sp["gamma"]), P(sp["beta"])
+            n.xn, n.xn_ld = (P(sp["xn"]), sp["xn"].ld) if sp["xn"] is not None else (None, 0)
+            self.keep.append(n)
+            return C.byref(n)
         if sp.get("wg"):
             x, dy, cw = sp["x"], sp["dy"], sp["cw"]
             d = into if into is not None else L.WgradDesc()
@@ -706,29 +737,45 @@ class Plan:
         F_ = self.fwd
         # ---- attention branch ----
         XN = self.act(Cs, Hs, Ws)
+        fused = self.gn_conv_on
         if pre is not None and FUSE_STATS:
             st1, ch1 = pre
-            self.gn_fwd(X, st1, 1, name + ".norm1", 0, None, XN)
         else:
             st1, ch1 = self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)
-            self.gn_stats_apply(X, st1, ch1, 1, name + ".norm1", 0, None, XN)
+            self._emit(self.fwd, "crd_gn_stats", [X.t, X.f32, X.ld, X.coff, self.B, X.P, X.C, st1, ch1])
+        if not fused:
+            self.gn_fwd(X, st1, 1, name + ".norm1", 0, None, XN)
         cq, ck, cp = self.new_conv(a + ".q"), self.new_conv(a + ".k"), self.new_conv(a + ".proj")
         Q = self.act(Cs, Hs, Ws)
-        with self.side(1):       # q projection: independent of the key path below
-            self.conv(F_, self.conv_desc(XN, cq, Cs, 1, 1, 0, Hs, Ws, Q, bias=cq.bias))
         xbar = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         U = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
         assert cp.cin_pad == Cs and cp.cout_pad == Cs
         K = self.act(Cs, Hs // sr, Ws // sr)
+        tr = self.need_grad
+        q_spec = self.conv_desc(XN, cq, Cs, 1, 1, 0, Hs, Ws, Q, bias=cq.bias)
+        if fused:           # Block.norm1 applied while q loads X; XN is written on the way (the key path and the weight
+            q_spec["x"] = X  # gradients read it)
+            self.gn_conv(F_, q_spec, st1, 1, name + ".norm1", 0, XN)
         if sr > 1:
             csr = self.new_conv(a + ".sr", scatter=True)
             KR = self.act(Cs, Hs // sr, Ws // sr)
             stk = self.zf(B, Cs // 16, 2)
-            self.conv(F_, self.conv_desc(XN, csr, Cs, sr, sr, 0, Hs // sr, Ws // sr, KR, bias=csr.bias, stats=stk))
             KRN = self.act(Cs, Hs // sr, Ws // sr)
-            self.gn_fwd(KR, stk, 1, a + ".norm", 0, None, KRN)
-            self.conv(F_, self.conv_desc(KRN, ck, Cs, 1, 1, 0, Hs // sr, Ws // sr, K, bias=ck.bias))
+            if not fused:
+                with self.side(1):       # q projection: independent of the key path below
+                    self.conv(F_, q_spec)
+            self.conv(F_, self.conv_desc(XN, csr, Cs, sr, sr, 0, Hs // sr, Ws // sr, KR, bias=csr.bias, stats=stk))
+            k_spec = self.conv_desc(KRN, ck, Cs, 1, 1, 0, Hs // sr, Ws // sr, K, bias=ck.bias)
+            if fused:       # attn.norm applied while k loads KR
+                k_spec["x"] = KR
+                self.gn_conv(F_, k_spec, stk, 1, a + ".norm", 0, KRN if tr else None)
+            else:
+                self.gn_fwd(KR, stk, 1, a + ".norm", 0, None, KRN)
+                self.conv(F_, k_spec)
         else:
+            if not fused:
+                with self.side(1):
+                    self.conv(F_, q_spec)
             self.conv(F_, self.conv_desc(XN, ck, Cs, 1, 1, 0, Hs, Ws, K, bias=ck.bias))
         self.join(F_, 1)
         Ssum = self.new((B, N), F32)
@@ -743,24 +790,34 @@ class Plan:
         XN2 = self.act(Cs, Hs, Ws)
         if FUSE_STATS:       # norm2's statistics come out of the kernel that writes X1
             self._emit(F_, "crd_attn_out_residual_stats", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t, st2])
-            self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
         else:
             self._emit(F_, "crd_attn_out_residual", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t])
-            self.gn_stats_apply(X1, st2, None, 1, name + ".norm2", 0, None, XN2)
+            self._emit(F_, "crd_gn_stats", [X1.t, X1.f32, X1.ld, X1.coff, self.B, X1.P, X1.C, st2, None])
         c1, c2 = self.new_conv(ml + ".fc1"), self.new_conv(ml + ".fc2")
         H1, H2, H3 = (self.act(hid, Hs, Ws) for _ in range(3))
         sth1, sth2 = self.zf(B, hid // 16, 2), self.zf(B, hid // 16, 2)
-        self.conv(F_, self.conv_desc(XN2, c1, hid, 1, 1, 0, Hs, Ws, H1, bias=c1.bias, stats=sth1))
+        fc1_spec = self.conv_desc(XN2, c1, hid, 1, 1, 0, Hs, Ws, H1, bias=c1.bias, stats=sth1)
+        if fused:            # Block.norm2 applied while fc1 loads X1
+            fc1_spec["x"] = X1
+            self.gn_conv(F_, fc1_spec, st2, 1, name + ".norm2", 0, XN2 if tr else None)
+        else:
+            self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
+            self.conv(F_, fc1_spec)
         # Mlp.norm1 is applied by the depthwise kernels while they stage H1 (the normalised tensor is never stored)
         n1 = [sth1, 1, self.p(ml + ".norm1.weight"), self.p(ml + ".norm1.bias")]
         w9 = self.new((9, hid), F32)
         self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9))
         self._emit(F_, "crd_dwconv3x3", [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1 + [None, None, None, None])
-        self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
         X2 = self.act(Cs, Hs, Ws, F32)
         nxt = (self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)) if (want_next and FUSE_STATS) else None
-        self.conv(F_, self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp,
-                                     stats=nxt[0] if nxt else None, chan=nxt[1] if nxt else None))
+        fc2_spec = self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp,
+                                  stats=nxt[0] if nxt else None, chan=nxt[1] if nxt else None)
+        if fused:            # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only)
+            fc2_spec["x"] = H2
+            self.gn_conv(F_, fc2_spec, sth2, ratio, ml + ".norm2", 1, H3 if tr else None)
+        else:
+            self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
+            self.conv(F_, fc2_spec)
 
         # ---- backward (executed after the later blocks'; DX holds d(X2) on entry, d(X) on exit) ----
         g = []

@@ -17,6 +17,7 @@ class InferenceGraph:
         model.eval()
         self.model, self.B, self.H, self.W = model, B, H, W
         x = torch.zeros((B, model.cfg.input_channels, H, W), device=model.flat.device)
+        model.__dict__["_need_grad"] = False        # inference: nothing is kept for a backward pass
         self.plan = model._plan_for(x)
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())

@@ -241,12 +241,16 @@ class CamRaDepth(nn.Module):
 
     def _plan_key(self, x):
         frozen = tuple(i for i, n in enumerate(self._names) if not self._param(n).requires_grad)
-        return (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None), frozen)
+        from .engine import gn_conv_default
+        return (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None), frozen,
+                bool(getattr(self, "_need_grad", True)), gn_conv_default())
 
     def forward(self, x, masks=None):
         """Returns the reference's nested dict (CamRaDepth.py:169-170).  `masks` optionally injects the
         DropPath / Dropout2d masks in train mode (camradepth_amd.synth.make_masks) for parity tests."""
         x = x.to(torch.float32)
+        # autograd.Function.forward runs with gradients disabled: note here whether a backward pass can follow
+        self.__dict__["_need_grad"] = torch.is_grad_enabled()
         outs = _Bridge.apply(self._anchor, x, self, masks)
         final, half, quarter = outs[0], outs[1], outs[2]
         seg = outs[3] if len(outs) > 3 else None

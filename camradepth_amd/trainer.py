@@ -109,6 +109,7 @@ class TrainStep:
         from .engine import LATE_WGRAD, W3_LATE_WGS
         self.late_wgrad = bool(LATE_WGRAD and use_graph)
         model.w3_total_wgs = W3_LATE_WGS if self.late_wgrad else None
+        model.__dict__["_need_grad"] = True
         self.plan = model._plan_for(x)
         model._ensure_grad_views()
         self.sup = model.cfg.supervised_seg

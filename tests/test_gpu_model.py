@@ -22,7 +22,7 @@ from tests.util import golden_state_dict, load_npz
 
 pytestmark = pytest.mark.gpu
 # measured on MI355X over repeated runs (see the test's printout in profiles/r02_gpu_tests.log); bound = 2x the largest
-RMSE_GAP_GOLDEN_256 = 1e-2
+RMSE_GAP_GOLDEN_256 = 1.5e-2       # measured 4e-4 .. 6.9e-3 (0.65 % of the reference RMSE 1.065 these weights give)
 VARIANTS = ["base", "supervised_seg", "unsupervised_seg", "sup_unsup_seg"]
 
 
@@ -260,7 +260,7 @@ def test_full_resolution_928x1600_matches_reference_golden():
     seg_miss = float((am != g["seg_argmax_s4"]).mean())
     print(f"928x1600 vs reference: final {r_full:.4f} half {r_half:.4f} quarter {r_quarter:.4f} seg arg-max mismatch {seg_miss:.4f} "
           f"rmse {rmse:.6f} / {float(g['rmse'][0]):.6f}")
-    assert r_full < 0.1 and r_half < 0.1 and r_quarter < 0.15
+    assert r_full < 0.2 and r_half < 0.1 and r_quarter < 0.1        # measured 0.089 / 0.041 / 0.028
     assert abs(rmse - float(g["rmse"][0])) < 3e-2 * float(g["rmse"][0])
     assert abs(float(fd.double().mean()) - g["final_stats"][0]) < 0.05 * abs(g["final_stats"][0]) + 1e-3
-    assert seg_miss < 0.15
+    assert seg_miss < 0.2              # measured 0.12 (arg-max over 21 near-tied logits of the ill-conditioned golden weights)

@@ -91,8 +91,8 @@ def test_shallow_per_parameter_gradients_with_oracle_argmax(variant):
     worst = max(errs)
     med = float(np.median([e for e, _ in errs]))
     print(f"per-parameter gradient rel-L2 with injected arg-max: median {med:.4f}, worst {worst}")
-    assert med < 0.02, med
-    assert worst[0] < 0.05, worst
+    assert med < 0.03, med              # measured 0.012-0.013
+    assert worst[0] < 0.08, worst       # measured 0.025-0.047 (block4 attn.q): 24x tighter than the un-injected bound
 
 
 def test_gradient_accumulation_matches_oracle_and_reference_loop():
@@ -307,8 +307,8 @@ def test_train_step_at_benchmark_size_graph_vs_eager_and_oracle():
     g_rel = rel(m2.flat_grad, g1)
     d_rel = rel(m2.flat - p_before, m1.flat - p_before)
     print(f"C2 train step, graph vs eager: loss {l2['loss']:.6f} / {float(loss):.6f}, grad rel-L2 {g_rel:.4f}, update rel-L2 {d_rel:.4f}")
-    assert g_rel < 0.15, g_rel
-    assert d_rel < 0.2, d_rel
+    assert g_rel < 2e-2, g_rel          # measured 6e-4
+    assert d_rel < 0.2, d_rel           # measured 0.07: sign-like first diffGradNorm step on near-zero gradient elements
     # oracle at batch 2 (same weights, masks of the first two samples)
     b2 = {k: v[:2] for k, v in batch_h.items()}
     mk2 = {"drop_path": [t[:2] for t in masks["drop_path"]], "dropout2d": [t[:2] for t in masks["dropout2d"]]}
@@ -339,7 +339,7 @@ def test_train_step_at_benchmark_size_graph_vs_eager_and_oracle():
         den += float((ref_delta ** 2).sum())
     upd = (num / den) ** 0.5
     print(f"C2-size first-step update vs oracle (batch 2): rel-L2 {upd:.4f}")
-    assert upd < 0.6, upd       # sign-like first step of diffGradNorm on a bf16-chaotic full-depth gradient (see module docstring)
+    assert upd < 0.25, upd      # measured 0.10; sign-like first step of diffGradNorm on a bf16-chaotic full-depth gradient (see module docstring)
 
 
 def _free_port():

@@ -27,6 +27,10 @@
 #include <cstdlib>
 
 using namespace crdk;
+bool crd_conv3x3p_applicable(const ConvK& k, int B);                                      // conv3x3p.hip
+int crd_conv3x3p(const ConvK& k, int B, hipStream_t st, int col0, int col1, int tn);
+long long crd_conv3x3p_partial_floats(const ConvK& k, int B);
+int crd_conv3x3p_finalize(const ConvK& k, int B, hipStream_t st);
 
 namespace {
 
@@ -327,6 +331,29 @@ extern "C" int crd_tune_conv3x3_small_grid(int workgroups) {
 
 // Called from crd_conv_igemm for 3x3 / stride 1 / pad 1 layers on grids large enough to fill the chip.
 int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_cap) {
+  // persistent one-wave-per-SIMD kernel (conv3x3p.hip) for the 128-column tiles (96 / 64 columns: one narrower tile).  Its
+  // GroupNorm sums need the caller's partial-sum buffer; without one (or a too small one) the launch stays here.
+  if (crd_conv3x3p_applicable(k, B) && (!k.stats || (k.stats_partial && crd_conv3x3p_partial_floats(k, B) <= partial_cap))) {
+    // a ragged tail of <= 64 columns (data gradients towards 136 / 144 / 296 / 304 channels) goes to the narrow tiles here
+    const int N = k.Cout;
+    int rc;
+    if (N <= 64) rc = crd_conv3x3p(k, B, st, 0, N, 2);
+    else if (N <= 96) rc = crd_conv3x3p(k, B, st, 0, N, 3);
+    else {
+      const int full = N / 128 * 128, rest = N - full;
+      if (rest == 0 || rest > 64) rc = crd_conv3x3p(k, B, st, 0, N, 4);
+      else {
+        CRD_UNSUPPORTED(!k.stats, "crd_conv_igemm: GroupNorm sums with a ragged column tail are not split over two kernels");
+        rc = crd_conv3x3p(k, B, st, 0, full, 4);
+        if (rc != CRD_OK) return rc;
+        ConvK kt = k;
+        kt.stats_partial = nullptr;
+        return rest <= 32 ? launch3<4, 1, 2, 1>(kt, B, st, 0, full, N, true) : launch3<4, 1, 2, 2>(kt, B, st, 0, full, N, true);
+      }
+    }
+    if (rc != CRD_OK || !k.stats) return rc;
+    return crd_conv3x3p_finalize(k, B, st);
+  }
   {   // grids that leave most CUs without a workgroup (the 32x52 decoder level: 64 pixel tiles): narrower column tiles
     if (g_small_thr < 0) { const char* e = getenv("CRD_CONV3_SMALL"); g_small_thr = e ? atoi(e) : 512; }
     const int thr = g_small_thr;

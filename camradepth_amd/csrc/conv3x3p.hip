@@ -1,0 +1,460 @@
+// Persistent halo-tile 3x3 convolution (stride 1, pad 1) on MFMA for gfx950: the decoder's big ShortResBlock convs at
+// the 128x208 and 256x416 levels (src/utils/utils.py:114-124,211), forward and data gradient.
+//
+// k_conv3x3 (conv3x3.hip) runs two 4-wave workgroups per CU at 256 VGPRs each; its ablation showed the DMA issue, the
+// LDS fragment reads and the MFMAs of a step to be ADDITIVE (0.20 + 0.19 + 0.25 ms of a 0.67 ms launch): a wave issues
+// its loads, waits, then issues its MFMAs, and the second wave of the SIMD is as often in the same phase as not.  This
+// kernel takes the other road of the CDNA playbook (cdna_hip_programming.md, 4-wave one-wave-per-SIMD structure):
+//   * ONE workgroup of 4 waves per CU, every wave alone on its SIMD with the whole 512-register file: a 128-pixel x
+//     128-column accumulator per wave (256 VGPRs; 0.5 fragment reads per MFMA instead of 0.75) and room to
+//     software-pipeline the fragment reads in registers -- the reads of the next half-step are issued before the 16
+//     MFMAs of the current one, so LDS latency and the DMA issue slots hide in the MFMA shadow (one wave can issue ~5
+//     other instructions per 32-cycle MFMA for free);
+//   * a 16 x 32 = 512-pixel tile per workgroup: one weight slab serves twice the pixels, halo overhead 1.20 instead of 1.33;
+//   * PERSISTENT workgroups walk over the tiles of their column range: the weight-slab ring simply keeps running across
+//     tiles and the first halo of the next tile is requested during the last channel chunk of the current one, so there
+//     is no exposed prologue (the one-workgroup-per-CU kernel of round 1 lost 23-54 % there);
+//   * the epilogue is per wave (its own 32-pixel x BN staging strip in LDS, 16-byte stores, GroupNorm sums by shuffles
+//     and one atomic per slab and wave), so it needs no workgroup barrier and no LDS that the running rings occupy.
+// Same K walk as k_conv3x3: (32-channel chunk) x (9 taps), halo of a chunk in LDS once (double buffered), weight slab
+// of every (chunk, tap) through a ring requested D steps ahead, counted vmcnt waits, one raw s_barrier per step.
+// Plain bf16 output (store or accumulate) with optional GroupNorm sums -- everything the decoder's 3x3 ConvLayers and
+// their data gradients need; bias / activation / fp32 / residual epilogues stay with k_conv3x3.
+#include "conv_common.h"
+#include <cstdlib>
+#include <type_traits>
+
+using namespace crdk;
+
+namespace {
+
+constexpr int TH = 16, TW = 32;            // output tile (pixels)
+constexpr int HW_ = TW + 2;                // halo width
+constexpr int HROWS = (TH + 2) * HW_;      // 612 halo pixels
+constexpr int QK = 32;                     // channels per chunk: 64-byte LDS rows
+constexpr int NW = 4;                      // waves
+constexpr int HG = (HROWS + 15) / 16;      // 39 halo DMA pieces (16 rows x 64 B)
+constexpr int HPAD = HG * 16;              // 624 rows allocated per halo buffer
+constexpr int HT = (HG + NW - 1) / NW;     // 10 pieces per wave
+constexpr int TM = 4;                      // 32-pixel row tiles per wave (rows 4 w .. 4 w + 3 of the tile)
+
+typedef __attribute__((address_space(3))) void* lds_ptr;
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// -DCRD_CONV3_ABLATE=bits: parts of the main loop compiled out (timing experiments; results are wrong).  256 no DMA,
+// 16 no vmcnt wait, 32 no barrier, 64 no fragment reads, 128 no MFMA   (tools/ablate_conv.sh FILE=conv3x3p)
+#ifdef CRD_CONV3_ABLATE
+#define ABL(bit) ((CRD_CONV3_ABLATE) & (bit))
+#else
+#define ABL(bit) false
+#endif
+
+// -DCRD_CONV3_PROF: cycles wave 0 of workgroup 0 spends in the main loops and in the epilogues (crd_dbg_conv3p_prof)
+#ifdef CRD_CONV3_PROF
+__device__ unsigned long long g_profp[4];
+#endif
+
+template <int TN, int MODE, int WS>
+__global__ __launch_bounds__(256, 1) void k_conv3x3p(ConvK a, int tiles_x, int tiles_y, int tiles_total) {
+  constexpr int D = WS - 1;
+  static_assert(D >= 2 && D <= 8, "slab prefetch distance");
+  constexpr int BN = TN * 32;
+  constexpr int WGROUPS = BN / 16;                // weight-slab DMA pieces (16 rows x 64 B)
+  constexpr int WJ = (WGROUPS + NW - 1) / NW;     // pieces per wave
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  bf16_t* sH = lds;                               // [2][HPAD][QK]
+  bf16_t* sW = sH + 2 * HPAD * QK;                // [WS][BN][QK]
+  bf16_t* sD = sW + WS * BN * QK;                 // [16][QK] landing area of the zero-fill dummies
+
+  const int t = threadIdx.x, l = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int n0 = a.col0 + blockIdx.y * BN;
+  const int H = a.IH, W = a.IW, Cin = a.Cin;
+  const int nChunks = (Cin + QK - 1) / QK;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot * 2, 0x00020000);
+
+  // weight slab: wave w stages pieces g = 4 j + w: rows n = 16 g + (l>>2), 16-byte slot l&3 <- granule (l&3) ^ ((n>>2)&3)
+  const int wch = ((l & 3) ^ ((l >> 4) & 3)) * 8;
+  unsigned wvo[WJ];
+#pragma unroll
+  for (int j = 0; j < WJ; ++j) {
+    const int g = NW * j + wv;
+    const int n = 16 * g + (l >> 2), ng = n0 + n;
+    wvo[j] = (g < WGROUPS && ng < a.Cout) ? (unsigned)((ng * a.Ktot + wch) * 2) : OOB;
+  }
+  auto stage_weights = [&](int chunk, int tap, int slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tail = Cin - chunk * QK;
+    const bool lane_ok = wch < tail;
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int g = NW * j + wv;
+      bf16_t* dst = g < WGROUPS ? sW + slot * BN * QK + 16 * g * QK : sD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, lane_ok ? wvo[j] : OOB, (tap * Cin + chunk * QK) * 2, 0, 0);
+    }
+#else
+    (void)chunk; (void)tap; (void)slot;
+#endif
+  };
+
+  // halo pieces of one tile: lane l of piece G stages halo row 16 G + (l>>2), slot l&3 <- granule (l&3) ^ ((row>>2)&3)
+  unsigned hvo[HT];
+  auto halo_offsets = [&](int tile) {             // tile >= tiles_total: everything out of range (zero fill)
+    const int bb = tile / (tiles_x * tiles_y), rem = tile - bb * (tiles_x * tiles_y);
+    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+#pragma unroll
+    for (int s = 0; s < HT; ++s) {
+      const int G = NW * s + wv;
+      const int hr = 16 * G + (l >> 2);
+      const int hy = hr / HW_, hx = hr - hy * HW_;
+      const int iy = tyi * TH - 1 + hy, ix = txi * TW - 1 + hx;
+      const bool ok = tile < tiles_total && G < HG && hr < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int ch = ((l & 3) ^ ((hr >> 2) & 3)) * 8;
+      hvo[s] = ok ? (unsigned)(((iy * W + ix) * a.x_ld + ch) * 2) : OOB;
+    }
+    return bb;
+  };
+  auto stage_halo = [&](const __amdgpu_buffer_rsrc_t& rx, int chunk, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tail = Cin - chunk * QK;
+#pragma unroll
+    for (int s = 0; s < HT; ++s) {
+      const int G = NW * s + wv;
+      const int ch = ((l & 3) ^ (((16 * G + (l >> 2)) >> 2) & 3)) * 8;
+      const bool real = G < HG;
+      bf16_t* dst = real ? sH + buf * HPAD * QK + G * 16 * QK : sD;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)dst, 16, (real && ch < tail) ? hvo[s] : OOB, chunk * QK * 2, 0, 0);
+    }
+#else
+    (void)rx; (void)chunk; (void)buf;
+#endif
+  };
+  auto make_rx = [&](int bb) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)bb * a.x_bstride), 0, (int)(a.x_bstride * 2), 0x00020000);
+  };
+
+  // fragment reads of half-step ks of (halo buffer hb, tap, ring slot wb)
+  auto read_frags = [&](int hb, int tap, int wb, int ks, bf16x8 (&af)[TM], bf16x8 (&bfr)[TN]) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int oy = (MODE == 0) ? ky : 2 - ky, ox = (MODE == 0) ? kx : 2 - kx;
+    const bf16_t* hbase = sH + hb * HPAD * QK;
+    const bf16_t* wbase = sW + wb * BN * QK;
+    const int gi = ks * 2 + (l >> 5);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int hr = (wv * TM + i + oy) * HW_ + (l & 31) + ox;
+      af[i] = *reinterpret_cast<const bf16x8*>(hbase + hr * QK + ((gi ^ ((hr >> 2) & 3)) << 3));
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int row = j * 32 + (l & 31);
+      bfr[j] = *reinterpret_cast<const bf16x8*>(wbase + row * QK + ((gi ^ ((row >> 2) & 3)) << 3));
+    }
+  };
+
+  f32x16 acc[TM][TN];
+  auto zero_acc = [&]() {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  };
+
+  int tile = blockIdx.x;
+  if (tile >= tiles_total) return;
+  // ---- prologue: halo of the first tile's chunk 0, slabs of steps 0 .. D-1 ----
+  int b = __builtin_amdgcn_readfirstlane(halo_offsets(tile));
+  __amdgpu_buffer_rsrc_t rx = make_rx(b);
+  stage_halo(rx, 0, 0);
+  int pc = 0, pt = 0;                                 // (chunk, tap) of the next slab to request; chunk wraps per tile
+#pragma unroll
+  for (int s = 0; s < D; ++s) {
+    stage_weights(pc, pt, s);
+    if (++pt == 9) { pt = 0; if (++pc == nChunks) pc = 0; }
+  }
+  wait_vm<(D - 1) * WJ>();                            // halo + slab 0 have landed
+  asm volatile("s_barrier" ::: "memory");
+  int gchunk = 0;                                     // chunks done so far (all tiles): parity = halo buffer
+  int wb = 0, wnext = D % WS;
+  bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
+  read_frags(0, 0, 0, 0, a0, b0);
+
+  for (; tile < tiles_total; tile += gridDim.x) {
+    const int rem = tile - b * (tiles_x * tiles_y);
+    const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    const int ty0 = tyi * TH, tx0 = txi * TW;
+    zero_acc();
+#ifdef CRD_CONV3_PROF
+    const unsigned long long pt0 = __builtin_readcyclecounter();
+#endif
+    for (int chunk = 0; chunk < nChunks; ++chunk, ++gchunk) {
+      const int hb = gchunk & 1;
+      const bool last = chunk + 1 == nChunks;
+      // one (chunk, tap) step; TWO: the chunk's second 16 channels hold data (false only for the 8- / 16-channel tail of
+      // Cin = 136 / 144 / 296 / 304).  The LDS reads are never conditional: with a branch around reads in the loop the
+      // compiler's lgkmcnt bookkeeping takes the worst case at the join and stalls the first MFMAs of every half-step on
+      // the reads issued for the next one (and two copies of the loop body spill 227 VGPRs).
+      // MFMAs and everything else of a half-step in ONE scheduling region, with the issue order pinned: an in-order wave
+      // that issues its 16 MFMAs back to back spends 512 cycles doing only that, and its loads, address arithmetic and DMA
+      // requests ADD to them (measured 2125 cycles per step against 1024 of MFMA issue); placed in the gaps between MFMAs
+      // (a wave can issue ~5 other instructions per 32-cycle MFMA for free) they cost nothing.
+      auto interleave = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < TM * TN; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);             // one MFMA
+          if (k < TM + TN) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);           // address arithmetic of a fragment read
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);           // the read
+          } else if (k < TM + TN + WJ) {
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);           // a slab request (VMEM read)
+          }
+        }
+      };
+      // one (chunk, tap) step.  Both 16-channel halves of the chunk are always multiplied (the 8- / 16-channel tails of
+      // Cin = 136 / 144 / 296 / 304 are zero-filled): a branch around the second half's MFMAs would split the scheduling
+      // region, and a branch around its reads makes the compiler's lgkmcnt bookkeeping stall the next MFMAs.
+      auto step = [&](int tap) __attribute__((always_inline)) {
+        // ---- at tap 0 the next halo (next chunk, or chunk 0 of the next tile) ----
+        if (tap == 0 && !ABL(256)) {
+          if (last) {                                  // the ring keeps running: first halo of the workgroup's next tile
+            const int nb = __builtin_amdgcn_readfirstlane(halo_offsets(tile + gridDim.x));
+            if (tile + gridDim.x < tiles_total) { b = nb; rx = make_rx(b); }
+            stage_halo(rx, 0, hb ^ 1);
+          } else {
+            stage_halo(rx, chunk + 1, hb ^ 1);
+          }
+        }
+        // ---- half-step 0: MFMAs on (a0, b0); in their shadow the slab request of step + D and the reads of half-step 1 ----
+        if (!ABL(256)) stage_weights(pc, pt, wnext);
+        if (++pt == 9) { pt = 0; if (++pc == nChunks) pc = 0; }
+        if (!ABL(64)) read_frags(hb, tap, wb, 1, a1, b1);
+        if (!ABL(128)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+        } else { acc[0][0][0] += (float)a0[0][0] * (float)b0[0][0]; }
+        if (!ABL(4096)) interleave();
+        // the slab of step+1 (requested D steps before it) has landed: all but the requests of the last D-1 steps (this
+        // step's included), which include this chunk's halo burst -- issued BEFORE this step's slab request -- while tap <= D-2
+        if (!ABL(16)) {
+        if (tap <= D - 2) wait_vm<(D - 1) * WJ + HT>();
+        else wait_vm<(D - 1) * WJ>();
+        }
+        // (the builtin, not inline asm: the compiler's own lgkmcnt bookkeeping must see that nothing is pending here)
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): (a1, b1) have arrived, all of this wave's LDS reads are done
+        if (!ABL(32)) __builtin_amdgcn_s_barrier();
+        wb = wb + 1 == WS ? 0 : wb + 1;
+        wnext = wnext + 1 == WS ? 0 : wnext + 1;
+        // ---- half-step 1: MFMAs on (a1, b1); in their shadow the reads of the NEXT step's half-step 0 ----
+        const int wrap = tap == 8;
+        if (!ABL(64)) read_frags(hb ^ wrap, wrap ? 0 : tap + 1, wb, 0, a0, b0);
+        if (!ABL(128)) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+        } else { acc[0][0][0] += (float)a1[0][0] * (float)b1[0][0]; }
+        if (!ABL(4096)) interleave();
+      };
+      // (tap loops not unrolled: with nine copies the compiler keeps every tap's fragment addresses live -- 345 spilled
+      // VGPRs; the address arithmetic of a step, ~60 VALU instructions, hides under its 32 MFMAs)
+#ifdef CRD_C3P_ROLLED
+#pragma unroll 1
+#else
+#pragma unroll
+#endif
+      for (int tap = 0; tap < 9; ++tap) step(tap);
+    }
+#ifdef CRD_CONV3_PROF
+    const unsigned long long pt1 = __builtin_readcyclecounter();
+#endif
+    // ---- epilogue of this wave's 4 x 32 pixels x BN columns, straight from the accumulators ----
+    // The MFMA operands are swapped (A = weight rows, B = pixels), so a lane holds ONE pixel (column l&31) and, per 32 x 32
+    // tile, the output channels (r&3) + 8 (r>>2) + 4 (l>>5): four runs of 4 consecutive channels.  v_permlane32_swap
+    // between the two half-waves (which hold the same pixel) turns two such runs into 8 consecutive channels = one
+    // 16-byte store per lane (the CDNA guide's T21).  No LDS staging (the first version's staging strip + barrier-free
+    // per-wave copy cost 0.6 ms of a 0.9 ms launch whose main loop takes 0.28 ms), no wait on anything in flight.
+    if (ABL(512)) {       // (every accumulator stays live: an ablation that lets the compiler drop MFMAs measures nothing)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(acc[i][j][r]));
+    } else
+    {
+      // lane-constant epilogue values must not be hoisted out of the tile loop (they would be spilled across the main loop
+      // and every reload waits vmcnt(0), behind the DMA queue): an opaque copy of the lane id makes them per-tile values
+      int le = l;
+      asm volatile("" : "+v"(le));
+      const int half = le >> 5, px = le & 31;
+      const int bt = (tile - rem) / (tiles_x * tiles_y);                 // image of THIS tile (b may already be the next one's)
+      bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)bt * a.y_bstride;
+      float s[TN][2], ss[TN][2];                                          // GroupNorm sums of this lane's pixel, per 16-channel slab
+#pragma unroll
+      for (int j = 0; j < TN; ++j) s[j][0] = s[j][1] = ss[j][0] = ss[j][1] = 0.f;
+      const int x = tx0 + px;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int y = ty0 + wv * TM + i;
+        const bool pok = y < H && x < W;
+        bf16_t* row = yb + ((long long)y * W + x) * a.y_ld + n0 + half * 8;
+        uint4 u[TN][2];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          __builtin_amdgcn_sched_barrier(0);          // one 32 x 32 tile at a time (hoisting every accumulator read spills)
+          uint32_t d[4][2];
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            d[g4][0] = pack_bf2(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1]);
+            d[g4][1] = pack_bf2(acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+            if (pok) {
+              const float v0 = bf_lo(d[g4][0]), v1 = bf_hi(d[g4][0]), v2 = bf_lo(d[g4][1]), v3 = bf_hi(d[g4][1]);
+              s[j][g4 >> 1] += (v0 + v1) + (v2 + v3);
+              ss[j][g4 >> 1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            }
+          }
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            // runs 2 pr (channels 16 pr + 4 half ..) and 2 pr + 1 (16 pr + 8 + 4 half ..): after the swaps the lower half-wave
+            // holds channels 16 pr .. 16 pr + 7 of its pixel, the upper one channels 16 pr + 8 .. 16 pr + 15
+            auto r0 = __builtin_amdgcn_permlane32_swap(d[2 * pr][0], d[2 * pr + 1][0], false, false);
+            auto r1 = __builtin_amdgcn_permlane32_swap(d[2 * pr][1], d[2 * pr + 1][1], false, false);
+            u[j][pr] = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ABL(1024)) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(u[j][0].x), "v"(u[j][0].w), "v"(u[j][1].x), "v"(u[j][1].w));
+        } else if (pok) {
+          // read-modify-write (gradient accumulation): ALL of the row's loads first, one wait, then the stores -- a load
+          // inside the per-store branch made the compiler wait vmcnt(0) before every single store
+          if (a.accumulate) {
+            uint4 o[TN][2];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {
+                o[j][pr] = make_uint4(0, 0, 0, 0);
+                if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) o[j][pr] = *reinterpret_cast<const uint4*>(row + j * 32 + pr * 16);
+              }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {
+                uint4& v = u[j][pr];
+                const uint4 q = o[j][pr];
+                v.x = pack_bf2(bf_lo(v.x) + bf_lo(q.x), bf_hi(v.x) + bf_hi(q.x));
+                v.y = pack_bf2(bf_lo(v.y) + bf_lo(q.y), bf_hi(v.y) + bf_hi(q.y));
+                v.z = pack_bf2(bf_lo(v.z) + bf_lo(q.z), bf_hi(v.z) + bf_hi(q.z));
+                v.w = pack_bf2(bf_lo(v.w) + bf_lo(q.w), bf_hi(v.w) + bf_hi(q.w));
+              }
+          }
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+              if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) *reinterpret_cast<uint4*>(row + j * 32 + pr * 16) = u[j][pr];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (a.stats && !ABL(2048)) {
+        // GroupNorm sums of this wave's part of the tile as one row of plain stores: [image][tile][wave][G16][2], summed by
+        // k_stats_finalize.  (Atomics straight into stats: the persistent workgroups reach their epilogues together, and
+        // 1024 waves x 16 atomics on the same few cache lines stalled every wave's next vmcnt wait -- 0.4 ms of a 1.1 ms launch.)
+        float* prow = a.stats_partial + ((((long long)bt * (tiles_x * tiles_y) + rem) * NW + wv) * a.G16) * 2;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int sl = 0; sl < 2; ++sl) {
+            // a lane's runs of slab sl are channels 16 sl + 4 half + {0..3, 8..11}: both half-waves feed both slabs
+            const float sv = wave_sum(s[j][sl]), sq = wave_sum(ss[j][sl]);
+            const int gidx = ((n0 + j * 32) >> 4) + sl;
+            if (le == 0 && gidx < a.G16) *reinterpret_cast<float2*>(prow + gidx * 2) = make_float2(sv, sq);
+          }
+      }
+      // the first fragments of the next tile are read (again) here, so that (a0, b0) need not survive the epilogue:
+      // 32 more live VGPRs there made the compiler spill, and a spill reload waits vmcnt(0) -- behind the tile's stores
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(gchunk & 1, 0, wb, 0, a0, b0);
+    }
+#ifdef CRD_CONV3_PROF
+    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
+      const unsigned long long pt2 = __builtin_readcyclecounter();
+      g_profp[0] += pt1 - pt0; g_profp[1] += pt2 - pt1; g_profp[2] += 1;
+    }
+#endif
+  }
+  wait_vm<0>();
+}
+
+template <int TN, int WS>
+int launch_p(const ConvK& k0, int B, hipStream_t st, int col0, int col1) {
+  constexpr int BN = TN * 32;
+  ConvK k = k0;
+  k.col0 = col0;
+  const int tiles_x = cdiv(k.IW, TW), tiles_y = cdiv(k.IH, TH);
+  const int tiles_total = tiles_x * tiles_y * B;
+  const int gy = cdiv(col1 - col0, BN);
+  int gx = 256 / gy;
+  if (gx < 1) gx = 1;
+  if (gx > tiles_total) gx = tiles_total;
+  const size_t lds = (size_t)(2 * HPAD * QK + WS * BN * QK + 16 * QK) * sizeof(bf16_t);
+  static bool attr_done[2] = {false, false};
+  const int m = k.gather_mode == 0 ? 0 : 1;
+  if (m == 0) {
+    if (!attr_done[0]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 0, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+    hipLaunchKernelGGL((k_conv3x3p<TN, 0, WS>), dim3(gx, gy), dim3(256), lds, st, k, tiles_x, tiles_y, tiles_total);
+  } else {
+    if (!attr_done[1]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 1, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+    hipLaunchKernelGGL((k_conv3x3p<TN, 1, WS>), dim3(gx, gy), dim3(256), lds, st, k, tiles_x, tiles_y, tiles_total);
+  }
+  CRD_LAUNCH_CHECK("crd_conv_igemm(3x3 persistent)");
+  return CRD_OK;
+}
+
+// rows of GroupNorm partial sums a launch writes per image (crd_conv_desc.stats_partial must hold B x rows x Cout/16 x 2 floats)
+inline long long partial_rows(const ConvK& k) { return (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * NW; }
+
+}  // namespace
+
+#ifdef CRD_CONV3_PROF
+extern "C" int crd_dbg_conv3p_prof(unsigned long long* out, int reset) {
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_profp), z, sizeof(z)); }
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_profp), sizeof(g_profp));
+}
+#endif
+
+// Can the persistent kernel take (part of) this launch?  Plain bf16 store / accumulate with optional GroupNorm sums, on
+// grids with enough 16 x 32 tiles to occupy the chip.
+bool crd_conv3x3p_applicable(const ConvK& k, int B) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("CRD_CONV3P"); on = e ? atoi(e) : 1; }
+  if (!on) return false;
+  const long long tiles = (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * B;
+  return !k.y_f32 && !k.bias && !k.act && !k.res && k.out_mode == 0 && k.vec_ok && (k.y_ld & 7) == 0 && (k.Cout & 7) == 0 &&
+         k.red_x == nullptr && !k.chan && tiles >= 192 && k.Cout >= 64;
+}
+
+// GroupNorm sums go through per-(tile, wave) partial rows: floats the caller's stats_partial buffer must hold
+long long crd_conv3x3p_partial_floats(const ConvK& k, int B) { return (long long)B * partial_rows(k) * k.G16 * 2; }
+int crd_conv3x3p_finalize(const ConvK& k, int B, hipStream_t st) {
+  hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, (int)partial_rows(k), k.G16, k.stats);
+  CRD_LAUNCH_CHECK("crd_conv_igemm(3x3 persistent, statistics)");
+  return CRD_OK;
+}
+
+// Output columns [col0, col1) in tiles of TN x 32 (col1 - col0 a multiple of the tile except for a masked last tile)
+int crd_conv3x3p(const ConvK& k, int B, hipStream_t st, int col0, int col1, int tn) {
+  if (tn == 4) return launch_p<4, 5>(k, B, st, col0, col1);
+  if (tn == 3) return launch_p<3, 5>(k, B, st, col0, col1);
+  return launch_p<2, 5>(k, B, st, col0, col1);
+}

@@ -108,6 +108,19 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
     return "k_igemm<2,2,2,2>"
 
 
+def persistent_conv3(spec, B):
+    """Does crd_conv_igemm send this 3x3 launch to the persistent one-wave-per-SIMD kernel (csrc/conv3x3p.hip)?  Plain bf16
+    store / accumulate (+ GroupNorm sums) on grids of >= 192 tiles of 16 x 32 pixels."""
+    if os.environ.get("CRD_CONV3P", "1") == "0":
+        return False
+    y = spec["y"]
+    plain = (not y.f32 and spec["bias"] is None and not spec["act"] and spec["res"] is None and spec["out_mode"] == 0
+             and spec.get("red") is None and spec.get("chan") is None)
+    halo = spec["k"] == 3 and spec["stride"] == 1 and spec["OW"] >= 32 and spec["OH"] >= 8
+    tiles = -(-spec["OW"] // 32) * -(-spec["OH"] // 16) * B
+    return bool(plain and halo and tiles >= 192 and spec["cout"] >= 64 and spec["cout"] % 8 == 0)
+
+
 def halo_tile(cout, OH=1 << 20, OW=1 << 20, B=1):
     """Tile configuration of the halo-tile 3x3 kernel (csrc/conv3x3.hip: crd_conv3x3_halo), for the bench labels."""
     tiles = -(-OW // 32) * -(-OH // 8) * B
@@ -172,6 +185,7 @@ class Plan:
         self._side_streams = None
         self.split_late = False            # trainer: ops of stream LATE are skipped by backward() and run by run_late()
         self.attn_parts = None
+        self.stats_scratch = None
         self.buffers = []
         # parameters with requires_grad=False (the reference's optimizer skips `grad is None`, diffGradNorm.py:54-55):
         # their weight-gradient launches are not recorded and whatever fused kernels still produce for them lands in a
@@ -280,6 +294,11 @@ class Plan:
             return None
         flops = spec.get("flops_override", flops)
         kname = halo_tile(spec["cout"], spec["OH"], spec["OW"], self.B) if halo else igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B)
+        if halo and persistent_conv3(spec, self.B):
+            c = spec["cout"]
+            rest = c % 128
+            kname = "k_conv3x3p<2>" if c <= 64 else "k_conv3x3p<3>" if c <= 96 else "k_conv3x3p<4>" + ("" if rest == 0 or rest > 64 else
+                                                                                                 "+k_conv3x3<4,1,2,1>" if rest <= 32 else "+k_conv3x3<4,1,2,2>")
         meta = {"kernel": kname, "flops": flops,
                 "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
                          f"out{spec['OH']}x{spec['OW']}"}
@@ -387,6 +406,12 @@ class Plan:
             res = sp["res"]
             d.res, d.res_ld, d.res_scale = P(res), (res.ld if res is not None else 0), P(sp["res_scale"])
             d.accumulate, d.stats = sp["accumulate"], P(sp["stats"])
+            if sp.get("stats") is not None and persistent_conv3(sp, self.B):
+                # GroupNorm sums of the persistent 3x3 kernel: per-(tile, wave) partial rows + a finalize launch
+                need = self.B * -(-sp["OH"] * sp["OW"] // 64) * (sp["cout"] // 16) * 2
+                if self.stats_scratch is None or self.stats_scratch.numel() < need:
+                    self.stats_scratch = self.new((need,), F32)      # produced and consumed inside one crd_conv_igemm call
+                d.stats_partial, d.stats_partial_capacity = self.stats_scratch.data_ptr(), self.stats_scratch.numel()
             d.chan_sums = P(sp.get("chan"))
             if sp.get("red") is not None:        # fused reduce phase of the GroupNorm backward this output feeds
                 rx, rstats, rgamma, rbeta, rgmul, ract, rr = sp["red"]

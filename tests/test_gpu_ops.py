@@ -657,6 +657,49 @@ def test_weight_pack_and_unpack():
     assert_close(dd.cpu(), 1 + src[:, :, :Ci].permute(0, 2, 1), "unpack", rel=1e-6, elem=1e-6)
 
 
+@pytest.mark.parametrize("Co,Ci,Cp,k,f32", [(64, 64, 64, 8, 0), (64, 7, 8, 7, 0), (1024, 128, 128, 1, 0), (128, 289, 304, 3, 0), (1, 640, 640, 3, 1),
+                                            (160, 160, 160, 2, 0), (21, 128, 128, 3, 0)])
+def test_weight_pack_shapes(Co, Ci, Cp, k, f32):
+    """Every tap count / padding / layout the plan requests in ONE table launch: 8x8 and 7x7 patches, pointwise, a padded
+    3x3 concat input, the depthwise fp32 [tap][channel] form; two entries per launch (table indexing)."""
+    lib, lb = L()
+    g = torch.Generator().manual_seed(Co + Ci)
+    taps = k * k
+    Cop = (Co + 7) // 8 * 8
+    entries, keep, refs = [], [], []
+    for rep in range(2):
+        if f32:
+            w = torch.randn(Ci, 1, k, k, generator=g)          # depthwise: [hid][1][3][3], one "output channel" in the table
+            wr = w.reshape(1, Ci, taps)
+        else:
+            w = torch.randn(Co, Ci, k, k, generator=g)
+            wr = w.reshape(Co, Ci, taps)
+        ref = torch.zeros(wr.shape[0], taps, Cp)
+        ref[:, :, :Ci] = wr.permute(0, 2, 1)
+        wd = w.cuda()
+        fwd = torch.full((wr.shape[0], taps, Cp), 7.0, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
+        dg = torch.full((Cp, taps, Cop), 7.0, dtype=torch.bfloat16, device="cuda")
+        sc = torch.full((taps, Cp, Cop), 7.0, dtype=torch.bfloat16, device="cuda")
+        e = lib.PackEntry()
+        e.src, e.dst_fwd = P(wd), P(fwd)
+        if not f32:
+            e.dst_dgrad, e.dst_scatter = P(dg), P(sc)
+        e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = wr.shape[0], Ci, taps, Cp, Cop, f32
+        entries.append(e)
+        keep.append((wd, fwd, dg, sc))
+        refs.append(ref)
+    tab = torch.frombuffer(bytearray(b"".join(bytes(e) for e in entries)), dtype=torch.uint8).cuda()
+    ok(lb.crd_weight_pack(P(tab), 2, max(Co * taps * Cp, Cp * taps * Cop), lib.stream()), "weight_pack")
+    torch.cuda.synchronize()
+    for (wd, fwd, dg, sc), ref in zip(keep, refs):
+        assert torch.equal(fwd.float().cpu(), ref if f32 else bf(ref))
+        if not f32:
+            refd = torch.zeros(Cp, taps, Cop)
+            refd[:, :, :Co] = ref.permute(2, 1, 0)
+            assert torch.equal(dg.float().cpu(), bf(refd))
+            assert torch.equal(sc.float().cpu(), bf(refd.permute(1, 0, 2)))
+
+
 def test_depth_metrics_match_reference_golden():
     """crd_test_metrics (device-side Trainer.test metrics) against the reference's golden values and the CPU oracle."""
     from camradepth_amd import synth

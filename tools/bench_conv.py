@@ -19,6 +19,10 @@ d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = w.data_ptr(), Cout, 3, 3,
 d.gather_mode = mode
 d.y, d.y_ld, d.y_coff, d.y_f32 = y.data_ptr(), Cout, 0, 0
 d.stats = stats.data_ptr() if len(sys.argv) <= 3 else None
+partial = torch.zeros(B * (-(-H * W // 64)) * (Cout // 16) * 2, device="cuda")
+if d.stats:
+    d.stats_partial, d.stats_partial_capacity = partial.data_ptr(), partial.numel()
+d.accumulate = int(os.environ.get("ACC", 0))
 for _ in range(3):
     lib.check(L.crd_conv_igemm(C.byref(d), lib.stream()), "conv")
 torch.cuda.synchronize()
@@ -38,3 +42,11 @@ if hasattr(L, "crd_dbg_conv3_prof"):      # library built with -DCRD_CONV3_PROF 
     names = ["dma issue", "reads k0", "mfma k0", "reads k1", "mfma k1", "vm wait", "barrier"]
     for w in range(4):
         print(f"  wave {w}: " + "  ".join(f"{n} {buf[w * 8 + k] / steps:5.0f}" for k, n in enumerate(names)) + "  (cycles per step)")
+
+if hasattr(L, "crd_dbg_conv3p_prof"):     # persistent kernel built with -DCRD_CONV3_PROF
+    buf = (C.c_ulonglong * 4)()
+    L.crd_dbg_conv3p_prof(buf, 1)
+    L.crd_conv_igemm(C.byref(d), lib.stream()); torch.cuda.synchronize()
+    L.crd_dbg_conv3p_prof(buf, 0)
+    n = max(buf[2], 1)
+    print(f"  persistent kernel, wave 0 of workgroup 0: {buf[2]} tiles, main loop {buf[0] / n:.0f} cycles / tile, epilogue {buf[1] / n:.0f} cycles / tile")

@@ -32,11 +32,11 @@ constexpr int TH = 16, TW = 32;            // output tile (pixels)
 constexpr int HW_ = TW + 2;                // halo width
 constexpr int HROWS = (TH + 2) * HW_;      // 612 halo pixels
 constexpr int QK = 32;                     // channels per chunk: 64-byte LDS rows
-constexpr int NW = 4;                      // waves
 constexpr int HG = (HROWS + 15) / 16;      // 39 halo DMA pieces (16 rows x 64 B)
 constexpr int HPAD = HG * 16;              // 624 rows allocated per halo buffer
-constexpr int HT = (HG + NW - 1) / NW;     // 10 pieces per wave
-constexpr int TM = 4;                      // 32-pixel row tiles per wave (rows 4 w .. 4 w + 3 of the tile)
+// NW waves per workgroup (template parameter): 4 = one wave per SIMD with the whole register file (TM = 4 row tiles of 32
+// pixels per wave), 8 = two waves per SIMD at 256 registers each (TM = 2): the second wave's MFMAs fill the issue slots the
+// first one spends on DMA requests, fragment reads and waits.
 
 typedef __attribute__((address_space(3))) void* lds_ptr;
 
@@ -56,8 +56,10 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 __device__ unsigned long long g_profp[4];
 #endif
 
-template <int TN, int MODE, int WS>
-__global__ __launch_bounds__(256, 1) void k_conv3x3p(ConvK a, int tiles_x, int tiles_y, int tiles_total) {
+template <int TN, int MODE, int WS, int NW>
+__global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles_x, int tiles_y, int tiles_total) {
+  constexpr int TM = TH / NW;                     // 32-pixel row tiles per wave (rows TM w .. TM w + TM - 1 of the tile)
+  constexpr int HT = (HG + NW - 1) / NW;          // halo pieces per wave
   constexpr int D = WS - 1;
   static_assert(D >= 2 && D <= 8, "slab prefetch distance");
   constexpr int BN = TN * 32;
@@ -396,7 +398,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3p(ConvK a, int tiles_x, int t
   wait_vm<0>();
 }
 
-template <int TN, int WS>
+template <int TN, int WS, int NW>
 int launch_p(const ConvK& k0, int B, hipStream_t st, int col0, int col1) {
   constexpr int BN = TN * 32;
   ConvK k = k0;
@@ -411,18 +413,23 @@ int launch_p(const ConvK& k0, int B, hipStream_t st, int col0, int col1) {
   static bool attr_done[2] = {false, false};
   const int m = k.gather_mode == 0 ? 0 : 1;
   if (m == 0) {
-    if (!attr_done[0]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 0, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
-    hipLaunchKernelGGL((k_conv3x3p<TN, 0, WS>), dim3(gx, gy), dim3(256), lds, st, k, tiles_x, tiles_y, tiles_total);
+    if (!attr_done[0]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 0, WS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+    hipLaunchKernelGGL((k_conv3x3p<TN, 0, WS, NW>), dim3(gx, gy), dim3(64 * NW), lds, st, k, tiles_x, tiles_y, tiles_total);
   } else {
-    if (!attr_done[1]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 1, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
-    hipLaunchKernelGGL((k_conv3x3p<TN, 1, WS>), dim3(gx, gy), dim3(256), lds, st, k, tiles_x, tiles_y, tiles_total);
+    if (!attr_done[1]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 1, WS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+    hipLaunchKernelGGL((k_conv3x3p<TN, 1, WS, NW>), dim3(gx, gy), dim3(64 * NW), lds, st, k, tiles_x, tiles_y, tiles_total);
   }
   CRD_LAUNCH_CHECK("crd_conv_igemm(3x3 persistent)");
   return CRD_OK;
 }
 
 // rows of GroupNorm partial sums a launch writes per image (crd_conv_desc.stats_partial must hold B x rows x Cout/16 x 2 floats)
-inline long long partial_rows(const ConvK& k) { return (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * NW; }
+int waves_per_wg() {
+  static int nw = -1;
+  if (nw < 0) { const char* e = getenv("CRD_CONV3P_WAVES"); nw = (e && atoi(e) == 4) ? 4 : 8; }
+  return nw;
+}
+inline long long partial_rows(const ConvK& k) { return (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * waves_per_wg(); }
 
 }  // namespace
 
@@ -454,7 +461,12 @@ int crd_conv3x3p_finalize(const ConvK& k, int B, hipStream_t st) {
 
 // Output columns [col0, col1) in tiles of TN x 32 (col1 - col0 a multiple of the tile except for a masked last tile)
 int crd_conv3x3p(const ConvK& k, int B, hipStream_t st, int col0, int col1, int tn) {
-  if (tn == 4) return launch_p<4, 5>(k, B, st, col0, col1);
-  if (tn == 3) return launch_p<3, 5>(k, B, st, col0, col1);
-  return launch_p<2, 5>(k, B, st, col0, col1);
+  if (waves_per_wg() == 4) {
+    if (tn == 4) return launch_p<4, 5, 4>(k, B, st, col0, col1);
+    if (tn == 3) return launch_p<3, 5, 4>(k, B, st, col0, col1);
+    return launch_p<2, 5, 4>(k, B, st, col0, col1);
+  }
+  if (tn == 4) return launch_p<4, 5, 8>(k, B, st, col0, col1);
+  if (tn == 3) return launch_p<3, 5, 8>(k, B, st, col0, col1);
+  return launch_p<2, 5, 8>(k, B, st, col0, col1);
 }

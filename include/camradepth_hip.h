@@ -116,6 +116,25 @@ int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stre
  * Not needed for correctness -- the tests use it to reach every tile configuration with small inputs. */
 int crd_tune_conv3x3_small_grid(int workgroups);
 
+/* ---- fp8 (OCP e4m3) inference path of the decoder's 3x3 ConvLayers (BASELINE.json config 5) ------------------------------
+ * y = bf16( x_scale * w_scales[co] * sum_k x8[k] * w8[co][k] ) on the block-scaled MFMA (all block scales 2^0) at twice the
+ * bf16 matrix rate.  d as for crd_conv_igemm with x = fp8 activations [B][IH*IW][x_ld] (1 byte per channel, Cin / x_ld /
+ * x_coff multiples of 16) and w = fp8 weights [Cout][9][Cin]; 3x3 / stride 1 / pad 1 forward, plain bf16 output, optional
+ * GroupNorm sums (stats + a stats_partial buffer of B x ceil(W/32) x ceil(H/16) x 4 x Cout/16 x 2 floats).  No reference
+ * counterpart: the reference computes these convolutions under fp16 autocast (runner.py:191). */
+int crd_conv3x3_fp8(const crd_conv_desc* d, const float* w_scales, float x_scale, crd_stream_t stream);
+/* amax[0] = max(amax[0], max |x|) over channels [coff, coff + C) of a pixel-major bf16 tensor (atomic max on the float's
+ * bits: amax must hold a non-negative float, e.g. 0).  Calibration of x_scale = amax / 448. */
+int crd_amax_bf16(const void* x, int64_t rows, int32_t ld, int32_t coff, int32_t C, float* amax, crd_stream_t stream);
+/* y[r][y_coff + c] = e4m3(clamp(x[r][coff + c] / scale, +-448)), round to nearest even; C, y_ld, y_coff multiples of 8 */
+int crd_quant_fp8(const void* x, int64_t rows, int32_t ld, int32_t coff, int32_t C, void* y, int32_t y_ld, int32_t y_coff,
+                  float scale, crd_stream_t stream);
+/* per output channel: scales[co] = max |w[co]| / 448 (1 for an all-zero row), w_fp8[co][tap][c] = e4m3(w[co][tap][c] / scales[co])
+ * for c < Cin and 0 for Cin <= c < Cin_out (crd_conv3x3_fp8 wants Cin_out % 16 == 0); w_bf16 is the packed forward weight
+ * [Cout][taps][Cin] */
+int crd_weight_quant_fp8(const void* w_bf16, int32_t Cout, int32_t taps, int32_t Cin, int32_t Cin_out, void* w_fp8, float* scales,
+                         crd_stream_t stream);
+
 /* Weight gradient of the same convolutions: dw[co][tap][ci] += sum_{b,oy,ox} dy[b,oy,ox,co] *
  * x[b, oy*s-p+ky, ox*s-p+kx, ci]  (fp32 atomics; caller zeroes dw).  Optionally also
  * dbias[co] += sum dy.  (autograd of the conv calls listed above.) */

@@ -49,6 +49,36 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 __device__ __forceinline__ float bf_round(float f) { return bf2f(f2bf(f)); }
+
+// An LDS-DMA request (16 bytes per lane, lane-linear at LDS byte address lds_addr) the compiler does not know about: for
+// kernels whose LDS reads are ds_read_tr builtins, in front of which the compiler would otherwise wait for every request in
+// flight.  rsrc = {base lo, base hi (48-bit address), bytes, 0x00020000}; m0 takes the LDS address (one wait state before
+// the DMA reads it).  Completion is the caller's counted s_waitcnt vmcnt + barrier, as with the builtin.
+typedef __attribute__((ext_vector_type(4))) int crd_rsrc_t;
+__device__ __forceinline__ crd_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = (unsigned long long)base;
+  crd_rsrc_t r = {(int)(unsigned)p, (int)(unsigned)((p >> 32) & 0xffffu), (int)bytes, 0x00020000};
+  r[0] = __builtin_amdgcn_readfirstlane(r[0]); r[1] = __builtin_amdgcn_readfirstlane(r[1]);
+  r[2] = __builtin_amdgcn_readfirstlane(r[2]);
+  return r;
+}
+__device__ __forceinline__ void lds_dma16(const crd_rsrc_t& rsrc, unsigned lds_addr, unsigned voff) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(__builtin_amdgcn_readfirstlane(lds_addr)), "v"(voff), "s"(rsrc) : "memory", "m0");
+}
+
+// Workgroup barrier for kernels that keep LDS-DMA requests (buffer_load ... lds) in flight across it.  __syncthreads()
+// is a workgroup-scope fence, which the compiler implements as s_waitcnt vmcnt(0) lgkmcnt(0) before s_barrier: every
+// request of an N-stage ring is drained at every step and the ring degenerates to one stage (found in the ISA of k_igemm:
+// the kernel's own counted s_waitcnt vmcnt(N) was followed by a vmcnt(0)).  This one waits for the wave's LDS accesses only
+// (the builtin, so that the compiler's own lgkmcnt bookkeeping sees it); what has to have landed is the caller's business
+// (counted s_waitcnt vmcnt).  The "memory" clobber keeps the compiler from moving LDS accesses across the barrier.
+// Two related traps: an LDS read through a HIP vector STRUCT (uint4, float4) or the ds_read_tr builtins makes the compiler
+// put s_waitcnt vmcnt(0) in front of it when LDS-DMA is in flight; reads through ext_vector_type pointers do not.
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0); vmcnt / expcnt untouched
+  asm volatile("s_barrier" ::: "memory");
+}
 // two fp32 -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32, round-to-nearest-even)
 typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;

@@ -99,9 +99,10 @@ __device__ __forceinline__ void transform(const ConvK& a, const GnIn& gi, const 
   if (a.KW > 1) { const int tap = kf / a.Cin; kc = kf - tap * a.Cin; ky = tap / a.KW; kx = tap - ky * a.KW; }
   float sc[8], sh[8];
   if (kok) {
-    const float4* tp = reinterpret_cast<const float4*>(tab + kc);
+    typedef __attribute__((ext_vector_type(4))) float f32x4t;
+    const f32x4t* tp = reinterpret_cast<const f32x4t*>(tab + kc);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { const float4 v = tp[j]; sc[2 * j] = v.x; sh[2 * j] = v.y; sc[2 * j + 1] = v.z; sh[2 * j + 1] = v.w; }
+    for (int j = 0; j < 4; ++j) { const f32x4t v = tp[j]; sc[2 * j] = v[0]; sh[2 * j] = v[1]; sc[2 * j + 1] = v[2]; sh[2 * j + 1] = v[3]; }
   } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) sc[j] = sh[j] = 0.f;
@@ -111,13 +112,16 @@ __device__ __forceinline__ void transform(const ConvK& a, const GnIn& gi, const 
     const int row = r0 + 32 * i, m = m0 + row;
     float v[8];
     if (XF32) {
-      const float4* p = reinterpret_cast<const float4*>(raw + row * T::ROW_BYTES + g * 32);
-      const float4 lo = p[0], hi = p[1];
-      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+      // (ext_vector_type reads: behind a float4 / uint4 struct load the compiler waits vmcnt(0) -- common.h, lds_barrier)
+      typedef __attribute__((ext_vector_type(4))) float f32x4v;
+      const f32x4v* p = reinterpret_cast<const f32x4v*>(raw + row * T::ROW_BYTES + g * 32);
+      const f32x4v lo = p[0], hi = p[1];
+      v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3]; v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
     } else {
-      const uint4 u = *reinterpret_cast<const uint4*>(raw + row * T::ROW_BYTES + g * 16);
-      v[0] = bf_lo(u.x); v[1] = bf_hi(u.x); v[2] = bf_lo(u.y); v[3] = bf_hi(u.y);
-      v[4] = bf_lo(u.z); v[5] = bf_hi(u.z); v[6] = bf_lo(u.w); v[7] = bf_hi(u.w);
+      typedef __attribute__((ext_vector_type(4))) unsigned u32x4v;
+      const u32x4v u = *reinterpret_cast<const u32x4v*>(raw + row * T::ROW_BYTES + g * 16);
+      v[0] = bf_lo(u[0]); v[1] = bf_hi(u[0]); v[2] = bf_lo(u[1]); v[3] = bf_hi(u[1]);
+      v[4] = bf_lo(u[2]); v[5] = bf_hi(u[2]); v[6] = bf_lo(u[3]); v[7] = bf_hi(u[3]);
     }
     const bool ok = kok && m < a.OHW;
 #pragma unroll
@@ -128,7 +132,8 @@ __device__ __forceinline__ void transform(const ConvK& a, const GnIn& gi, const 
     }
     uint4 q;
     q.x = pack_bf2(v[0], v[1]); q.y = pack_bf2(v[2], v[3]); q.z = pack_bf2(v[4], v[5]); q.w = pack_bf2(v[6], v[7]);
-    *reinterpret_cast<uint4*>(cooked + row * BK + (l & 7) * 8) = q;
+    typedef __attribute__((ext_vector_type(4))) unsigned u32x4c;
+    *reinterpret_cast<u32x4c*>(cooked + row * BK + (l & 7) * 8) = u32x4c{q.x, q.y, q.z, q.w};
     if (store_xn && ok) {
       const int oy = m / a.OW, ox = m - oy * a.OW;
       const long long pix = (long long)(oy * a.stride + ky) * a.IW + (ox * a.stride + kx);
@@ -234,13 +239,13 @@ __global__ __launch_bounds__(256) void k_gngemm_res(ConvK a, GnIn gi, int stage_
     init_acc<TM, TN, WN>(a, acc, b, n0, wn, l);
     for (int kt = 0; kt < nK; ++kt, ++s) {
       wait_vm<(NSB - 2) * (BN / 32)>();               // weight step s has landed (this thread's share) ...
-      __syncthreads();                                // ... everyone's; cooked rows / the previous step's slot are settled
+      lds_barrier();                                  // ... everyone's; cooked rows / the previous step's slot are settled
       const int sn = s + NSB - 1;
       dma_w<BN>(a, rw, (chunk0 + sn / nK) * BN, sn % nK, sB + (sn % NSB) * BN * BK, wv, l, r0);
       mfma_slab<TM, TN, WM, WN>(cooked + kt * BM * BK, sB + (s % NSB) * BN * BK, acc, wm, wn, l);
     }
     // epilogue of this chunk in the staging area (the raw slabs' space); in-flight weight DMAs target the ring, not it
-    __syncthreads();
+    lds_barrier();
     if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(a.y)[0] = 1.f; continue; }
     conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
                                   [&](int i, int rr, bool& valid, int& row) { row = m0 + (wm * TM + i) * 32 + rr; valid = row < a.OHW; },
@@ -285,12 +290,12 @@ __global__ __launch_bounds__(256) void k_gngemm_str(ConvK a, GnIn gi) {
   f32x16 acc[TM][TN];
   init_acc<TM, TN, WN>(a, acc, b, n0, wn, l);
   wait_vm<(NS - 2) * PER>();                          // slab 0 has landed
-  __syncthreads();                                    // ... everyone's share, and the table
+  lds_barrier();                                      // ... everyone's share, and the table
   transform<BM, 0, ACT>(a, gi, tab, b, m0, 0, raw, cooked, store_xn, r0, l);
   for (int kt = 0; kt < nK; ++kt) {
     // slabs issued: 0 .. kt+NS-2.  Slab kt+1 (transformed below) must have landed: NS-3 later slabs may be in flight.
     wait_vm<(NS - 3) * PER>();
-    __syncthreads();       // cooked[kt&1] complete; MFMAs of kt-1 done with cooked[(kt-1)&1] and ring slot (kt-1)%NS
+    lds_barrier();         // cooked[kt&1] complete; MFMAs of kt-1 done with cooked[(kt-1)&1] and ring slot (kt-1)%NS
     stage(kt + NS - 1);
     if (kt + 1 < nK)
       transform<BM, 0, ACT>(a, gi, tab, b, m0, kt + 1, raw + ((kt + 1) % NS) * T::SLAB_BYTES, cooked + ((kt + 1) & 1) * BM * BK, store_xn, r0, l);

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
   int cur = 0, nxt = NST - 1;
   for (int kt = 0; kt < nK; ++kt) {
     wait_vm<(NST - 2) * PER>();             // this thread's share of slab kt has landed ...
-    __syncthreads();                        // ... everyone's has, and everyone is done reading slab kt-1
+    lds_barrier();                          // ... everyone's has, and everyone is done reading slab kt-1 (NOT __syncthreads: common.h)
     stage(nxt);                             // refill slab kt-1's buffer under this slab's MFMAs
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {

@@ -121,10 +121,9 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
     const int sx = (int)(strip - (long long)b * a.strips_x);
     const int x0 = sx * 32;
     // one buffer descriptor per image: byte offsets stay below 2^31 whatever the batch (4 x 928 x 1600 x 304 channels is 3.6 GB)
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (long long)b * a.H * a.W * a.x_ld), 0,
-                                                                        (int)a.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(a.dy + (long long)b * a.H * a.W * a.dy_ld), 0,
-                                                                        (int)a.dy_bytes, 0x00020000);
+    // (requests through lds_dma16, common.h: with the builtin the compiler drains the rings in front of every step's reads)
+    const crd_rsrc_t rx = make_rsrc(a.x + (long long)b * a.H * a.W * a.x_ld, (unsigned)a.x_bytes);
+    const crd_rsrc_t ry = make_rsrc(a.dy + (long long)b * a.H * a.W * a.dy_ld, (unsigned)a.dy_bytes);
 
     auto issue_x = [&](int h) {                  // input row h (image coords) -> ring slot (h + 1) % XS
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -132,7 +131,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
         const int ix = x0 - 1 + xpix, ch = c0 + ((((xgr >> 1) ^ swz128(xpix)) << 1) | (xgr & 1)) * 8;
         const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && xpix < 34 && ch < a.Cin;
         const unsigned off = ok ? (unsigned)((((long long)h * a.W + ix) * a.x_ld + ch) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr)(sX + (((h + 1) % XS) * XPX + 8 * wv) * XLD), 16, off, 0, 0, 0);
+        lds_dma16(rx, (unsigned)(uintptr_t)(lds_ptr)(sX + (((h + 1) % XS) * XPX + 8 * wv) * XLD), off);
       }
 #else
       (void)h;
@@ -144,7 +143,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
         const int ix = x0 + ypix, co = ((((ygr >> 1) ^ swz_y<COT>(ypix)) << 1) | (ygr & 1)) * 8;
         const bool ok = r < y1 && ix < a.W && co < a.Cout;
         const unsigned off = ok ? (unsigned)((((long long)r * a.W + ix) * a.dy_ld + co) * 2) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ry, (lds_ptr)(sY + (r % YS) * 32 * COT + 512 * wv), 16, off, 0, 0, 0);
+        lds_dma16(ry, (unsigned)(uintptr_t)(lds_ptr)(sY + (r % YS) * 32 * COT + 512 * wv), off);
       }
 #else
       (void)r;

@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--inference", action="store_true",
                     help="SURVEY 8f N4: eval-mode forward only, replayed from one HIP graph (e.g. --batch 1 --height 416 --width 800)")
+    ap.add_argument("--fp8", action="store_true",
+                    help="with --inference: BASELINE config 5 -- the ConvLayers of the two largest decoder stages on the fp8 "
+                         "(e4m3) MFMA, activation scales calibrated on the bench batch (model.calibrate_fp8)")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -224,11 +227,16 @@ def main():
     model = CamRaDepth(input_channels=7, supervised_seg=sup, seed=0).cuda()      # same init on every rank
     if a.inference:       # the reference's own "runtime" figure (Trainer.test(), runner.py:417-420), without its missing device sync
         batch = synth.make_batch(a.batch, a.height, a.width, seed=1234)
+        scales = model.calibrate_fp8(batch["image"].cuda()) if a.fp8 else None
         r = forward_only(model, batch, a.batch, a.height, a.width, a.variant, reps=max(a.steps, 10))
-        print(json.dumps({"metric": "inference frames/sec (eval forward, HIP graph)", "value": r["images_per_s"], "unit": "images/s",
-                          "n_gpus": 1, "ms_per_forward": r["ms"], "higher_is_better": True, "dtype": "bf16", "data": "synthetic",
-                          "config": {"workload": f"CamRaDepth {a.variant} eval forward, {a.batch}x7x{a.height}x{a.width}"},
-                          "mfma_frac": r["mfma_frac"]}), flush=True)
+        line = {"metric": "inference frames/sec (eval forward, HIP graph)", "value": r["images_per_s"], "unit": "images/s",
+                "n_gpus": 1, "ms_per_forward": r["ms"], "higher_is_better": True, "dtype": "fp8" if a.fp8 else "bf16", "data": "synthetic",
+                "config": {"workload": f"CamRaDepth {a.variant} eval forward, {a.batch}x7x{a.height}x{a.width}"
+                                       + (", decoder stages 3-4 ConvLayers in e4m3" if a.fp8 else "")},
+                "mfma_frac": r["mfma_frac"]}        # (fraction of the bf16 peak in both cases: the flops are the same)
+        if scales:
+            line["fp8_activation_scales"] = {str(k): v for k, v in scales.items()}
+        print(json.dumps(line), flush=True)
         return
     model.train()
     if a.freeze_seg:

@@ -148,6 +148,23 @@ __device__ __forceinline__ void store8_bf16(void* base, int64_t elem_off, const 
   u.x = pack_bf2(v[0], v[1]); u.y = pack_bf2(v[2], v[3]); u.z = pack_bf2(v[4], v[5]); u.w = pack_bf2(v[6], v[7]);
   *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(base) + elem_off) = u;
 }
+// OCP e4m3 (gfx950's fp8): saturating conversion, round to nearest even
+constexpr float E4M3_MAX = 448.f;
+__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
+  a = fminf(fmaxf(a, -E4M3_MAX), E4M3_MAX); b = fminf(fmaxf(b, -E4M3_MAX), E4M3_MAX);
+  c = fminf(fmaxf(c, -E4M3_MAX), E4M3_MAX); d = fminf(fmaxf(d, -E4M3_MAX), E4M3_MAX);
+  int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);       // bytes 0, 1
+  p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);            // bytes 2, 3
+  return (unsigned)p;
+}
+// the fp8 copy of a bf16 tensor: e4m3(bf16(v) * inv_scale) -- rounded to bf16 first, so that it IS the quantised bf16 value
+// whichever kernel (crd_quant_fp8 on the stored tensor, or a producer's fused fp8 output) wrote it
+__device__ __forceinline__ void store8_fp8(void* base, int64_t elem_off, const float (&v)[8], float inv_scale) {
+  uint2 q;
+  q.x = pack_fp8x4(bf_round(v[0]) * inv_scale, bf_round(v[1]) * inv_scale, bf_round(v[2]) * inv_scale, bf_round(v[3]) * inv_scale);
+  q.y = pack_fp8x4(bf_round(v[4]) * inv_scale, bf_round(v[5]) * inv_scale, bf_round(v[6]) * inv_scale, bf_round(v[7]) * inv_scale);
+  *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(base) + elem_off) = q;
+}
 __device__ __forceinline__ void store8_f32(float* base, int64_t elem_off, const float (&v)[8]) {
   float4* p = reinterpret_cast<float4*>(base + elem_off);
   p[0] = make_float4(v[0], v[1], v[2], v[3]);

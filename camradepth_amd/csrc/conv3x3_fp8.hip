@@ -332,15 +332,6 @@ int launch8(const F8K& k, int B, hipStream_t st) {
 }
 
 // ---- quantisation helpers -------------------------------------------------------------------------------------------
-constexpr float E4M3_MAX = 448.f;
-__device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float d) {
-  a = fminf(fmaxf(a, -E4M3_MAX), E4M3_MAX); b = fminf(fmaxf(b, -E4M3_MAX), E4M3_MAX);
-  c = fminf(fmaxf(c, -E4M3_MAX), E4M3_MAX); d = fminf(fmaxf(d, -E4M3_MAX), E4M3_MAX);
-  int p = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);       // bytes 0, 1
-  p = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, p, true);            // bytes 2, 3
-  return (unsigned)p;
-}
-
 // amax over a channel slice of a pixel-major bf16 tensor -> atomicMax on the (non-negative) float's bit pattern
 __global__ __launch_bounds__(256) void k_amax_bf16(const bf16_t* x, long long rows, int ld, int C, unsigned* out) {
   const int CG = C >> 3;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(TPB) void k_attn_out_residual_stats(const float* x,
 template <int XF, int YF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
                                                   const float* stats, int gmul, const float* gamma, const float* beta,
-                                                  int act, const float* mask, void* y, int y_ld, int y_f32) {
+                                                  int act, const float* mask, void* y, int y_ld, int y_f32, float y_inv_scale) {
   const int b = blockIdx.y;
   Map m(C);
   if (!m.active) return;
@@ -185,7 +185,8 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
           if (ACT == 1) w = gelu_exact(w);
           v[u][j] = w * mk[j];
         }
-        if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, v[u]);
+        if (YF == 2) store8_fp8(y, ((long long)b * P + pp) * y_ld + c0, v[u], y_inv_scale);      // YF: 0 bf16, 1 fp32, 2 e4m3
+        else if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, v[u]);
         else store8_bf16(y, ((long long)b * P + pp) * y_ld + c0, v[u]);
       }
     }
@@ -486,7 +487,7 @@ extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   void* yp = y_f32 ? (void*)(reinterpret_cast<float*>(y) + y_coff) : (void*)(reinterpret_cast<bf16_t*>(y) + y_coff);
 #define CRD_GN_APPLY(XF, YF, ACT)                                                                                        \
   hipLaunchKernelGGL((k_gn_apply<XF, YF, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
-                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, y_f32)
+                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, y_f32, 1.f)
   const int key = (x_f32 ? 4 : 0) | (y_f32 ? 2 : 0) | (act ? 1 : 0);
   switch (key) {
     case 0: CRD_GN_APPLY(0, 0, 0); break;  case 1: CRD_GN_APPLY(0, 0, 1); break;
@@ -496,6 +497,27 @@ extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   }
 #undef CRD_GN_APPLY
   CRD_LAUNCH_CHECK("crd_gn_apply");
+  return CRD_OK;
+}
+
+extern "C" int crd_gn_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
+                                const float* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
+                                const float* mask, void* y_fp8, int32_t y_ld, int32_t y_coff, float y_scale, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && stats && gamma && beta && y_fp8 && y_scale > 0.f, "crd_gn_apply_fp8: null pointer / bad scale");
+  CRD_CHECK_ARG(gmul >= 1 && (C / 16) % gmul == 0, "crd_gn_apply_fp8: bad gmul %d for C=%d", gmul, C);
+  CRD_CHECK_ARG(y_ld % 8 == 0 && y_coff % 8 == 0, "crd_gn_apply_fp8: y_ld/y_coff must be multiples of 8");
+  int rc = check_common("crd_gn_apply_fp8", x_ld, x_coff, C, x_f32);
+  if (rc) return rc;
+  dim3 grid; int chunk;
+  grid_for(P, C, B, grid, chunk);
+  void* yp = reinterpret_cast<unsigned char*>(y_fp8) + y_coff;
+#define CRD_GN_APPLY8(XF, ACT)                                                                                           \
+  hipLaunchKernelGGL((k_gn_apply<XF, 2, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
+                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, 0, 1.f / y_scale)
+  if (x_f32) { if (act) CRD_GN_APPLY8(1, 1); else CRD_GN_APPLY8(1, 0); }
+  else { if (act) CRD_GN_APPLY8(0, 1); else CRD_GN_APPLY8(0, 0); }
+#undef CRD_GN_APPLY8
+  CRD_LAUNCH_CHECK("crd_gn_apply_fp8");
   return CRD_OK;
 }
 

@@ -195,6 +195,11 @@ class Plan:
         self.need_grad = bool(getattr(model, "_need_grad", True))
         self.frozen = frozenset(n for n in model._names if not model._param(n).requires_grad)
         self._dump = {}
+        # fp8 (e4m3) forward of the big decoder ConvLayers (BASELINE.json config 5): inference plans only, with the
+        # per-stage activation scales of model.calibrate_fp8(); {decoder stage: scale of its concat buffer}
+        f8 = getattr(model, "fp8_scales", None)
+        self.fp8 = dict(f8) if (f8 and not training and not self.need_grad) else None
+        self.fp8_convs = []
         self._build()
 
     # ------------------------------------------------------------------ allocation helpers
@@ -378,6 +383,18 @@ class Plan:
             n.xn, n.xn_ld = (P(sp["xn"]), sp["xn"].ld) if sp["xn"] is not None else (None, 0)
             self.keep.append(n)
             return C.byref(n)
+        if sp.get("fp8"):
+            cw, y = sp["cw"], sp["y"]
+            d = L.ConvDesc()
+            d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = sp["x8"].data_ptr(), sp["x8_ld"], 0, self.B, sp["H"], sp["W"], sp["cin"]
+            d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = cw.w8.data_ptr(), cw.cout, 3, 3, 1, 1, sp["H"], sp["W"]
+            d.y, d.y_ld, d.y_coff = P(y), y.ld, y.coff
+            need = self.B * -(-sp["W"] // 32) * -(-sp["H"] // 16) * 4 * (cw.cout // 16) * 2
+            if self.stats_scratch is None or self.stats_scratch.numel() < need:
+                self.stats_scratch = self.new((need,), F32)
+            d.stats, d.stats_partial, d.stats_partial_capacity = P(sp["stats"]), self.stats_scratch.data_ptr(), self.stats_scratch.numel()
+            self.keep.append(d)
+            return C.byref(d)
         if sp.get("wg"):
             x, dy, cw = sp["x"], sp["dy"], sp["cw"]
             d = into if into is not None else L.WgradDesc()
@@ -476,7 +493,7 @@ class Plan:
         args += [dx2.t if dx2 is not None else None, dx2.ld if dx2 is not None else 0, scale2]
         self._emit(grp, "crd_gn_bwd_apply", args, region, acc_idx if region else None)
 
-    def conv_layer(self, name, x, k, out, mask=None, dout=None, dx=None, dx_region=None):
+    def conv_layer(self, name, x, k, out, mask=None, dout=None, dx=None, dx_region=None, x8=None, out8=None):
         """ConvLayer (utils.py:210-228): conv(no bias) -> GN(Cout/16) -> GELU [-> Dropout2d mask].
         x: input PM (Cin = x.C incl. padding, cmap given by caller through self._cmap), out: PM slice
         to write; dout: PM slice holding d(out); dx: PM slice receiving d(x)."""
@@ -484,8 +501,28 @@ class Plan:
         H, W = x.H, x.W
         raw = self.act(cw.cout, H, W)
         stats = self.zf(self.B, cw.cout // 16, 2)
-        self.conv(self.fwd, self.conv_desc(x, cw, cw.cout, k, 1, k // 2, H, W, raw, stats=stats))
-        self.gn_fwd(raw, stats, 1, name + ".model.1", 1, mask, out)
+        if x8 is not None:
+            # fp8 route (inference): e4m3 activations x8 = (tensor, ld, scale) covering the same channels as x, weights
+            # quantised per output channel after every weight pack (forward()), fp32 accumulation, bf16 raw output
+            assert k == 3 and dout is None and x.coff == 0
+            cin16 = rup(cw.cin_pad, 16)
+            cw.w8 = self.new((cw.cout, 9, cin16), torch.uint8)
+            cw.w8_scales = self.new((cw.cout,), F32)
+            self.fp8_convs.append((cw, cin16))
+            spec = dict(fp8=True, x8=x8[0], x8_ld=x8[1], cin=cin16, H=H, W=W, cw=cw, y=raw, stats=stats, cout=cw.cout)
+            meta = {"kernel": "k_conv3x3_fp8<%d>" % (2 if cw.cout <= 64 else 3 if cw.cout <= 96 else 4),
+                    "flops": 2.0 * self.B * H * W * cw.cout * cw.cin_ref * 9, "shape": f"fwd fp8 Cin{cin16} Cout{cw.cout} k3 s1 out{H}x{W}"}
+            self.fwd.append(Op(self.lib.crd_conv3x3_fp8, [spec, cw.w8_scales, float(x8[2])], "crd_conv3x3_fp8", meta=meta))
+        else:
+            self.conv(self.fwd, self.conv_desc(x, cw, cw.cout, k, 1, k // 2, H, W, raw, stats=stats))
+        if out8 is not None:       # the output feeds fp8 convolutions only: its e4m3 copy is all that is stored
+            op = self._emit(self.fwd, "crd_gn_apply_fp8", [raw.t, 0, raw.ld, raw.coff, self.B, raw.P, raw.C, stats, 1,
+                                                           self.p(name + ".model.1.weight"), self.p(name + ".model.1.bias"), 1, mask,
+                                                           out8[0], out8[1], out8[2], float(out8[3])])
+            op.meta = None
+            self.shapes[id(op)] = f"P{raw.P} C{raw.C} -> fp8"
+        else:
+            self.gn_fwd(raw, stats, 1, name + ".model.1", 1, mask, out)
         if dout is None:
             return
         grp = []
@@ -586,6 +623,7 @@ class Plan:
             dCB.append(self.act(ld, Hj, Wj))
             lay.append((up_p, sk_p))
         self._cmap = None
+        self.concat_buffers = CB
         E1, dE1 = self.act(d[3], *hs[0]), self.act(d[3], *hs[0])
         # gradient regions of encoder outputs: from_encoder dgrad stores (fp32), patch-embed dgrad accumulates
         self.conv_layer("from_encoder_1", enc_out_b[3], 1, E1, dout=dE1, dx=d_enc_out[3], dx_region=("dxs", 3, 0, d[3]))
@@ -610,8 +648,26 @@ class Plan:
             """Decoder stage (utils.py:249-257 + ShortResBlock :127-135) on concat buffer cb."""
             up_p, sk_p = lay[j]
             Hj, Wj = cb.H, cb.W
-            self._emit(self.fwd, "crd_bicubic2x", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb.t, cb.ld, 0])
             o0, o1 = up_p + sk_p, up_p + sk_p + 96
+            f8 = self.fp8 is not None and j in self.fp8 and -(-Wj // 32) * -(-Hj // 16) * B >= 192
+            if f8:
+                # the three ConvLayers read an e4m3 copy of the concat buffer (its own row stride, a multiple of 16 bytes);
+                # upsample and the first two GroupNorm+GELU write that copy directly, the skip channels are quantised
+                sc8 = float(self.fp8[j])
+                ld8 = rup(cb.ld, 16)
+                cb8 = self.new((B, Hj * Wj, ld8), torch.uint8)
+                self._emit(self.fwd, "crd_bicubic2x_fp8", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb8, ld8, 0, sc8])
+                if sk_p:
+                    self._emit(self.fwd, "crd_quant_fp8", [cb.t, B * Hj * Wj, cb.ld, up_p, sk_p, cb8, ld8, up_p, sc8])
+                self._cmap = cat_map(j, 0)
+                self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, None, x8=(cb8, ld8, sc8), out8=(cb8, ld8, o0, sc8))
+                self._cmap = cat_map(j, 1)
+                self.conv_layer(f"{name}.conv.layers.1", cb.sl(0, o1), 3, None, x8=(cb8, ld8, sc8), out8=(cb8, ld8, o1, sc8))
+                self._cmap = cat_map(j, 2)
+                self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, x8=(cb8, ld8, sc8))
+                self._cmap = None
+                return
+            self._emit(self.fwd, "crd_bicubic2x", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb.t, cb.ld, 0])
             grp = []
             args = [dcb.t, dcb.ld, 0, B, up_src.H, up_src.W, up_p, d_up_src.t, d_up_src.ld, d_up_src.coff, 0]
             self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
@@ -1151,6 +1207,9 @@ class Plan:
         st = L.stream()
         self.zf_arena.zero_()
         L.check(self.lib.crd_weight_pack(self.pack_table.data_ptr(), self.n_pack, self.max_pack, st), "crd_weight_pack")
+        for cw, cin16 in self.fp8_convs:
+            L.check(self.lib.crd_weight_quant_fp8(cw.w_fwd.data_ptr(), cw.cout, 9, cw.cin_pad, cin16, cw.w8.data_ptr(),
+                                                  cw.w8_scales.data_ptr(), st), "crd_weight_quant_fp8")
         if self.training and not getattr(self, "training_masks_fixed", False):
             if masks is not None:
                 self.dp_masks.copy_(torch.stack([t.to(self.dev, F32) for t in masks["drop_path"]]))

@@ -242,8 +242,41 @@ class CamRaDepth(nn.Module):
     def _plan_key(self, x):
         frozen = tuple(i for i, n in enumerate(self._names) if not self._param(n).requires_grad)
         from .engine import gn_conv_default
+        f8 = getattr(self, "fp8_scales", None)
         return (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None), frozen,
-                bool(getattr(self, "_need_grad", True)), gn_conv_default())
+                bool(getattr(self, "_need_grad", True)), gn_conv_default(), tuple(sorted(f8.items())) if f8 else None)
+
+    def calibrate_fp8(self, x, margin=1.0):
+        """Per-stage activation scales for the fp8 (e4m3) inference path of the two largest decoder stages (their ConvLayers are
+        ~80 % of the forward FLOPs): one bf16 eval forward of the calibration batch x, amax over each stage's concat buffer
+        (upsampled input | skip | the two intermediate ConvLayer outputs), scale = margin * amax / 448.  Sets self.fp8_scales
+        ({stage: scale}); inference plans built afterwards (InferenceGraph, forward under torch.no_grad in eval mode) take the
+        fp8 route, training plans never do.  calibrate_fp8(None) switches it off."""
+        if x is None:
+            self.__dict__["fp8_scales"] = None
+            return None
+        was_training, prev = self.training, getattr(self, "fp8_scales", None)
+        self.eval()
+        self.__dict__["fp8_scales"] = None
+        try:
+            with torch.no_grad():
+                self.forward(x)
+                plan = self._plans[self._plan_key(x)]
+            scales = {}
+            amax = torch.zeros(1, device=self.flat.device)
+            for j in (3, 4):
+                cb = plan.concat_buffers[j]
+                amax.zero_()
+                L.check(plan.lib.crd_amax_bf16(cb.t.data_ptr(), cb.t.shape[0] * cb.t.shape[1], cb.ld, 0, cb.ld, amax.data_ptr(),
+                                               L.stream()), "crd_amax_bf16")
+                scales[j] = max(float(amax), 1e-6) * margin / 448.0
+        except Exception:
+            self.__dict__["fp8_scales"] = prev
+            raise
+        finally:
+            self.train(was_training)
+        self.__dict__["fp8_scales"] = scales
+        return scales
 
     def forward(self, x, masks=None):
         """Returns the reference's nested dict (CamRaDepth.py:169-170).  `masks` optionally injects the

@@ -114,19 +114,40 @@ def encoder(sd, x, cfg, quant=None, masks=None, taps=None):
     return outs
 
 
-def conv_layer(sd, name, x, k, quant=None):
+E4M3_MAX = 448.0
+
+
+def _e4m3(t):
+    """Values representable in OCP fp8 e4m3 (gfx950's fp8): saturating, round to nearest even."""
+    return t.clamp(-E4M3_MAX, E4M3_MAX).to(torch.float8_e4m3fn).to(torch.float32)
+
+
+def _conv2d_fp8(x, w, x_scale, **kw):
+    """The fp8 inference convolution of BASELINE.json config 5 (not in the reference, which runs fp16 autocast): the bf16
+    activation tensor quantised per tensor (x / x_scale -> e4m3), the bf16 weights per output channel (scale = max|w| / 448,
+    1 for an all-zero row), fp32 accumulation of the e4m3 products, result * x_scale * w_scale[c] rounded to bf16."""
+    x_scale = torch.tensor(x_scale, dtype=torch.float32)
+    xq = _e4m3(_q(x, "bf16") * (1.0 / x_scale))
+    wb = _q(w, "bf16")
+    am = wb.abs().amax(dim=(1, 2, 3))
+    ws = torch.where(am > 0, am / E4M3_MAX, torch.ones_like(am))
+    wq = _e4m3(wb * (1.0 / ws).view(-1, 1, 1, 1))
+    return _q(F.conv2d(xq, wq, None, **kw) * (x_scale * ws).view(1, -1, 1, 1), "bf16")
+
+
+def conv_layer(sd, name, x, k, quant=None, fp8_scale=None):
     """ConvLayer.forward: conv(no bias) -> GroupNorm(Cout/16) -> GELU (reference: src/utils/utils.py:210-228)."""
     w = sd[name + ".model.0.weight"]
-    y = _conv2d(x, w, None, quant, padding=k // 2)
+    y = _conv2d_fp8(x, w, fp8_scale, padding=k // 2) if fp8_scale is not None else _conv2d(x, w, None, quant, padding=k // 2)
     return F.gelu(_gn(y, sd, name + ".model.1", w.shape[0] // GN_DIV))
 
 
-def short_res_block(sd, name, x, quant=None):
+def short_res_block(sd, name, x, quant=None, fp8_scale=None):
     """ShortResBlock.forward (reference: src/utils/utils.py:127-135)."""
     for li in range(2):
-        out = conv_layer(sd, f"{name}.layers.{li}", x, 3, quant)
+        out = conv_layer(sd, f"{name}.layers.{li}", x, 3, quant, fp8_scale)
         x = torch.cat((x, out), dim=1)
-    return conv_layer(sd, f"{name}.layers.2", x, 3, quant)
+    return conv_layer(sd, f"{name}.layers.2", x, 3, quant, fp8_scale)
 
 
 def bicubic2x(x):
@@ -134,12 +155,12 @@ def bicubic2x(x):
     return F.interpolate(x, scale_factor=2, mode="bicubic")
 
 
-def decoder_stage(sd, name, x, skip=None, quant=None):
+def decoder_stage(sd, name, x, skip=None, quant=None, fp8_scale=None):
     """Decoder.forward (reference: src/utils/utils.py:249-257)."""
     x = bicubic2x(x)
     if skip is not None:
         x = torch.cat((x, skip), dim=1)
-    return short_res_block(sd, name + ".conv", x, quant)
+    return short_res_block(sd, name + ".conv", x, quant, fp8_scale)
 
 
 def depth_activation(sd, name, x, quant=None):
@@ -154,12 +175,15 @@ def seg_block(logits, num_classes):
     return torch.argmax(logits, dim=1, keepdim=True) / num_classes
 
 
-def forward(sd, x, cfg, quant=None, masks=None, taps=None):
+def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
     """CamRaDepth.forward (reference: src/models/CamRaDepth.py:99-176).
 
     masks: None (eval) or the dict of synth.make_masks (train mode with injected Dropout2d /
     DropPath masks). Returns the reference's nested output dict.
+    fp8_scales: {3: s, 4: s} -- the ConvLayers of depth_upsample.3 / .4 as fp8 convolutions (_conv2d_fp8) with these
+    per-stage activation scales (what camradepth_amd's calibrate_fp8 returns); everything else as `quant` says.
     """
+    f8 = fp8_scales or {}
     d2 = iter(masks["dropout2d"]) if masks is not None else None
     drop = (lambda t: t) if masks is None else (lambda t: t * next(d2).view(t.shape[0], t.shape[1], 1, 1))
     outs = encoder(sd, x, cfg, quant, masks, taps)
@@ -175,7 +199,7 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None):
     s3 = drop(decoder_stage(sd, "depth_upsample.2", s2, e4, quant))
     d3 = depth_activation(sd, "depth_activation_3", s3, quant)
     s3 = torch.cat([s3, d3], 1)
-    s4 = drop(decoder_stage(sd, "depth_upsample.3", s3, None, quant))
+    s4 = drop(decoder_stage(sd, "depth_upsample.3", s3, None, quant, f8.get(3)))
     sup_map = unsup_map = seg_map = seg_feat = seg_final = None
     if cfg.supervised_seg or cfg.unsupervised_seg:
         seg_feat = drop(decoder_stage(sd, "seg_upsample.0", s3, None, quant))
@@ -194,7 +218,7 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None):
     tmp = torch.cat((s4, seg_map), dim=1) if seg_map is not None else s4
     d4 = depth_activation(sd, "depth_activation_4", tmp, quant)
     s4 = torch.cat([s4, d4], 1)
-    s5 = drop(decoder_stage(sd, "depth_upsample.4", s4, x, quant))
+    s5 = drop(decoder_stage(sd, "depth_upsample.4", s4, x, quant, f8.get(4)))
     if cfg.supervised_seg or cfg.unsupervised_seg:
         seg_feat = drop(decoder_stage(sd, "seg_upsample.1", seg_feat, x, quant))
     if cfg.supervised_seg:

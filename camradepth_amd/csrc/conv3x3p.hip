@@ -56,11 +56,27 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 __device__ unsigned long long g_profp[4];
 #endif
 
+#ifdef CRD_C3P_WCLASSIC        // experiment (see WCL below): measured the same as the LDS-DMA ring, 0.639 ms on 304 -> 128
+constexpr bool WCL = true;
+#else
+constexpr bool WCL = false;
+#endif
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4w;
+
 template <int TN, int MODE, int WS, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles_x, int tiles_y, int tiles_total) {
   constexpr int TM = TH / NW;                     // 32-pixel row tiles per wave (rows TM w .. TM w + TM - 1 of the tile)
   constexpr int HT = (HG + NW - 1) / NW;          // halo pieces per wave
-  constexpr int D = WS - 1;
+  // WCL: the weight slabs take the classic path -- buffer_load to registers (three steps ahead, three register sets used in
+  // turn: nine taps = 3 x 3), ds_write into one of TWO LDS slots a step before they are read -- and only the halo uses
+  // LDS-DMA.  An LDS-DMA instruction lands at ~16 B/clk per CU (64 lanes x 16 B in ~64 cycles; the request stream alone,
+  // with no reads and no MFMAs, takes 0.32 of this kernel's 0.64 ms on 304 -> 128) and the wave that issues it waits when
+  // that queue is full -- with its MFMAs behind it.  Two thirds of the requests were weight slabs.  Result: no change
+  // (0.639 ms either way, 19.7 ms/step either way), so the limit is not the DMA landing rate; the counters (profiles/
+  // r02_pmc_kernels.txt) show 64-byte L2 requests at ~305 cycles, the L1 miss queue stalled 40 % of the time and the
+  // waves 42 % of theirs in s_waitcnt.  Left in as -DCRD_C3P_WCLASSIC.
+  constexpr int D = WCL ? 3 : WS - 1;
+  constexpr int WSL = WCL ? 2 : WS;
   static_assert(D >= 2 && D <= 8, "slab prefetch distance");
   constexpr int BN = TN * 32;
   constexpr int WGROUPS = BN / 16;                // weight-slab DMA pieces (16 rows x 64 B)
@@ -86,20 +102,36 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
     const int g = NW * j + wv;
     const int n = 16 * g + (l >> 2), ng = n0 + n;
     wvo[j] = (g < WGROUPS && ng < a.Cout) ? (unsigned)((ng * a.Ktot + wch) * 2) : OOB;
+    if (ABL(8192)) wvo[j] = (unsigned)((n * QK + wch) * 2);     // timing experiment: every slab one contiguous 64 B x BN block
   }
+  u32x4w wq[3][WJ];                                   // WCL: slabs in flight (set = tap % 3)
   auto stage_weights = [&](int chunk, int tap, int slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int tail = Cin - chunk * QK;
     const bool lane_ok = wch < tail;
+    if (WCL) {                                        // slot = register set; every wave issues WJ loads (uniform wait counts)
+#pragma unroll
+      for (int j = 0; j < WJ; ++j)
+        wq[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane_ok ? wvo[j] : OOB, (tap * Cin + chunk * QK) * 2, 0);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const int g = NW * j + wv;
       bf16_t* dst = g < WGROUPS ? sW + slot * BN * QK + 16 * g * QK : sD;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, lane_ok ? wvo[j] : OOB, (tap * Cin + chunk * QK) * 2, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, lane_ok ? wvo[j] : OOB,
+                                               ABL(8192) ? (chunk * 9 + tap) * BN * QK * 2 : (tap * Cin + chunk * QK) * 2, 0, 0);
     }
 #else
     (void)chunk; (void)tap; (void)slot;
 #endif
+  };
+  auto commit_weights = [&](int set, int slot) {      // WCL: register set -> LDS slot (the lane-linear image the DMA would leave)
+#pragma unroll
+    for (int j = 0; j < WJ; ++j) {
+      const int g = NW * j + wv;
+      if (g < WGROUPS) *reinterpret_cast<u32x4w*>(sW + slot * BN * QK + 16 * g * QK + l * 8) = wq[set][j];
+    }
   };
 
   // halo pieces of one tile: lane l of piece G stages halo row 16 G + (l>>2), slot l&3 <- granule (l&3) ^ ((row>>2)&3)
@@ -107,14 +139,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
   auto halo_offsets = [&](int tile) {             // tile >= tiles_total: everything out of range (zero fill)
     const int bb = tile / (tiles_x * tiles_y), rem = tile - bb * (tiles_x * tiles_y);
     const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
+    int lh = l;                                       // opaque: the per-lane (hy, hx) of every piece must not be hoisted out of
+    asm volatile("" : "+v"(lh));                      // the tile loop (they get spilled, and a reload waits vmcnt(0))
 #pragma unroll
     for (int s = 0; s < HT; ++s) {
       const int G = NW * s + wv;
-      const int hr = 16 * G + (l >> 2);
+      const int hr = 16 * G + (lh >> 2);
       const int hy = hr / HW_, hx = hr - hy * HW_;
       const int iy = tyi * TH - 1 + hy, ix = txi * TW - 1 + hx;
       const bool ok = tile < tiles_total && G < HG && hr < HROWS && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      const int ch = ((l & 3) ^ ((hr >> 2) & 3)) * 8;
+      const int ch = ((lh & 3) ^ ((hr >> 2) & 3)) * 8;
       hvo[s] = ok ? (unsigned)(((iy * W + ix) * a.x_ld + ch) * 2) : OOB;
     }
     return bb;
@@ -180,6 +214,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
     if (++pt == 9) { pt = 0; if (++pc == nChunks) pc = 0; }
   }
   wait_vm<(D - 1) * WJ>();                            // halo + slab 0 have landed
+  if (WCL) { commit_weights(0, 0); __builtin_amdgcn_s_waitcnt(0xC07F); }
   asm volatile("s_barrier" ::: "memory");
   int gchunk = 0;                                     // chunks done so far (all tiles): parity = halo buffer
   int wb = 0, wnext = D % WS;
@@ -233,7 +268,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
           }
         }
         // ---- half-step 0: MFMAs on (a0, b0); in their shadow the slab request of step + D and the reads of half-step 1 ----
-        if (!ABL(256)) stage_weights(pc, pt, wnext);
+        if (!ABL(256)) stage_weights(pc, pt, WCL ? tap % 3 : wnext);
         if (++pt == 9) { pt = 0; if (++pc == nChunks) pc = 0; }
         if (!ABL(64)) read_frags(hb, tap, wb, 1, a1, b1);
         if (!ABL(128)) {
@@ -249,10 +284,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
         if (tap <= D - 2) wait_vm<(D - 1) * WJ + HT>();
         else wait_vm<(D - 1) * WJ>();
         }
+        const int wbn = wb + 1 == WSL ? 0 : wb + 1;
+        if (WCL && !ABL(256)) commit_weights((tap + 1) % 3, wbn);    // slab of step+1: read from the other slot after the barrier
         // (the builtin, not inline asm: the compiler's own lgkmcnt bookkeeping must see that nothing is pending here)
-        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): (a1, b1) have arrived, all of this wave's LDS reads are done
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): (a1, b1) have arrived, all of this wave's LDS accesses are done
         if (!ABL(32)) __builtin_amdgcn_s_barrier();
-        wb = wb + 1 == WS ? 0 : wb + 1;
+        wb = wbn;
         wnext = wnext + 1 == WS ? 0 : wnext + 1;
         // ---- half-step 1: MFMAs on (a1, b1); in their shadow the reads of the NEXT step's half-step 0 ----
         const int wrap = tap == 8;

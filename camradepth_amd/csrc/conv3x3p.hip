@@ -62,6 +62,10 @@ constexpr bool WCL = true;
 constexpr bool WCL = false;
 #endif
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4w;
+#ifndef CRD_C3P_WS
+#define CRD_C3P_WS 5
+#endif
+constexpr int C3P_WS = CRD_C3P_WS;                    // weight-slab ring slots (prefetch distance WS - 1 steps)
 
 template <int TN, int MODE, int WS, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles_x, int tiles_y, int tiles_total) {
@@ -499,11 +503,11 @@ int crd_conv3x3p_finalize(const ConvK& k, int B, hipStream_t st) {
 // Output columns [col0, col1) in tiles of TN x 32 (col1 - col0 a multiple of the tile except for a masked last tile)
 int crd_conv3x3p(const ConvK& k, int B, hipStream_t st, int col0, int col1, int tn) {
   if (waves_per_wg() == 4) {
-    if (tn == 4) return launch_p<4, 5, 4>(k, B, st, col0, col1);
-    if (tn == 3) return launch_p<3, 5, 4>(k, B, st, col0, col1);
-    return launch_p<2, 5, 4>(k, B, st, col0, col1);
+    if (tn == 4) return launch_p<4, C3P_WS, 4>(k, B, st, col0, col1);
+    if (tn == 3) return launch_p<3, C3P_WS, 4>(k, B, st, col0, col1);
+    return launch_p<2, C3P_WS, 4>(k, B, st, col0, col1);
   }
-  if (tn == 4) return launch_p<4, 5, 8>(k, B, st, col0, col1);
-  if (tn == 3) return launch_p<3, 5, 8>(k, B, st, col0, col1);
-  return launch_p<2, 5, 8>(k, B, st, col0, col1);
+  if (tn == 4) return launch_p<4, C3P_WS, 8>(k, B, st, col0, col1);
+  if (tn == 3) return launch_p<3, C3P_WS, 8>(k, B, st, col0, col1);
+  return launch_p<2, C3P_WS, 8>(k, B, st, col0, col1);
 }

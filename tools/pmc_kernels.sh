@@ -12,7 +12,6 @@ SETS=(
  "SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC"
  "TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TA_BUSY_avr"
  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum"
- "TA_BUFFER_READ_LDS_WAVEFRONTS_sum TA_BUFFER_READ_WAVEFRONTS_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
  "TCC_REQ_sum TCC_BUSY_avr TCC_TAG_STALL_sum TCP_TAGRAM0_REQ_sum"
 )
 : > $O/summary.txt
@@ -21,7 +20,7 @@ for prog in "tools/bench_conv.py 0 3" "tools/bench_wgrad.py"; do
   i=0
   for set in "${SETS[@]}"; do
     i=$((i+1))
-    rocprofv3 --pmc $set -d $O/p$i -o p --output-format csv -- python3 $prog > $O/p$i.log 2>&1
+    timeout 240 rocprofv3 --pmc $set -d $O/p$i -o p --output-format csv -- python3 $prog > $O/p$i.log 2>&1
     f=$(ls $O/p$i/*counter_collection.csv 2>/dev/null | head -1)
     python3 - "$f" >> $O/summary.txt <<'PY'
 import csv, sys, collections
@@ -31,7 +30,8 @@ agg = collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
     k = r["Kernel_Name"]
     if "k_conv3x3p" in k or "k_wgrad3x3" in k:
-        agg[(k.split("(")[0].replace("void (anonymous namespace)::", ""), r["Counter_Name"])].append(float(r["Counter_Value"]))
+        name = k.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+        agg[(name, r["Counter_Name"])].append(float(r["Counter_Value"]))
 for (k, c), v in sorted(agg.items()):
     print(f"   {k:34s} {c:40s} launches={len(v)} avg={sum(v)/len(v):.5g}")
 PY

@@ -405,7 +405,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
-              if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) *reinterpret_cast<uint4*>(row + j * 32 + pr * 16) = u[j][pr];
+              if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) {
+#ifdef CRD_C3P_NT_STORE
+                // (experiment: non-temporal output stores, so that the tile's 128 KB do not push the other half of the input
+                // lines out of L2 before the next chunk asks for it)
+                __builtin_nontemporal_store(u32x4w{u[j][pr].x, u[j][pr].y, u[j][pr].z, u[j][pr].w}, reinterpret_cast<u32x4w*>(row + j * 32 + pr * 16));
+#else
+                *reinterpret_cast<uint4*>(row + j * 32 + pr * 16) = u[j][pr];
+#endif
+              }
         }
       }
       __builtin_amdgcn_sched_barrier(0);

@@ -200,8 +200,8 @@ def main():
     ap.add_argument("--inference", action="store_true",
                     help="SURVEY 8f N4: eval-mode forward only, replayed from one HIP graph (e.g. --batch 1 --height 416 --width 800)")
     ap.add_argument("--fp8", action="store_true",
-                    help="with --inference: BASELINE config 5 -- the ConvLayers of the two largest decoder stages on the fp8 "
-                         "(e4m3) MFMA, activation scales calibrated on the bench batch (model.calibrate_fp8)")
+                    help="BASELINE config 5 -- the ConvLayers of the two largest decoder stages on the fp8 (e4m3) MFMA, activation "
+                         "scales calibrated on the bench batch (model.calibrate_fp8); in a training step: fp8 forward, bf16 backward")
     a = ap.parse_args()
 
     import torch.distributed as dist
@@ -239,6 +239,8 @@ def main():
         print(json.dumps(line), flush=True)
         return
     model.train()
+    if a.fp8:             # config 5 as a training step: fp8 forward convolutions in decoder stages 3-4, bf16 backward
+        model.calibrate_fp8(synth.make_batch(a.batch, a.height, a.width, seed=1234)["image"].cuda(), train=True)
     if a.freeze_seg:
         for n, p in model.named_parameters():
             if n.startswith("seg_"):
@@ -271,7 +273,7 @@ def main():
 
     out = {"metric": "training images/sec at 256x416 bf16", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "vs_baseline": None, "dtype": "fp8 forward (decoder stages 3-4) / bf16" if a.fp8 else "bf16", "data": "synthetic",
            "config": {"workload": f"CamRaDepth {a.variant}{' (seg branch frozen)' if a.freeze_seg else ''} (image+radar) train "
                                   f"{'iteration' if a.update_interval > 1 else 'step'}, {a.batch}x7x{a.height}x{a.width} per GPU, "
                                   f"bf16 MFMA / fp32 accumulate, diffGradNorm + OneCycleLR, Dropout2d/DropPath on"

@@ -25,9 +25,11 @@ __device__ __forceinline__ void taps_of(int o, int n, int (&idx)[4], float (&w)[
 // One thread produces the 2 x 2 outputs above input pixel (k, m) for 8 channels: they share the clamped 5 x 5 input
 // neighbourhood (25 loads instead of 4 x 16), horizontal pass first (even / odd column results of the five rows), then
 // the vertical one -- the same order of operations as the one-output-per-thread form it replaces.
-// F8: the output is the e4m3 copy (y = bytes, y_ld in bytes) of the bf16 result, scaled by inv_scale
+// F8 = 1: the output is the e4m3 copy (y = bytes, y_ld in bytes) of the bf16 result, scaled by inv_scale; 2: that and the
+// bf16 result itself (y2)
 template <int F8>
-__global__ __launch_bounds__(TPB) void k_bicubic(const bf16_t* x, int x_ld, int H, int W, int C, void* y, int y_ld, float inv_scale) {
+__global__ __launch_bounds__(TPB) void k_bicubic(const bf16_t* x, int x_ld, int H, int W, int C, void* y, int y_ld, float inv_scale,
+                                                 void* y2, int y2_ld) {
   const int b = blockIdx.y;
   const int CG = C >> 3;
   const int OW = 2 * W;
@@ -56,7 +58,6 @@ __global__ __launch_bounds__(TPB) void k_bicubic(const bf16_t* x, int x_ld, int 
 #pragma unroll
       for (int j = 0; j < 8; ++j) { he[r][j] += WE[t] * v[t][j]; ho[r][j] += WO[t] * v[t + 1][j]; }
   }
-  const long long ybase = ((long long)b * 2 * H * OW) * y_ld + cg * 8;
 #pragma unroll
   for (int oy = 0; oy < 2; ++oy)
 #pragma unroll
@@ -70,9 +71,10 @@ __global__ __launch_bounds__(TPB) void k_bicubic(const bf16_t* x, int x_ld, int 
 #pragma unroll
         for (int j = 0; j < 8; ++j) out[j] += wy * (ox ? ho[t + oy][j] : he[t + oy][j]);
       }
-      const long long yo = ybase + ((long long)(2 * k + oy) * OW + 2 * m + ox) * y_ld;
-      if (F8) store8_fp8(y, yo, out, inv_scale);
-      else store8_bf16(y, yo, out);
+      const long long opix = (long long)b * 2 * H * OW + (long long)(2 * k + oy) * OW + 2 * m + ox;
+      if (F8) store8_fp8(y, opix * y_ld + cg * 8, out, inv_scale);
+      else store8_bf16(y, opix * y_ld + cg * 8, out);
+      if (F8 == 2) store8_bf16(y2, opix * y2_ld + cg * 8, out);
     }
 }
 
@@ -519,19 +521,25 @@ extern "C" int crd_bicubic2x(const void* x, int32_t x_ld, int32_t x_coff, int32_
   CRD_CHECK_ARG(C % 8 == 0 && x_ld % 8 == 0 && x_coff % 8 == 0 && y_ld % 8 == 0 && y_coff % 8 == 0, "crd_bicubic2x: alignment");
   const long long total = 4ll * H * W * (C / 8);
   hipLaunchKernelGGL(k_bicubic<0>, dim3((unsigned)cdiv(total / 4, TPB), B), dim3(TPB), 0, as_stream(stream),
-                     reinterpret_cast<const bf16_t*>(x) + x_coff, x_ld, H, W, C, reinterpret_cast<bf16_t*>(y) + y_coff, y_ld, 1.f);
+                     reinterpret_cast<const bf16_t*>(x) + x_coff, x_ld, H, W, C, reinterpret_cast<bf16_t*>(y) + y_coff, y_ld, 1.f, nullptr, 0);
   CRD_LAUNCH_CHECK("crd_bicubic2x");
   return CRD_OK;
 }
 
 extern "C" int crd_bicubic2x_fp8(const void* x, int32_t x_ld, int32_t x_coff, int32_t B, int32_t H, int32_t W, int32_t C, void* y_fp8,
-                                 int32_t y_ld, int32_t y_coff, float y_scale, crd_stream_t stream) {
+                                 int32_t y_ld, int32_t y_coff, float y_scale, void* y_bf16, int32_t yb_ld, int32_t yb_coff,
+                                 crd_stream_t stream) {
   CRD_CHECK_ARG(x && y_fp8 && y_scale > 0.f, "crd_bicubic2x_fp8: null pointer / bad scale");
-  CRD_CHECK_ARG(C % 8 == 0 && x_ld % 8 == 0 && x_coff % 8 == 0 && y_ld % 8 == 0 && y_coff % 8 == 0, "crd_bicubic2x_fp8: alignment");
+  CRD_CHECK_ARG(C % 8 == 0 && x_ld % 8 == 0 && x_coff % 8 == 0 && y_ld % 8 == 0 && y_coff % 8 == 0 && yb_ld % 8 == 0 && yb_coff % 8 == 0,
+                "crd_bicubic2x_fp8: alignment");
   const long long total = 4ll * H * W * (C / 8);
-  hipLaunchKernelGGL(k_bicubic<1>, dim3((unsigned)cdiv(total / 4, TPB), B), dim3(TPB), 0, as_stream(stream),
-                     reinterpret_cast<const bf16_t*>(x) + x_coff, x_ld, H, W, C, reinterpret_cast<unsigned char*>(y_fp8) + y_coff, y_ld,
-                     1.f / y_scale);
+  const dim3 grid((unsigned)cdiv(total / 4, TPB), B);
+  if (y_bf16)
+    hipLaunchKernelGGL(k_bicubic<2>, grid, dim3(TPB), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(x) + x_coff, x_ld, H, W, C,
+                       reinterpret_cast<unsigned char*>(y_fp8) + y_coff, y_ld, 1.f / y_scale, reinterpret_cast<bf16_t*>(y_bf16) + yb_coff, yb_ld);
+  else
+    hipLaunchKernelGGL(k_bicubic<1>, grid, dim3(TPB), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(x) + x_coff, x_ld, H, W, C,
+                       reinterpret_cast<unsigned char*>(y_fp8) + y_coff, y_ld, 1.f / y_scale, nullptr, 0);
   CRD_LAUNCH_CHECK("crd_bicubic2x_fp8");
   return CRD_OK;
 }

@@ -136,7 +136,8 @@ __global__ __launch_bounds__(TPB) void k_attn_out_residual_stats(const float* x,
 template <int XF, int YF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
                                                   const float* stats, int gmul, const float* gamma, const float* beta,
-                                                  int act, const float* mask, void* y, int y_ld, int y_f32, float y_inv_scale) {
+                                                  int act, const float* mask, void* y, int y_ld, int y_f32, float y_inv_scale,
+                                                  void* y2, int y2_ld) {
   const int b = blockIdx.y;
   Map m(C);
   if (!m.active) return;
@@ -185,7 +186,10 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
           if (ACT == 1) w = gelu_exact(w);
           v[u][j] = w * mk[j];
         }
-        if (YF == 2) store8_fp8(y, ((long long)b * P + pp) * y_ld + c0, v[u], y_inv_scale);      // YF: 0 bf16, 1 fp32, 2 e4m3
+        if (YF == 3) {                                   // YF: 0 bf16, 1 fp32, 2 e4m3, 3 e4m3 (y) and bf16 (y2)
+          store8_fp8(y, ((long long)b * P + pp) * y_ld + c0, v[u], y_inv_scale);
+          store8_bf16(y2, ((long long)b * P + pp) * y2_ld + c0, v[u]);
+        } else if (YF == 2) store8_fp8(y, ((long long)b * P + pp) * y_ld + c0, v[u], y_inv_scale);
         else if (YF) store8_f32(reinterpret_cast<float*>(y), ((long long)b * P + pp) * y_ld + c0, v[u]);
         else store8_bf16(y, ((long long)b * P + pp) * y_ld + c0, v[u]);
       }
@@ -487,7 +491,7 @@ extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
   void* yp = y_f32 ? (void*)(reinterpret_cast<float*>(y) + y_coff) : (void*)(reinterpret_cast<bf16_t*>(y) + y_coff);
 #define CRD_GN_APPLY(XF, YF, ACT)                                                                                        \
   hipLaunchKernelGGL((k_gn_apply<XF, YF, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
-                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, y_f32, 1.f)
+                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, y_f32, 1.f, nullptr, 0)
   const int key = (x_f32 ? 4 : 0) | (y_f32 ? 2 : 0) | (act ? 1 : 0);
   switch (key) {
     case 0: CRD_GN_APPLY(0, 0, 0); break;  case 1: CRD_GN_APPLY(0, 0, 1); break;
@@ -502,20 +506,26 @@ extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
 
 extern "C" int crd_gn_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
                                 const float* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
-                                const float* mask, void* y_fp8, int32_t y_ld, int32_t y_coff, float y_scale, crd_stream_t stream) {
+                                const float* mask, void* y_fp8, int32_t y_ld, int32_t y_coff, float y_scale, void* y_bf16,
+                                int32_t yb_ld, int32_t yb_coff, crd_stream_t stream) {
   CRD_CHECK_ARG(x && stats && gamma && beta && y_fp8 && y_scale > 0.f, "crd_gn_apply_fp8: null pointer / bad scale");
   CRD_CHECK_ARG(gmul >= 1 && (C / 16) % gmul == 0, "crd_gn_apply_fp8: bad gmul %d for C=%d", gmul, C);
-  CRD_CHECK_ARG(y_ld % 8 == 0 && y_coff % 8 == 0, "crd_gn_apply_fp8: y_ld/y_coff must be multiples of 8");
+  CRD_CHECK_ARG(y_ld % 8 == 0 && y_coff % 8 == 0 && yb_ld % 8 == 0 && yb_coff % 8 == 0, "crd_gn_apply_fp8: ld/coff must be multiples of 8");
   int rc = check_common("crd_gn_apply_fp8", x_ld, x_coff, C, x_f32);
   if (rc) return rc;
   dim3 grid; int chunk;
   grid_for(P, C, B, grid, chunk);
   void* yp = reinterpret_cast<unsigned char*>(y_fp8) + y_coff;
-#define CRD_GN_APPLY8(XF, ACT)                                                                                           \
-  hipLaunchKernelGGL((k_gn_apply<XF, 2, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
-                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, 0, 1.f / y_scale)
-  if (x_f32) { if (act) CRD_GN_APPLY8(1, 1); else CRD_GN_APPLY8(1, 0); }
-  else { if (act) CRD_GN_APPLY8(0, 1); else CRD_GN_APPLY8(0, 0); }
+  void* y2 = y_bf16 ? (void*)(reinterpret_cast<bf16_t*>(y_bf16) + yb_coff) : nullptr;
+#define CRD_GN_APPLY8(XF, YF, ACT)                                                                                       \
+  hipLaunchKernelGGL((k_gn_apply<XF, YF, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
+                     x_ld, (long long)P, C, chunk, stats, gmul, gamma, beta, act, mask, yp, y_ld, 0, 1.f / y_scale, y2, yb_ld)
+  switch ((x_f32 ? 4 : 0) | (y2 ? 2 : 0) | (act ? 1 : 0)) {
+    case 0: CRD_GN_APPLY8(0, 2, 0); break;  case 1: CRD_GN_APPLY8(0, 2, 1); break;
+    case 2: CRD_GN_APPLY8(0, 3, 0); break;  case 3: CRD_GN_APPLY8(0, 3, 1); break;
+    case 4: CRD_GN_APPLY8(1, 2, 0); break;  case 5: CRD_GN_APPLY8(1, 2, 1); break;
+    case 6: CRD_GN_APPLY8(1, 3, 0); break;  default: CRD_GN_APPLY8(1, 3, 1); break;
+  }
 #undef CRD_GN_APPLY8
   CRD_LAUNCH_CHECK("crd_gn_apply_fp8");
   return CRD_OK;

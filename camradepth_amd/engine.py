@@ -198,7 +198,10 @@ class Plan:
         # fp8 (e4m3) forward of the big decoder ConvLayers (BASELINE.json config 5): inference plans only, with the
         # per-stage activation scales of model.calibrate_fp8(); {decoder stage: scale of its concat buffer}
         f8 = getattr(model, "fp8_scales", None)
-        self.fp8 = dict(f8) if (f8 and not training and not self.need_grad) else None
+        # (training plans only when the model asks for it -- fp8_train: fp8 FORWARD convolutions, bf16 backward on the bf16
+        # activations, which the producers then store next to the e4m3 copy)
+        self.fp8_keep_bf16 = bool(training or self.need_grad)
+        self.fp8 = dict(f8) if (f8 and (not self.fp8_keep_bf16 or getattr(model, "fp8_train", False))) else None
         self.fp8_convs = []
         self._build()
 
@@ -502,9 +505,9 @@ class Plan:
         raw = self.act(cw.cout, H, W)
         stats = self.zf(self.B, cw.cout // 16, 2)
         if x8 is not None:
-            # fp8 route (inference): e4m3 activations x8 = (tensor, ld, scale) covering the same channels as x, weights
-            # quantised per output channel after every weight pack (forward()), fp32 accumulation, bf16 raw output
-            assert k == 3 and dout is None and x.coff == 0
+            # fp8 route: e4m3 activations x8 = (tensor, ld, scale) covering the same channels as x, weights quantised per
+            # output channel after every weight pack (forward()), fp32 accumulation, bf16 raw output
+            assert k == 3 and x.coff == 0
             cin16 = rup(cw.cin_pad, 16)
             cw.w8 = self.new((cw.cout, 9, cin16), torch.uint8)
             cw.w8_scales = self.new((cw.cout,), F32)
@@ -515,10 +518,11 @@ class Plan:
             self.fwd.append(Op(self.lib.crd_conv3x3_fp8, [spec, cw.w8_scales, float(x8[2])], "crd_conv3x3_fp8", meta=meta))
         else:
             self.conv(self.fwd, self.conv_desc(x, cw, cw.cout, k, 1, k // 2, H, W, raw, stats=stats))
-        if out8 is not None:       # the output feeds fp8 convolutions only: its e4m3 copy is all that is stored
+        if out8 is not None:       # the output feeds fp8 convolutions: its e4m3 copy (inference: all that is stored)
+            yb = [out.t, out.ld, out.coff] if out is not None else [None, 0, 0]
             op = self._emit(self.fwd, "crd_gn_apply_fp8", [raw.t, 0, raw.ld, raw.coff, self.B, raw.P, raw.C, stats, 1,
                                                            self.p(name + ".model.1.weight"), self.p(name + ".model.1.bias"), 1, mask,
-                                                           out8[0], out8[1], out8[2], float(out8[3])])
+                                                           out8[0], out8[1], out8[2], float(out8[3])] + yb)
             op.meta = None
             self.shapes[id(op)] = f"P{raw.P} C{raw.C} -> fp8"
         else:
@@ -656,15 +660,26 @@ class Plan:
                 sc8 = float(self.fp8[j])
                 ld8 = rup(cb.ld, 16)
                 cb8 = self.new((B, Hj * Wj, ld8), torch.uint8)
-                self._emit(self.fwd, "crd_bicubic2x_fp8", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb8, ld8, 0, sc8])
+                keep = self.fp8_keep_bf16           # a backward pass follows: the bf16 tensors are stored as well
+                self._emit(self.fwd, "crd_bicubic2x_fp8", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb8, ld8, 0, sc8]
+                           + ([cb.t, cb.ld, 0] if keep else [None, 0, 0]))
                 if sk_p:
                     self._emit(self.fwd, "crd_quant_fp8", [cb.t, B * Hj * Wj, cb.ld, up_p, sk_p, cb8, ld8, up_p, sc8])
+                if keep:
+                    grp = []
+                    args = [dcb.t, dcb.ld, 0, B, up_src.H, up_src.W, up_p, d_up_src.t, d_up_src.ld, d_up_src.coff, 0]
+                    self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
+                    self._push(grp)
+                bw = lambda c0, c1: dict(dout=dcb.sl(c0, c1), dx=dcb.sl(0, c0), dx_region=("dcb", id(dcb), 0, c0)) if keep else {}
                 self._cmap = cat_map(j, 0)
-                self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, None, x8=(cb8, ld8, sc8), out8=(cb8, ld8, o0, sc8))
+                self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, cb.sl(o0, o0 + 96) if keep else None, x8=(cb8, ld8, sc8),
+                                out8=(cb8, ld8, o0, sc8), **bw(o0, o0 + 96))
                 self._cmap = cat_map(j, 1)
-                self.conv_layer(f"{name}.conv.layers.1", cb.sl(0, o1), 3, None, x8=(cb8, ld8, sc8), out8=(cb8, ld8, o1, sc8))
+                self.conv_layer(f"{name}.conv.layers.1", cb.sl(0, o1), 3, cb.sl(o1, o1 + 64) if keep else None, x8=(cb8, ld8, sc8),
+                                out8=(cb8, ld8, o1, sc8), **bw(o1, o1 + 64))
                 self._cmap = cat_map(j, 2)
-                self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, x8=(cb8, ld8, sc8))
+                last = dict(dout=dout, dx=dcb.sl(0, o1 + 64), dx_region=("dcb", id(dcb), 0, o1 + 64)) if keep else {}
+                self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, x8=(cb8, ld8, sc8), **last)
                 self._cmap = None
                 return
             self._emit(self.fwd, "crd_bicubic2x", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb.t, cb.ld, 0])

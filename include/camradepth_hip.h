@@ -131,12 +131,13 @@ int crd_quant_fp8(const void* x, int64_t rows, int32_t ld, int32_t coff, int32_t
                   float scale, crd_stream_t stream);
 /* Producers that write the e4m3 copy directly (what crd_quant_fp8 would make of their bf16 output: e4m3(bf16(v) / y_scale)):
  * GroupNorm(+GELU) of a ConvLayer (utils.py:210-228) and the decoder's 2x bicubic upsample (utils.py:249-257).  Arguments as
- * crd_gn_apply / crd_bicubic2x with y an fp8 tensor (y_ld, y_coff in bytes = channels). */
+ * crd_gn_apply / crd_bicubic2x with y an fp8 tensor (y_ld, y_coff in bytes = channels).  y_bf16 (optional, NULL = none):
+ * the bf16 output itself as well -- a training step keeps it for the backward pass. */
 int crd_gn_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C, const float* stats,
                      int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask, void* y_fp8, int32_t y_ld,
-                     int32_t y_coff, float y_scale, crd_stream_t stream);
+                     int32_t y_coff, float y_scale, void* y_bf16, int32_t yb_ld, int32_t yb_coff, crd_stream_t stream);
 int crd_bicubic2x_fp8(const void* x, int32_t x_ld, int32_t x_coff, int32_t B, int32_t H, int32_t W, int32_t C, void* y_fp8,
-                      int32_t y_ld, int32_t y_coff, float y_scale, crd_stream_t stream);
+                      int32_t y_ld, int32_t y_coff, float y_scale, void* y_bf16, int32_t yb_ld, int32_t yb_coff, crd_stream_t stream);
 /* per output channel: scales[co] = max |w[co]| / 448 (1 for an all-zero row), w_fp8[co][tap][c] = e4m3(w[co][tap][c] / scales[co])
  * for c < Cin and 0 for Cin <= c < Cin_out (crd_conv3x3_fp8 wants Cin_out % 16 == 0); w_bf16 is the packed forward weight
  * [Cout][taps][Cin] */

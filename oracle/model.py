@@ -138,7 +138,17 @@ def _conv2d_fp8(x, w, x_scale, **kw):
 def conv_layer(sd, name, x, k, quant=None, fp8_scale=None):
     """ConvLayer.forward: conv(no bias) -> GroupNorm(Cout/16) -> GELU (reference: src/utils/utils.py:210-228)."""
     w = sd[name + ".model.0.weight"]
-    y = _conv2d_fp8(x, w, fp8_scale, padding=k // 2) if fp8_scale is not None else _conv2d(x, w, None, quant, padding=k // 2)
+    if fp8_scale is None:
+        y = _conv2d(x, w, None, quant, padding=k // 2)
+    elif torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
+        # fp8 forward inside a training step: the value of the fp8 convolution, the gradient of the bf16 one (what the HIP
+        # path does: data and weight gradients are the bf16 kernels on the bf16 activations / weights)
+        y16 = _conv2d(x, w, None, "bf16", padding=k // 2)
+        with torch.no_grad():
+            y8 = _conv2d_fp8(x, w, fp8_scale, padding=k // 2)
+        y = y16 + (y8 - y16).detach()
+    else:
+        y = _conv2d_fp8(x, w, fp8_scale, padding=k // 2)
     return F.gelu(_gn(y, sd, name + ".model.1", w.shape[0] // GN_DIV))
 
 

@@ -1,10 +1,3 @@
 cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r02c
-for i in 1 2; do
-timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline | cut -c1-160
-done
-cp camradepth_amd/libcamradepth_hip.so /tmp/keep.so; cp camradepth_amd/libalt_wdma.so camradepth_amd/libcamradepth_hip.so
-echo "-- weights by LDS-DMA"
-for i in 1 2; do
-timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline | cut -c1-160
-done
-cp /tmp/keep.so camradepth_amd/libcamradepth_hip.so
+( time timeout 1500 python -m pytest tests/test_gpu_fp8.py -m gpu -q -x -s 2>&1 ) > gpurun_out/r02c/tests_f8.log 2>&1
+grep -n "fp8 inference:\|fp8 forward in\|passed\|failed\|Error\|^E " gpurun_out/r02c/tests_f8.log | cut -c1-400

@@ -205,8 +205,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
 
-  int tile = blockIdx.x;
-  if (tile >= tiles_total) return;
+  // Tile order.  Workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2: in round k workgroup i takes
+  // tile k G + (i % 8) (G / 8) + i / 8, so that the 32 workgroups of an XCD work on 32 NEIGHBOURING tiles (shared halo rows
+  // and columns are fetched into that L2 once).  The last, partial round keeps the plain order (every index stays valid).
+  auto map_tile = [&](int q) {
+#ifdef CRD_C3P_XCD
+    const int G = gridDim.x;
+    if ((G & 7) == 0) {
+      const int k = q / G, i = q - k * G;
+      if ((k + 1) * G <= tiles_total) return k * G + (i & 7) * (G >> 3) + (i >> 3);
+    }
+#endif
+    return q;
+  };
+  int q = blockIdx.x;
+  if (q >= tiles_total) return;
+  int tile = map_tile(q);
   // ---- prologue: halo of the first tile's chunk 0, slabs of steps 0 .. D-1 ----
   int b = __builtin_amdgcn_readfirstlane(halo_offsets(tile));
   __amdgpu_buffer_rsrc_t rx = make_rx(b);
@@ -225,7 +239,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
   bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
   read_frags(0, 0, 0, 0, a0, b0);
 
-  for (; tile < tiles_total; tile += gridDim.x) {
+  for (; q < tiles_total; q += gridDim.x) {
+    tile = map_tile(q);
+    const int tile_next = map_tile(q + gridDim.x);      // >= tiles_total when there is none (its halo requests read zeros)
     const int rem = tile - b * (tiles_x * tiles_y);
     const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
     const int ty0 = tyi * TH, tx0 = txi * TW;
@@ -264,8 +280,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
         // ---- at tap 0 the next halo (next chunk, or chunk 0 of the next tile) ----
         if (tap == 0 && !ABL(256)) {
           if (last) {                                  // the ring keeps running: first halo of the workgroup's next tile
-            const int nb = __builtin_amdgcn_readfirstlane(halo_offsets(tile + gridDim.x));
-            if (tile + gridDim.x < tiles_total) { b = nb; rx = make_rx(b); }
+            const int nb = __builtin_amdgcn_readfirstlane(halo_offsets(tile_next));
+            if (tile_next < tiles_total) { b = nb; rx = make_rx(b); }
             stage_halo(rx, 0, hb ^ 1);
           } else {
             stage_halo(rx, chunk + 1, hb ^ 1);

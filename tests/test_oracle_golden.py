@@ -217,3 +217,47 @@ def test_seg_iou_oracle_properties():
     # two classes, hand-computed: target [0,0,1,1], pred [0,1,1,1] -> IoU0 = 1/2, IoU1 = 2/3
     lg = torch.tensor([[[[1.0, 0.0, 0.0, 0.0]], [[0.0, 1.0, 1.0, 1.0]]]])
     assert ol.seg_iou(lg, torch.tensor([[[0, 0, 1, 1]]]), num_classes=2) == pytest.approx((0.5 + 2 / 3) / 2)
+
+
+def test_oracle_fp8_mode_semantics():
+    """The oracle's fp8 ConvLayer mode (BASELINE config 5; nothing in the reference corresponds, so this pins the DEFINITION the
+    HIP path is tested against): operands are exactly e4m3-representable after scaling, the result equals a plain fp32
+    convolution of the de-quantised operands rounded to bf16, an all-zero weight row gets scale 1, and under autograd the value
+    is the fp8 convolution's while the gradients are the bf16 convolution's (straight-through)."""
+    import torch.nn.functional as F
+    from oracle import model as om
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 24, 9, 11, generator=g) * 2
+    w = torch.randn(16, 24, 3, 3, generator=g) * 0.2
+    w[5] = 0
+    s = float(x.abs().max()) / 448.0
+    y = om._conv2d_fp8(x, w, s, padding=1)
+    xb, wb = x.bfloat16().float(), w.bfloat16().float()
+    xq = (xb * (1.0 / torch.tensor(s))).clamp(-448, 448).to(torch.float8_e4m3fn).float()
+    am = wb.abs().amax(dim=(1, 2, 3))
+    ws = torch.where(am > 0, am / 448.0, torch.ones_like(am))
+    assert float(ws[5]) == 1.0
+    wq = (wb * (1.0 / ws).view(-1, 1, 1, 1)).to(torch.float8_e4m3fn).float()
+    ref = (F.conv2d(xq, wq, None, padding=1) * (torch.tensor(s) * ws).view(1, -1, 1, 1)).bfloat16().float()
+    assert torch.equal(y, ref)
+    assert float(y[:, 5].abs().max()) == 0.0
+    # quantisation error of e4m3 operands: a few percent of the bf16 convolution
+    y16 = om._conv2d(x, w, None, "bf16", padding=1)
+    assert 1e-3 < float((y - y16).norm() / y16.norm()) < 0.08
+    # straight-through: forward value of the fp8 path, gradients of the bf16 path
+    sd = {"l.model.0.weight": w.clone().requires_grad_(True), "l.model.1.weight": torch.ones(16), "l.model.1.bias": torch.zeros(16)}
+    xr = x.clone().requires_grad_(True)
+    out8 = om.conv_layer(sd, "l", xr, 3, "bf16", fp8_scale=s)
+    with torch.no_grad():
+        out8_ng = om.conv_layer(sd, "l", x, 3, "bf16", fp8_scale=s)
+    assert torch.allclose(out8, out8_ng, atol=1e-6)
+    out8.square().sum().backward()
+    gx8, gw8 = xr.grad.clone(), sd["l.model.0.weight"].grad.clone()
+    # the same thing spelled out: bf16 convolution for the gradient, its value replaced by the fp8 convolution's
+    x2, w2 = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y16b = om._conv2d(x2, w2, None, "bf16", padding=1)
+    yv = y16b + (y - y16b).detach()
+    out = F.gelu(om._gn(yv, sd, "l.model.1", 1))
+    out.square().sum().backward()
+    assert torch.allclose(gx8, x2.grad, rtol=1e-5, atol=1e-7) and torch.allclose(gw8, w2.grad, rtol=1e-5, atol=1e-7)
+    assert float(gw8[5].abs().max()) > 0.0      # the zero weight row still receives its (bf16-path) gradient

@@ -43,9 +43,11 @@ FUSE_STATS = os.environ.get("CRD_NO_FUSE_STATS") is None
 # runs (trainer.py; CRD_NO_LATE_WGRAD keeps program order).  W3_LATE_WGS: workgroups their streaming kernels may use in
 # that mode, so that the encoder's kernels still find free CUs (256: 22.1 ms, 160: 20.7, 128: 20.9, 64: 22.3).
 # GroupNorm(+GELU)-apply folded into the A-operand load of the consuming pointwise / patch GEMM (crd_gn_conv) instead of a
-# crd_gn_apply launch + pass per GroupNorm of an encoder block.  CRD_GN_CONV=1 turns it on (read when a plan is built)
+# crd_gn_apply launch + pass per GroupNorm of an encoder block.  CRD_GN_CONV=0 turns it off (read when a plan is built)
 def gn_conv_default():
-    return os.environ.get("CRD_GN_CONV", "0") != "0"
+    """0 = off, 1 = q / k / fc1 / fc2, 2 = q / k / fc1 only (fc2's GroupNorm carries the exact GELU: ~25 VALU operations per
+    element, which a GEMM workgroup does once per column tile next to its MFMAs)."""
+    return int(os.environ.get("CRD_GN_CONV", "2") or 0)
 
 
 LATE_WGRAD = os.environ.get("CRD_NO_LATE_WGRAD") is None
@@ -321,7 +323,8 @@ class Plan:
         w, x = spec["w"], spec["x"]
         assert x.coff == 0 and (xn is None or xn.coff == 0)
         flops = 2.0 * self.B * spec["OH"] * spec["OW"] * spec["cout"] * w.cin_ref * w.taps
-        kname = ("k_gngemm_res" if w.cin_ref * w.taps <= 256 else "k_gngemm_str") + ("<64x64>" if spec["cout"] <= 64 else "<64x128>")
+        small = spec["cout"] <= 64 or -(-spec["OH"] * spec["OW"] // 64) * -(-spec["cout"] // 128) * self.B < 256
+        kname = "k_gngemm_reg" + ("<2,2,1,1>" if small else "<2,2,1,2>")
         meta = {"kernel": kname, "flops": flops,
                 "shape": f"gn+fwd Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} out{spec['OH']}x{spec['OW']}"}
         gn = dict(gn_in=True, x_f32=x.f32, gmul=gmul, stats=stats, gamma=self.p(gname + ".weight"), beta=self.p(gname + ".bias"),
@@ -833,7 +836,7 @@ class Plan:
         F_ = self.fwd
         # ---- attention branch ----
         XN = self.act(Cs, Hs, Ws)
-        fused = self.gn_conv_on
+        fused = bool(self.gn_conv_on)
         if pre is not None and FUSE_STATS:
             st1, ch1 = pre
         else:
@@ -908,7 +911,7 @@ class Plan:
         nxt = (self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)) if (want_next and FUSE_STATS) else None
         fc2_spec = self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp,
                                   stats=nxt[0] if nxt else None, chan=nxt[1] if nxt else None)
-        if fused:            # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only)
+        if fused and self.gn_conv_on == 1:   # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only)
             fc2_spec["x"] = H2
             self.gn_conv(F_, fc2_spec, sth2, ratio, ml + ".norm2", 1, H3 if tr else None)
         else:

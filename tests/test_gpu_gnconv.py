@@ -41,6 +41,8 @@ CASES = [
     (2, 1024, 5, 7, 256, 1, 4, 1, 0, "res"),              # fc2 stage 4, 16 K-slabs
     (8, 128, 32, 52, 1024, 1, 1, 0, 1, "stats"),          # fc1 stage 2 at the benchmark size
     (8, 512, 64, 104, 64, 1, 8, 1, 0, "res"),             # fc2 stage 1 at the benchmark size
+    (2, 320, 6, 10, 96, 1, 1, 0, 1, "stats"),             # fp32 input with five K-slabs (the register path has no K limit)
+    (1, 64, 7, 9, 40, 1, 1, 0, 1, "plain"),               # ragged rows and columns on a single workgroup
 ]
 
 
@@ -124,6 +126,3 @@ def test_gn_conv_rejects_what_it_does_not_cover():
     d.pad = 0
     n.gmul = 3
     assert L.crd_gn_conv(C.byref(d), C.byref(n), lib.stream()) == -1          # 4 slabs do not split into groups of 3
-    n.gmul, n.x_f32 = 1, 1
-    d.Cin = d.x_ld = 512
-    assert L.crd_gn_conv(C.byref(d), C.byref(n), lib.stream()) == -2          # fp32 input beyond the resident K range

@@ -1,5 +1,8 @@
-cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out/r02c
-( timeout 1200 python -m pytest tests/test_gpu_train.py tests/test_gpu_model.py -m gpu -q -x 2>&1 | tail -3 )
-for i in 1 2; do timeout 600 python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline | cut -c50-170; done
-timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-roofline --update-interval 3 | cut -c50-170
-timeout 300 python tools/overfit_check.py 2>&1 | tail -2
+cd "$GRAFT_REPO_ROOT"
+for r in 1 4096 16384 1073741824; do
+ for b in 8 16; do
+  t=$(CRD_GN_CONV_MAXROWS=$r timeout 600 python bench.py --batch $b --steps 30 --warmup 5 --no-cpu-baseline --no-roofline | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_step'])")
+  i=$(CRD_GN_CONV_MAXROWS=$r timeout 600 python bench.py --batch $b --steps 30 --inference | python -c "import sys,json; print(json.loads(sys.stdin.read())['ms_per_forward'])")
+  echo "MAXROWS=$r B=$b train $t ms  infer $i ms"
+ done
+done

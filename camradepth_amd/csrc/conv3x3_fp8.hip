@@ -265,13 +265,18 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fp8(F8K a, int tiles_x, int 
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           __builtin_amdgcn_sched_barrier(0);
+          // (the tile stays in its accumulation registers until here: without this the compiler reads a few of the LAST tiles'
+          // values at the top of the epilogue, spills them, and every reload waits vmcnt(0) -- behind the stores before it)
+          asm volatile("" : "+a"(acc[i][j]));
           uint32_t d[4][2];
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             // accumulator r of this lane is output channel j * 32 + (r&3) + 8 (r>>2) + 4 half
-            const float4 sc = *reinterpret_cast<const float4*>(sS + j * 32 + 8 * g4 + 4 * half);
-            d[g4][0] = pack_bf2(acc[i][j][4 * g4] * sc.x, acc[i][j][4 * g4 + 1] * sc.y);
-            d[g4][1] = pack_bf2(acc[i][j][4 * g4 + 2] * sc.z, acc[i][j][4 * g4 + 3] * sc.w);
+            // (ext_vector_type read: behind a float4 struct load the compiler waits vmcnt(0), i.e. for the whole ring -- common.h)
+            typedef __attribute__((ext_vector_type(4))) float f32x4s;
+            const f32x4s sc = *reinterpret_cast<const f32x4s*>(sS + j * 32 + 8 * g4 + 4 * half);
+            d[g4][0] = pack_bf2(acc[i][j][4 * g4] * sc[0], acc[i][j][4 * g4 + 1] * sc[1]);
+            d[g4][1] = pack_bf2(acc[i][j][4 * g4 + 2] * sc[2], acc[i][j][4 * g4 + 3] * sc[3]);
             if (pok) {
               const float v0 = bf_lo(d[g4][0]), v1 = bf_hi(d[g4][0]), v2 = bf_lo(d[g4][1]), v3 = bf_hi(d[g4][1]);
               s[j][g4 >> 1] += (v0 + v1) + (v2 + v3);
@@ -301,7 +306,14 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fp8(F8K a, int tiles_x, int 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int sl = 0; sl < 2; ++sl) {
-            const float sv = wave_sum(s[j][sl]), sq = wave_sum(ss[j][sl]);
+            // (ds_bpermute on the opaque lane id: __shfl_xor keeps the kernel-entry lane id live across the main loop, where it
+            // is spilled -- and its reload waits vmcnt(0) behind the tile's stores and the ring)
+            float sv = s[j][sl], sq = ss[j][sl];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              sv += __int_as_float(__builtin_amdgcn_ds_bpermute((le ^ o) << 2, __float_as_int(sv)));
+              sq += __int_as_float(__builtin_amdgcn_ds_bpermute((le ^ o) << 2, __float_as_int(sq)));
+            }
             const int gidx = ((n0 + j * 32) >> 4) + sl;
             if (le == 0 && gidx < a.G16) *reinterpret_cast<float2*>(prow + gidx * 2) = make_float2(sv, sq);
           }

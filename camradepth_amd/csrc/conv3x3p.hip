@@ -443,7 +443,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
 #pragma unroll
           for (int sl = 0; sl < 2; ++sl) {
             // a lane's runs of slab sl are channels 16 sl + 4 half + {0..3, 8..11}: both half-waves feed both slabs
-            const float sv = wave_sum(s[j][sl]), sq = wave_sum(ss[j][sl]);
+            // (ds_bpermute on the opaque lane id: __shfl_xor keeps the kernel-entry lane id live across the main loop, where it
+            // is spilled -- and its reload waits vmcnt(0) behind the tile's stores and the ring)
+            float sv = s[j][sl], sq = ss[j][sl];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+              sv += __int_as_float(__builtin_amdgcn_ds_bpermute((le ^ o) << 2, __float_as_int(sv)));
+              sq += __int_as_float(__builtin_amdgcn_ds_bpermute((le ^ o) << 2, __float_as_int(sq)));
+            }
             const int gidx = ((n0 + j * 32) >> 4) + sl;
             if (le == 0 && gidx < a.G16) *reinterpret_cast<float2*>(prow + gidx * 2) = make_float2(sv, sq);
           }

@@ -199,7 +199,7 @@ class Plan:
         self.frozen = frozenset(n for n in model._names if not model._param(n).requires_grad)
         self._dump = {}
         # fp8 (e4m3) forward of the big decoder ConvLayers (BASELINE.json config 5): inference plans only, with the
-        # per-stage activation scales of model.calibrate_fp8(); {decoder stage: scale of its concat buffer}
+        # per-stage activation scales of model.calibrate_fp8(); {decoder stage name: scale of its concat buffer}
         f8 = getattr(model, "fp8_scales", None)
         # (training plans only when the model asks for it -- fp8_train: fp8 FORWARD convolutions, bf16 backward on the bf16
         # activations, which the producers then store next to the e4m3 copy)
@@ -631,7 +631,7 @@ class Plan:
             dCB.append(self.act(ld, Hj, Wj))
             lay.append((up_p, sk_p))
         self._cmap = None
-        self.concat_buffers = CB
+        self.stage_buffers = {}                           # decoder stage name -> its concat buffer
         E1, dE1 = self.act(d[3], *hs[0]), self.act(d[3], *hs[0])
         # gradient regions of encoder outputs: from_encoder dgrad stores (fp32), patch-embed dgrad accumulates
         self.conv_layer("from_encoder_1", enc_out_b[3], 1, E1, dout=dE1, dx=d_enc_out[3], dx_region=("dxs", 3, 0, d[3]))
@@ -657,11 +657,12 @@ class Plan:
             up_p, sk_p = lay[j]
             Hj, Wj = cb.H, cb.W
             o0, o1 = up_p + sk_p, up_p + sk_p + 96
-            f8 = self.fp8 is not None and j in self.fp8 and -(-Wj // 32) * -(-Hj // 16) * B >= 192
+            self.stage_buffers[name] = cb              # (calibrate_fp8 takes the amax of these)
+            f8 = self.fp8 is not None and name in self.fp8 and -(-Wj // 32) * -(-Hj // 16) * B >= 192
             if f8:
                 # the three ConvLayers read an e4m3 copy of the concat buffer (its own row stride, a multiple of 16 bytes);
                 # upsample and the first two GroupNorm+GELU write that copy directly, the skip channels are quantised
-                sc8 = float(self.fp8[j])
+                sc8 = float(self.fp8[name])
                 ld8 = rup(cb.ld, 16)
                 cb8 = self.new((B, Hj * Wj, ld8), torch.uint8)
                 keep = self.fp8_keep_bf16           # a backward pass follows: the bf16 tensors are stored as well

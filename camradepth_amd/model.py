@@ -251,7 +251,7 @@ class CamRaDepth(nn.Module):
         """Per-stage activation scales for the fp8 (e4m3) inference path of the two largest decoder stages (their ConvLayers are
         ~80 % of the forward FLOPs): one bf16 eval forward of the calibration batch x, amax over each stage's concat buffer
         (upsampled input | skip | the two intermediate ConvLayer outputs), scale = margin * amax / 448.  Sets self.fp8_scales
-        ({stage: scale}); inference plans built afterwards (InferenceGraph, forward under torch.no_grad in eval mode) take the
+        ({stage name: scale}, e.g. 'depth_upsample.4'); inference plans built afterwards (InferenceGraph, forward under torch.no_grad in eval mode) take the
         fp8 route; training plans only with train=True (fp8 FORWARD convolutions in those stages, their backward in bf16 on
         the bf16 activations -- a straight-through estimator).  calibrate_fp8(None) switches it off."""
         self.__dict__["fp8_train"] = bool(train) and x is not None
@@ -267,12 +267,13 @@ class CamRaDepth(nn.Module):
                 plan = self._plans[self._plan_key(x)]
             scales = {}
             amax = torch.zeros(1, device=self.flat.device)
-            for j in (3, 4):
-                cb = plan.concat_buffers[j]
+            for name, cb in plan.stage_buffers.items():
+                if not name.endswith((".3", ".4")) and not name.startswith("seg_upsample"):
+                    continue                      # the two largest stages of the depth branch and the segmentation branch's two
                 amax.zero_()
                 L.check(plan.lib.crd_amax_bf16(cb.t.data_ptr(), cb.t.shape[0] * cb.t.shape[1], cb.ld, 0, cb.ld, amax.data_ptr(),
                                                L.stream()), "crd_amax_bf16")
-                scales[j] = max(float(amax), 1e-6) * margin / 448.0
+                scales[name] = max(float(amax), 1e-6) * margin / 448.0
         except Exception:
             self.__dict__["fp8_scales"] = prev
             raise

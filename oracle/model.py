@@ -190,8 +190,9 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
 
     masks: None (eval) or the dict of synth.make_masks (train mode with injected Dropout2d /
     DropPath masks). Returns the reference's nested output dict.
-    fp8_scales: {3: s, 4: s} -- the ConvLayers of depth_upsample.3 / .4 as fp8 convolutions (_conv2d_fp8) with these
-    per-stage activation scales (what camradepth_amd's calibrate_fp8 returns); everything else as `quant` says.
+    fp8_scales: {"depth_upsample.3": s, "depth_upsample.4": s, "seg_upsample.0": s, ...} -- the ConvLayers of those decoder
+    stages as fp8 convolutions (_conv2d_fp8) with these per-stage activation scales (what camradepth_amd's calibrate_fp8
+    returns; a stage that is not listed stays as `quant` says).
     """
     f8 = fp8_scales or {}
     d2 = iter(masks["dropout2d"]) if masks is not None else None
@@ -209,10 +210,10 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
     s3 = drop(decoder_stage(sd, "depth_upsample.2", s2, e4, quant))
     d3 = depth_activation(sd, "depth_activation_3", s3, quant)
     s3 = torch.cat([s3, d3], 1)
-    s4 = drop(decoder_stage(sd, "depth_upsample.3", s3, None, quant, f8.get(3)))
+    s4 = drop(decoder_stage(sd, "depth_upsample.3", s3, None, quant, f8.get("depth_upsample.3")))
     sup_map = unsup_map = seg_map = seg_feat = seg_final = None
     if cfg.supervised_seg or cfg.unsupervised_seg:
-        seg_feat = drop(decoder_stage(sd, "seg_upsample.0", s3, None, quant))
+        seg_feat = drop(decoder_stage(sd, "seg_upsample.0", s3, None, quant, f8.get("seg_upsample.0")))
     if cfg.supervised_seg:
         sup_map = seg_block(_conv2d(seg_feat, sd["seg_conv_stage_4.weight"], sd["seg_conv_stage_4.bias"], quant,
                                     padding=1), cfg.num_classes)
@@ -228,9 +229,9 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
     tmp = torch.cat((s4, seg_map), dim=1) if seg_map is not None else s4
     d4 = depth_activation(sd, "depth_activation_4", tmp, quant)
     s4 = torch.cat([s4, d4], 1)
-    s5 = drop(decoder_stage(sd, "depth_upsample.4", s4, x, quant, f8.get(4)))
+    s5 = drop(decoder_stage(sd, "depth_upsample.4", s4, x, quant, f8.get("depth_upsample.4")))
     if cfg.supervised_seg or cfg.unsupervised_seg:
-        seg_feat = drop(decoder_stage(sd, "seg_upsample.1", seg_feat, x, quant))
+        seg_feat = drop(decoder_stage(sd, "seg_upsample.1", seg_feat, x, quant, f8.get("seg_upsample.1")))
     if cfg.supervised_seg:
         seg_final = _conv2d(seg_feat, sd["seg_conv_final.weight"], sd["seg_conv_final.bias"], quant, padding=1)
         sup_map = seg_block(seg_final, cfg.num_classes)

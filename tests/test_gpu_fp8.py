@@ -171,7 +171,7 @@ def test_fp8_inference_model_matches_oracle_fp8_mode():
     with torch.no_grad():
         out16 = model(x)["depth"]["final_depth"].clone()
     scales = model.calibrate_fp8(x)
-    assert set(scales) == {3, 4} and all(s > 0 for s in scales.values())
+    assert set(scales) == {"depth_upsample.3", "depth_upsample.4"} and all(s > 0 for s in scales.values())
     with torch.no_grad():
         res = model(x)
         out8, half8 = res["depth"]["final_depth"].clone(), res["depth"]["intermediate_depths"][3].clone()
@@ -247,4 +247,39 @@ def test_fp8_forward_in_training_matches_oracle_ste():
     assert abs(float(loss) - float(lo)) <= 5e-3 * abs(float(lo))
     assert r_out < 3e-2
     assert med < 0.03 and worst_dec < 0.02          # measured 9.1e-3 / 3.6e-3 (profiles/r02_gpu_tests.log)
+    model.calibrate_fp8(None)
+
+
+def test_fp8_route_selection_by_grid_and_variant():
+    """Which stages take the fp8 route is decided per plan: a stage needs >= 192 tiles of 16 x 32 pixels (a single 416 x 800 frame
+    qualifies with its full-resolution stages only), and the segmentation branch's stages are calibrated on their own concat
+    buffers.  The supervised-seg model agrees with the oracle's fp8 mode restricted to the stages the plan chose."""
+    from camradepth_amd import synth
+    from camradepth_amd.config import ModelConfig
+    from camradepth_amd.inference import InferenceGraph
+    from oracle import model as om
+    from tests.test_gpu_model import build, rel
+    cfg = ModelConfig.variant("supervised_seg")
+    model = build(cfg)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = synth.make_batch(1, 416, 800, seed=5)
+    x = batch["image"].cuda()
+    with torch.no_grad():
+        ref = model(x)
+    d16, s16 = ref["depth"]["final_depth"].clone(), ref["seg"]["final_seg"].clone()
+    scales = model.calibrate_fp8(x)
+    assert set(scales) == {"depth_upsample.3", "depth_upsample.4", "seg_upsample.0", "seg_upsample.1"}
+    ig = InferenceGraph(model, 1, 416, 800)
+    n8 = sum(op.name == "crd_conv3x3_fp8" for op in ig.plan.fwd)
+    assert n8 == 6, n8       # 13 x 25 tiles at full resolution (both branches), 13 x 13 = 169 < 192 at half resolution
+    out = ig.run(x)
+    used = {k: v for k, v in scales.items() if k in ("depth_upsample.4", "seg_upsample.1")}
+    o8 = om.forward(sd, batch["image"], cfg, quant="bf16", fp8_scales=used)
+    r_d, r_s = rel(out["depth"]["final_depth"], d16), rel(out["seg"]["final_seg"], s16)
+    p_d, p_s = rel(out["depth"]["final_depth"], o8["depth"]["final_depth"]), rel(out["seg"]["final_seg"], o8["seg"]["final_seg"])
+    print(f"fp8 (full-resolution stages) 1x416x800 supervised_seg: depth vs bf16 {r_d:.4f} / vs oracle fp8 {p_d:.4f}, "
+          f"seg logits vs bf16 {r_s:.4f} / vs oracle fp8 {p_s:.4f}, scales {scales}")
+    # (seg logits at the reference initialisation are small and zero-mean: their bf16-vs-oracle floor is ~2e-2 already;
+    # measured here 0.012 / 0.009 depth, 0.059 / 0.046 seg -- bounds = 2x)
+    assert r_d < 3e-2 and p_d < 2e-2 and r_s < 0.12 and p_s < 0.09
     model.calibrate_fp8(None)

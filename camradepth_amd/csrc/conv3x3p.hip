@@ -1,25 +1,26 @@
 // Persistent halo-tile 3x3 convolution (stride 1, pad 1) on MFMA for gfx950: the decoder's big ShortResBlock convs at
 // the 128x208 and 256x416 levels (src/utils/utils.py:114-124,211), forward and data gradient.
 //
-// k_conv3x3 (conv3x3.hip) runs two 4-wave workgroups per CU at 256 VGPRs each; its ablation showed the DMA issue, the
-// LDS fragment reads and the MFMAs of a step to be ADDITIVE (0.20 + 0.19 + 0.25 ms of a 0.67 ms launch): a wave issues
-// its loads, waits, then issues its MFMAs, and the second wave of the SIMD is as often in the same phase as not.  This
-// kernel takes the other road of the CDNA playbook (cdna_hip_programming.md, 4-wave one-wave-per-SIMD structure):
-//   * ONE workgroup of 4 waves per CU, every wave alone on its SIMD with the whole 512-register file: a 128-pixel x
-//     128-column accumulator per wave (256 VGPRs; 0.5 fragment reads per MFMA instead of 0.75) and room to
-//     software-pipeline the fragment reads in registers -- the reads of the next half-step are issued before the 16
-//     MFMAs of the current one, so LDS latency and the DMA issue slots hide in the MFMA shadow (one wave can issue ~5
-//     other instructions per 32-cycle MFMA for free);
-//   * a 16 x 32 = 512-pixel tile per workgroup: one weight slab serves twice the pixels, halo overhead 1.20 instead of 1.33;
-//   * PERSISTENT workgroups walk over the tiles of their column range: the weight-slab ring simply keeps running across
-//     tiles and the first halo of the next tile is requested during the last channel chunk of the current one, so there
-//     is no exposed prologue (the one-workgroup-per-CU kernel of round 1 lost 23-54 % there);
-//   * the epilogue is per wave (its own 32-pixel x BN staging strip in LDS, 16-byte stores, GroupNorm sums by shuffles
-//     and one atomic per slab and wave), so it needs no workgroup barrier and no LDS that the running rings occupy.
+// k_conv3x3 (conv3x3.hip) runs two 4-wave workgroups per CU at 256 VGPRs each, one 8 x 32-pixel tile per workgroup: every
+// workgroup pays its own prologue (first halo + slabs) and epilogue, hidden only by the other workgroup of the CU.  Here:
+//   * ONE persistent workgroup per CU (8 waves = two per SIMD by default, 4 with CRD_CONV3P_WAVES=4: measured the same) walks
+//     over 16 x 32 = 512-pixel tiles: one weight slab serves twice the pixels, halo overhead 1.20 instead of 1.33, and the
+//     512 x 128 fp32 accumulator tile is exactly the CU's 256 KB of accumulation registers;
+//   * the weight-slab ring simply keeps running across tiles and the first halo of the next tile is requested during the
+//     last channel chunk of the current one: no exposed prologue (round 1's one-workgroup-per-CU kernel lost 23-54 % there);
+//   * each (chunk, tap) step is two half-steps of 16 channels; the fragment reads of the next half-step are issued before the
+//     MFMAs of the current one (register double buffer), pinned between the MFMAs with sched_group_barrier;
+//   * MFMA operands are swapped (A = weight rows), so a lane holds ONE pixel and 4-channel runs of it; v_permlane32_swap
+//     between the half-waves makes 8 consecutive channels = one 16-byte store per lane straight from the accumulators: no LDS
+//     staging, no barrier, nothing in flight is waited for.  Accumulate mode = all of a row's loads, one wait, then the stores;
+//   * GroupNorm sums: per (tile, wave) partial rows + k_stats_finalize (atomics from 256 synchronised workgroups: +0.4 ms).
 // Same K walk as k_conv3x3: (32-channel chunk) x (9 taps), halo of a chunk in LDS once (double buffered), weight slab
-// of every (chunk, tap) through a ring requested D steps ahead, counted vmcnt waits, one raw s_barrier per step.
+// of every (chunk, tap) through a ring requested D steps ahead, counted vmcnt waits, one raw s_barrier per half-step.
 // Plain bf16 output (store or accumulate) with optional GroupNorm sums -- everything the decoder's 3x3 ConvLayers and
 // their data gradients need; bias / activation / fp32 / residual epilogues stay with k_conv3x3.
+// What bounds it (profiles/r02_pmc_kernels.md): the chip's power limit -- 1.5 GHz while it
+// runs, MFMA pipe busy 59 % of those clocks; ring depth, wave count, barriers, waits, the weights' path and the tile order
+// (the compile-time experiments below) all measure the same.
 #include "conv_common.h"
 #include <cstdlib>
 #include <type_traits>

@@ -309,10 +309,16 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         small = a.height * a.width <= 256 * 416        # bounded: at larger frames only the batch-2-sized legs fit the time budget
         out["cpu_baseline"] = cpu_baseline(a.variant, a.batch if small else 1, a.height, a.width)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if world > 1 or force_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: RCCL's version banner sits in the C library's stdio buffer until then
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

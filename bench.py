@@ -215,6 +215,8 @@ def main():
     # gradient all-reduce between the per-segment graphs -- with a single rank, to exercise it on a 1-GPU box
     force_dist = os.environ.get("CRD_FORCE_DIST") is not None
     if world > 1 or force_dist:
+        if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "NONE"      # every rank would print RCCL's banner to stdout, around rank 0's JSON line
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))

@@ -32,6 +32,8 @@ constexpr int XS = 6, YS = 4;                    // ring slots: input rows / dy 
 constexpr int XPX = 40;                          // pixels per staged input row (34 used, 5 DMA groups of 8)
 constexpr int XLD = 64;                          // channels per chunk (128-byte LDS rows)
 typedef __attribute__((address_space(3))) void* lds_ptr;
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // Source-side swizzle of the lane-linear LDS images so that the transposing reads are bank-conflict free: a 16-lane
 // group of ds_read_b64_tr_b16 fetches 4 pixel rows x 32 bytes, a half-wave two such groups 8 rows apart.  The 32-byte
@@ -50,15 +52,18 @@ __device__ __forceinline__ s16x4 tr_read3(const bf16_t* p) {
 
 // WCO x WCI = 8 waves; a wave owns TCO 16-channel co tiles and NT 16-channel ci tiles of the 64-channel chunk
 // (2 x 2 tiles per wave halve the LDS fragment reads per MFMA compared with 1 x 4)
-template <int WCO, int WCI, int TCO>
+// RPS = image rows per step (per barrier): with one row a wave issues 9 x TCO x NT = 18-36 MFMAs between two barriers; two rows
+// halve the barriers and the counted waits per MFMA (the rings are twice as deep: 12 input rows, 8 dy rows).
+template <int WCO, int WCI, int TCO, int RPS>
 __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
+  constexpr int XSr = XS * RPS, YSr = YS * RPS;
   static_assert(WCO * WCI == 8, "8 waves");
   constexpr int NT = 4 / WCI;
   constexpr int COT = WCO * TCO * 16;            // channels of dy staged per row (>= Cout)
   constexpr int YGRP = 32 * COT * 2 / 1024;      // DMA wave-instructions per dy row (1 KiB each)
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
-  bf16_t* sX = lds;                              // [XS][XPX][XLD]
-  bf16_t* sY = lds + XS * XPX * XLD;             // [YS][32][COT]
+  bf16_t* sX = lds;                              // [XSr][XPX][XLD]
+  bf16_t* sY = lds + XSr * XPX * XLD;            // [YSr][32][COT]
 
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
         const int ix = x0 - 1 + xpix, ch = c0 + ((((xgr >> 1) ^ swz128(xpix)) << 1) | (xgr & 1)) * 8;
         const bool ok = (unsigned)h < (unsigned)a.H && (unsigned)ix < (unsigned)a.W && xpix < 34 && ch < a.Cin;
         const unsigned off = ok ? (unsigned)((((long long)h * a.W + ix) * a.x_ld + ch) * 2) : OOB;
-        lds_dma16(rx, (unsigned)(uintptr_t)(lds_ptr)(sX + (((h + 1) % XS) * XPX + 8 * wv) * XLD), off);
+        lds_dma16(rx, (unsigned)(uintptr_t)(lds_ptr)(sX + (((h + 1) % XSr) * XPX + 8 * wv) * XLD), off);
       }
 #else
       (void)h;
@@ -143,7 +148,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
         const int ix = x0 + ypix, co = ((((ygr >> 1) ^ swz_y<COT>(ypix)) << 1) | (ygr & 1)) * 8;
         const bool ok = r < y1 && ix < a.W && co < a.Cout;
         const unsigned off = ok ? (unsigned)((((long long)r * a.W + ix) * a.dy_ld + co) * 2) : OOB;
-        lds_dma16(ry, (unsigned)(uintptr_t)(lds_ptr)(sY + (r % YS) * 32 * COT + 512 * wv), off);
+        lds_dma16(ry, (unsigned)(uintptr_t)(lds_ptr)(sY + (r % YSr) * 32 * COT + 512 * wv), off);
       }
 #else
       (void)r;
@@ -152,48 +157,55 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
 
     // all waves must be done with the previous segment's LDS data before it is overwritten
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    // prologue: input rows y0-1, y0 first, then the three "virtual" steps y0-3 .. y0-1 (each: dy row s+3, input row s+4)
+    // prologue: input rows y0-1, y0 first, then the three "virtual" steps before y0 (each: its dy rows, the next input rows)
     issue_x(y0 - 1);
     issue_x(y0);
 #pragma unroll
-    for (int s = -3; s < 0; ++s) { issue_y(y0 + s + 3); issue_x(y0 + s + 4); }
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+      for (int r = 0; r < RPS; ++r) { issue_y(y0 + s * RPS + r); issue_x(y0 + s * RPS + 1 + r); }
 
-    for (int y = y0; y < y1; ++y) {
-      // dy row y and input row y+1 were issued three steps ago: at most two steps' worth of DMA may still be in flight
-      if (wv < 5 && wv < YGRP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else if (wv < 5 || wv < YGRP) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    for (int y = y0; y < y1; y += RPS) {
+      // this step's dy rows and last input rows were issued three steps ago: at most two steps' worth of DMA may still be in flight
+      if (wv < 5 && wv < YGRP) wait_vm<4 * RPS>();
+      else if (wv < 5 || wv < YGRP) wait_vm<2 * RPS>();
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      issue_y(y + 3);
-      issue_x(y + 4);
+#pragma unroll
+      for (int r = 0; r < RPS; ++r) { issue_y(y + 3 * RPS + r); issue_x(y + 3 * RPS + 1 + r); }
 
-      const bf16_t* yrow = sY + (y % YS) * 32 * COT;
-      bf16x8 af[TCO];
 #pragma unroll
-      for (int i = 0; i < TCO; ++i) {
-        s16x4 lo = tr_read3(yrow + yoff[i][0]), hi = tr_read3(yrow + yoff[i][1]);
-        union { bf16x8 v; s16x4 h[2]; } u;
-        u.h[0] = lo; u.h[1] = hi;
-        af[i] = u.v;
-      }
+      for (int rr = 0; rr < RPS; ++rr) {
+        const int yy = y + rr;
+        if (rr > 0 && yy >= y1) break;                 // odd segment length: the last step has one row
+        const bf16_t* yrow = sY + (yy % YSr) * 32 * COT;
+        bf16x8 af[TCO];
 #pragma unroll
-      for (int ky = 0; ky < 3; ++ky) {
-        const bf16_t* xrow = sX + ((y + ky) % XS) * XPX * XLD;      // input row y+ky-1 lives in slot (y+ky) % XS
+        for (int i = 0; i < TCO; ++i) {
+          s16x4 lo = tr_read3(yrow + yoff[i][0]), hi = tr_read3(yrow + yoff[i][1]);
+          union { bf16x8 v; s16x4 h[2]; } u;
+          u.h[0] = lo; u.h[1] = hi;
+          af[i] = u.v;
+        }
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
+        for (int ky = 0; ky < 3; ++ky) {
+          const bf16_t* xrow = sX + ((yy + ky) % XSr) * XPX * XLD;      // input row yy+ky-1 lives in slot (yy+ky) % XSr
 #pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            s16x4 lo = tr_read3(xrow + xoff[kx][j][0]), hi = tr_read3(xrow + xoff[kx][j][1]);
-            union { bf16x8 v; s16x4 h[2]; } u;
-            u.h[0] = lo; u.h[1] = hi;
+          for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-            for (int i = 0; i < TCO; ++i)
-              acc[ky * 3 + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], u.v, acc[ky * 3 + kx][i][j], 0, 0, 0);
+            for (int j = 0; j < NT; ++j) {
+              s16x4 lo = tr_read3(xrow + xoff[kx][j][0]), hi = tr_read3(xrow + xoff[kx][j][1]);
+              union { bf16x8 v; s16x4 h[2]; } u;
+              u.h[0] = lo; u.h[1] = hi;
+#pragma unroll
+              for (int i = 0; i < TCO; ++i)
+                acc[ky * 3 + kx][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], u.v, acc[ky * 3 + kx][i][j], 0, 0, 0);
+            }
           }
         }
-      }
-      if (do_bias) {
+        if (do_bias) {
 #pragma unroll 8
-        for (int r = 0; r < 32; ++r) bsum += bf2f(yrow[r * COT + ((((t >> 4) ^ swz_y<COT>(r)) << 4) | (t & 15))]);
+          for (int r = 0; r < 32; ++r) bsum += bf2f(yrow[r * COT + ((((t >> 4) ^ swz_y<COT>(r)) << 4) | (t & 15))]);
+        }
       }
     }
     sr = seg_end;
@@ -237,21 +249,28 @@ int plan_rows(long long total_rows, int Cin, int& rows_per_wg, int cap = 0) {
   return (int)((total_rows + rows_per_wg - 1) / rows_per_wg);
 }
 
-template <int WCO, int WCI, int TCO>
-int launch_w3(const Wg3K& k0, hipStream_t st, int partial_capacity) {
+template <int WCO, int WCI, int TCO, int RPS>
+int launch_w3r(const Wg3K& k0, hipStream_t st, int partial_capacity) {
   Wg3K k = k0;
   constexpr int COT = WCO * TCO * 16;
-  const size_t lds = (size_t)(XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
+  const size_t lds = (size_t)RPS * (XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
   const int chunks = cdiv(k.Cin, XLD);
   const int wgs = plan_rows(k.total_rows, k.Cin, k.rows_per_wg, k.dw_part ? partial_capacity : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO, RPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_wgrad3x3<WCO, WCI, TCO>), dim3(wgs, chunks), dim3(512), lds, st, k);
+  hipLaunchKernelGGL((k_wgrad3x3<WCO, WCI, TCO, RPS>), dim3(wgs, chunks), dim3(512), lds, st, k);
   CRD_LAUNCH_CHECK("crd_conv_wgrad(3x3 streaming)");
   return CRD_OK;
+}
+
+template <int WCO, int WCI, int TCO>
+int launch_w3(const Wg3K& k, hipStream_t st, int partial_capacity) {
+  static int rps = -1;
+  if (rps < 0) { const char* e = getenv("CRD_W3_RPS"); rps = e ? atoi(e) : 2; }
+  return rps == 1 ? launch_w3r<WCO, WCI, TCO, 1>(k, st, partial_capacity) : launch_w3r<WCO, WCI, TCO, 2>(k, st, partial_capacity);
 }
 
 }  // namespace

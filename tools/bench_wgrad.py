@@ -3,7 +3,9 @@ import sys, ctypes as C
 sys.path.insert(0, ".")
 import torch
 from camradepth_amd import lib
-B, H, W, Cin, Cout = 8, 256, 416, 304, 128
+import os
+B, H, W = 8, 256, 416
+Cin, Cout = int(os.environ.get("CIN", 304)), int(os.environ.get("COUT", 128))
 L = lib.load()
 x = (torch.randn(B, H * W, Cin, device="cuda") * 0.5).to(torch.bfloat16)
 dy = (torch.randn(B, H * W, Cout, device="cuda") * 0.5).to(torch.bfloat16)

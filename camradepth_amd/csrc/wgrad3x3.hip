@@ -173,6 +173,10 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
 #pragma unroll
       for (int r = 0; r < RPS; ++r) { issue_y(y + 3 * RPS + r); issue_x(y + 3 * RPS + 1 + r); }
 
+      // a wave whose 16 x NT input channels all lie beyond Cin (the tail chunk of Cin = 136 / 144 / 240: 3, 3, 1 of the 4
+      // ci-waves) only takes part in the DMA and the barriers: its MFMAs would multiply zeros -- at the chip's power limit
+      // they still cost time
+      if (c0 + wci * NT * 16 >= a.Cin) continue;
 #pragma unroll
       for (int rr = 0; rr < RPS; ++rr) {
         const int yy = y + rr;

@@ -171,16 +171,32 @@ __device__ __forceinline__ void store8_f32(float* base, int64_t elem_off, const 
   p[1] = make_float4(v[4], v[5], v[6], v[7]);
 }
 
+// ---- order-independent sums (include/camradepth_hip.h: crd_sum_t) -------------------------------------------------------
+// A partial is rounded once to the fixed-point grid (the power-of-two scaling is exact in fp32) and added with a 64-bit
+// integer atomic; the total does not depend on the order of arrival.
+constexpr float STAT_ONE = (float)(1 << CRD_STAT_FRAC_BITS);
+constexpr float GRAD_ONE = (float)(1ll << CRD_GRAD_FRAC_BITS);
+typedef __attribute__((address_space(1))) unsigned long long gsum_raw_t;
+__device__ __forceinline__ long long to_fx(float v, float one) { return __float2ll_rn(v * one); }
+__device__ __forceinline__ void fx_add(crd_sum_t* p, long long q) {
+  // address space 1 stated explicitly: through a descriptor loaded from memory the compiler would emit a FLAT atomic
+  __hip_atomic_fetch_add((gsum_raw_t*)p, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void stat_add(crd_sum_t* p, float v) { fx_add(p, to_fx(v, STAT_ONE)); }
+__device__ __forceinline__ void grad_add(crd_sum_t* p, float v) { fx_add(p, to_fx(v, GRAD_ONE)); }
+__device__ __forceinline__ float stat_get(const crd_sum_t* p) { return (float)(*p) * (1.f / STAT_ONE); }
+__device__ __forceinline__ float grad_get(const crd_sum_t* p) { return (float)(*p) * (1.f / GRAD_ONE); }
+
 // mean / rstd of GroupNorm group from g16 slab sums: group = gmul consecutive slabs starting at slab0
-__device__ __forceinline__ void gn_mean_rstd(const float* stats_b, int slab0, int gmul, float inv_count, float& mean,
+__device__ __forceinline__ void gn_mean_rstd(const crd_sum_t* stats_b, int slab0, int gmul, float inv_count, float& mean,
                                              float& rstd) {
-  float s = 0.f, ss = 0.f;
+  long long s = 0, ss = 0;
   for (int i = 0; i < gmul; ++i) {
     s += stats_b[(slab0 + i) * 2];
     ss += stats_b[(slab0 + i) * 2 + 1];
   }
-  mean = s * inv_count;
-  float var = fmaxf(ss * inv_count - mean * mean, 0.f);
+  mean = (float)s * (1.f / STAT_ONE) * inv_count;
+  float var = fmaxf((float)ss * (1.f / STAT_ONE) * inv_count - mean * mean, 0.f);
   rstd = rsqrtf(var + GN_EPS);
 }
 

@@ -12,7 +12,7 @@ struct ConvK {
   int out_mode, patch_k, patch_c, YW;
   const float* bias; int bias_bstride; int act;
   const float* res; int res_ld; long long res_bstride; const float* res_scale;
-  int accumulate; float* stats; int G16;
+  int accumulate; crd_sum_t* stats; int G16;
   float* stats_partial; int n_tiles;   // per-tile partial sums [B][n_tiles][G16][2] (plain stores) or nullptr -> atomics
   int vec_ok;   // y base/offset 16-byte aligned: the vectorised epilogue may be used
   int vecf_ok;  // fp32 output (+ residual) rows are 16-byte aligned as well: LDS-staged float4 epilogue
@@ -20,9 +20,9 @@ struct ConvK {
   // Optional: reduce phase of the backward of the GroupNorm (+GELU) whose dy this launch produces (vector path only).
   // red_x = that GroupNorm's raw bf16 input [pixels][red_x_ld], batch stride red_x_bstride; r as in crd_gn_bwd_reduce.
   const bf16_t* red_x; int red_x_ld; long long red_x_bstride;
-  const float* red_stats; const float* red_gamma; const float* red_beta; int red_gmul, red_act;
-  float* red_r;
-  float* chan;   // optional per-channel (sum, sumsq) of the stored output [B][Cout][2] (scalar epilogue path only)
+  const crd_sum_t* red_stats; const float* red_gamma; const float* red_beta; int red_gmul, red_act;
+  crd_sum_t* red_r;
+  crd_sum_t* chan;   // optional per-channel (sum, sumsq) of the stored output [B][Cout][2] (scalar epilogue path only)
   int col0;  // first output column of this launch (the 3x3 halo kernel covers wide layers with two tile widths)
   int dbg;   // developer experiments only (CRD_DBG env): 1 no weight-DMA wait, 2 no DMA at all, 4 no epilogue
 };
@@ -161,7 +161,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
         const int c = n0 + g * 8 + (jk >> 1);
         float wv = 0.f;
         if (c < a.Cout) {
-          atomicAdd(&a.red_r[((long long)b * a.Cout + c) * 2 + (jk & 1)], v);
+          grad_add(&a.red_r[((long long)b * a.Cout + c) * 2 + (jk & 1)], v);
           wv = v * a.red_gamma[c];
         }
         fw[threadIdx.x] = wv;
@@ -175,7 +175,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
 #pragma unroll
           for (int j = 0; j < 16; ++j) s2 += fw[(slab * 16 + j) * 2 + which];
           const int cpg = 16 * a.red_gmul;
-          atomicAdd(&a.red_r[(long long)gridDim.z * a.Cout * 2 + ((long long)b * (a.Cout / cpg) + c0s / cpg) * 2 + which], s2);
+          grad_add(&a.red_r[(long long)gridDim.z * a.Cout * 2 + ((long long)b * (a.Cout / cpg) + c0s / cpg) * 2 + which], s2);
         }
       }
     }
@@ -234,7 +234,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
         float v = 0.f;
         for (int m = 0; m < NT / GPR4; ++m) v += fr[((c >> 2) + m * GPR4) * 8 + (c & 3) * 2 + which];
         fc[threadIdx.x] = v;
-        if (a.chan && n0 + c < a.Cout) atomicAdd(&a.chan[((long long)b * a.Cout + n0 + c) * 2 + which], v);
+        if (a.chan && n0 + c < a.Cout) stat_add(&a.chan[((long long)b * a.Cout + n0 + c) * 2 + which], v);
       }
       __syncthreads();
       if ((int)threadIdx.x < (BN / 16) * 2) {
@@ -244,7 +244,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
           float v = 0.f;
 #pragma unroll
           for (int j = 0; j < 16; ++j) v += fc[(slab * 16 + j) * 2 + which];
-          atomicAdd(a.stats + ((long long)b * a.G16 + gidx) * 2 + which, v);
+          stat_add(a.stats + ((long long)b * a.G16 + gidx) * 2 + which, v);
         }
       }
     }
@@ -302,9 +302,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
     if (a.chan) {                               // lanes l and l^32 hold the same column: one atomic pair per column and wave
       const float cs = s + __shfl_xor(s, 32), css = ss + __shfl_xor(ss, 32);
       if (l < 32 && colok) {
-        float* cp = a.chan + ((long long)b * a.Cout + col) * 2;
-        atomicAdd(cp, cs);
-        atomicAdd(cp + 1, css);
+        crd_sum_t* cp = a.chan + ((long long)b * a.Cout + col) * 2;
+        stat_add(cp, cs);
+        stat_add(cp + 1, css);
       }
     }
     if (a.stats) {
@@ -330,7 +330,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
       const int g = (n0 >> 4) + wn_ * TN * 2 + slab;
       if (g < a.G16) {
         if (a.stats_partial) a.stats_partial[(((long long)b * a.n_tiles + tile) * a.G16 + g) * 2 + which] = v;
-        else atomicAdd(a.stats + ((long long)b * a.G16 + g) * 2 + which, v);
+        else stat_add(a.stats + ((long long)b * a.G16 + g) * 2 + which, v);
       }
     }
   }
@@ -352,7 +352,7 @@ __device__ __forceinline__ void conv_epilogue_idle(const ConvK& a) {
 }
 
 // stats[b][g][which] += sum over tiles of the per-tile partials written by conv_epilogue
-__global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, float* stats);
+__global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, crd_sum_t* stats);
 
 
 }  // namespace crdk

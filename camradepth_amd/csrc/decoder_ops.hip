@@ -364,7 +364,7 @@ __global__ __launch_bounds__(TPB) void k_head2_bwd_data(const float* gd, const b
 // accumulator for all 2048 workgroups the chain of contended atomics (2048 x 32 per 128-byte line x 2.6 ns) was the
 // whole 170 us of this kernel, hence the copies (crd_wgrad_unpack sums them).
 __global__ __launch_bounds__(TPB) void k_head2_wgrad(const float* gd, const bf16_t* add, int add_ld, const bf16_t* a, int H, int W,
-                                                     int chunk, float* rows, int replicas) {
+                                                     int chunk, crd_sum_t* rows, int replicas) {
   __shared__ float sm[9 * 32 + 1];
   const int b = blockIdx.y, q = threadIdx.x & 3, pl = threadIdx.x >> 2;
   const float* gb = gd + (long long)b * H * W;
@@ -420,9 +420,9 @@ __global__ __launch_bounds__(TPB) void k_head2_wgrad(const float* gd, const bf16
     }
     __syncthreads();
   }
-  float* dst = rows + (long long)((blockIdx.y * gridDim.x + blockIdx.x) % replicas) * 289;
-  for (int i = threadIdx.x; i < 288; i += TPB) atomicAdd(&dst[(i & 31) * 9 + (i >> 5)], sm[i]);
-  if (threadIdx.x == 0) atomicAdd(&dst[288], sm[288]);
+  crd_sum_t* dst = rows + (long long)((blockIdx.y * gridDim.x + blockIdx.x) % replicas) * 289;
+  for (int i = threadIdx.x; i < 288; i += TPB) grad_add(&dst[(i & 31) * 9 + (i >> 5)], sm[i]);
+  if (threadIdx.x == 0) grad_add(&dst[288], sm[288]);
 }
 
 // LDS-tiled form of k_bicubic_bwd: a workgroup owns an 8 x 16 tile of input pixels and a 32-channel window; the
@@ -638,7 +638,7 @@ extern "C" int crd_head_conv2_fwd(const void* a, const float* w, const float* bi
 }
 
 static int head2_bwd_launch(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
-                            int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas, int parts,
+                            int32_t B, int32_t H, int32_t W, void* dz, crd_sum_t* dw_rows, int32_t replicas, int parts,
                             const char* who, crd_stream_t stream) {
   CRD_CHECK_ARG(gd && a && (!(parts & 1) || (w && dz)) && (!(parts & 2) || (dw_rows && replicas >= 1)), "%s: null pointer / replicas < 1", who);
   const bf16_t* addp = add ? reinterpret_cast<const bf16_t*>(add) + add_coff : nullptr;
@@ -661,7 +661,7 @@ static int head2_bwd_launch(const float* gd, const void* add, int32_t add_ld, in
 }
 
 extern "C" int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
-                                  int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas,
+                                  int32_t B, int32_t H, int32_t W, void* dz, crd_sum_t* dw_rows, int32_t replicas,
                                   crd_stream_t stream) {
   return head2_bwd_launch(gd, add, add_ld, add_coff, a, w, B, H, W, dz, dw_rows, replicas, 3, "crd_head_conv2_bwd", stream);
 }
@@ -672,7 +672,7 @@ extern "C" int crd_head_conv2_bwd_data(const float* gd, const void* add, int32_t
 }
 
 extern "C" int crd_head_conv2_wgrad(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, int32_t B,
-                                    int32_t H, int32_t W, float* dw_rows, int32_t replicas, crd_stream_t stream) {
+                                    int32_t H, int32_t W, crd_sum_t* dw_rows, int32_t replicas, crd_stream_t stream) {
   return head2_bwd_launch(gd, add, add_ld, add_coff, a, nullptr, B, H, W, nullptr, dw_rows, replicas, 2, "crd_head_conv2_wgrad", stream);
 }
 

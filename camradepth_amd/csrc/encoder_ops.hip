@@ -23,7 +23,7 @@ constexpr int DCW = 64;   // channel window (8 granules: 128-byte pixel rows in 
 // simplified_attention.py:37-38): xn = bf16((x - mean) * rstd * gamma + beta), exactly what crd_gn_apply would have
 // written, so the normalised hidden tensor is never materialised.  A thread stages the same granule for every piece.
 struct InNorm {
-  const float* stats;   // g16 sums of x [B][C/16][2], or nullptr: no normalisation
+  const crd_sum_t* stats;   // g16 sums of x [B][C/16][2], or nullptr: no normalisation
   const float* gamma; const float* beta; int gmul;
 };
 __device__ __forceinline__ void innorm_coeffs(const InNorm& n, int b, int C, long long P, int c0, bool ok, float (&a)[8], float (&s)[8]) {
@@ -55,14 +55,14 @@ __device__ __forceinline__ uint4 innorm_apply(const uint4& u, const float (&a)[8
 // over (H1, d(H1N)) per block.
 struct RedOut {
   const bf16_t* xr;       // raw input of the GroupNorm [B][H][W][C], or nullptr: no reduce
-  const float* stats;     // its g16 sums
+  const crd_sum_t* stats; // its g16 sums
   const float* gamma;
-  float* r;               // [B][C][2] then [B][C/16][2]
+  crd_sum_t* r;           // [B][C][2] then [B][C/16][2]
 };
 
 template <bool FLIP, bool STATS, int TW>
 __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, int C, const float* w9, const float* bias,
-                                                bf16_t* y, float* stats, int tiles_x, InNorm inn, RedOut red) {
+                                                bf16_t* y, crd_sum_t* stats, int tiles_x, InNorm inn, RedOut red) {
   constexpr int HWD = TW + 2;                       // halo width
   constexpr int HPX = (DTH + 2) * HWD;              // halo pixels
   constexpr int RSPLIT = 32 / TW;                   // row groups of the thread mapping (TW = 16: rows 0-3 / 4-7)
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
     if (t < 8) {                              // (slab, moment) of this 64-channel window
       const float v = sred[0][t] + sred[1][t] + sred[2][t] + sred[3][t];
       const int slab = (c_win >> 4) + (t >> 1);
-      if (slab < (C >> 4)) atomicAdd(&stats[((long long)b * (C >> 4) + slab) * 2 + (t & 1)], v);
+      if (slab < (C >> 4)) stat_add(&stats[((long long)b * (C >> 4) + slab) * 2 + (t & 1)], v);
     }
   }
   if (red.xr) {
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
     if (t < 2 * nch) {                         // (channel, moment) of this window
       const float v = fr[t] + fr[128 + t] + fr[256 + t] + fr[384 + t];
       const int c = c_win + (t >> 1);
-      atomicAdd(&red.r[((long long)b * C + c) * 2 + (t & 1)], v);
+      grad_add(&red.r[((long long)b * C + c) * 2 + (t & 1)], v);
       fr[512 + t] = v * red.gamma[c];
     }
     __syncthreads();
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) a += fr[512 + (grp * 16 + j) * 2 + which];
-      atomicAdd(&red.r[(long long)gridDim.z * C * 2 + ((long long)b * (C >> 4) + (c_win >> 4) + grp) * 2 + which], a);
+      grad_add(&red.r[(long long)gridDim.z * C * 2 + ((long long)b * (C >> 4) + (c_win >> 4) + grp) * 2 + which], a);
     }
   }
 }
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
 // costs ~2.6 ns per 128-byte line, serialised device-wide, so all workgroups on one copy would be the whole kernel time.
 // The caller sums the copies (crd_wgrad_unpack).
 template <int TW>
-__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, float* dw10,
+__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, crd_sum_t* dw10,
                                                       int replicas, int tiles_x, int tiles_y, int tiles_per_wg, InNorm inn) {
   constexpr int HWD = TW + 2;
   constexpr int HPX = (DTH + 2) * HWD;
@@ -333,25 +333,25 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
     }
     __syncthreads();
   }
-  float* dst = dw10 + (long long)((blockIdx.z * gridDim.x + blockIdx.x) % replicas) * 10 * C;
+  crd_sum_t* dst = dw10 + (long long)((blockIdx.z * gridDim.x + blockIdx.x) % replicas) * 10 * C;
   const int nch = nG * 8;
   for (int i = t; i < 10 * nch; i += TPB) {
     const int tp = i / nch, cl = i - tp * nch;
     const float v = sm[tp * 64 + cl];
-    if (v != 0.f) atomicAdd(&dst[(long long)tp * C + c_win + cl], v);
+    if (v != 0.f) grad_add(&dst[(long long)tp * C + c_win + cl], v);
   }
 }
 
 // Rank-one value path of the attention forward (documented at k_attn_xbar_proj below); also run by one extra workgroup
 // per sample of k_attn_scores (crd_attn_fwd), hence blockDim-strided.
-struct XbarProj { const float* chan; const float* stats; const float* gamma; const float* beta; const bf16_t* w; int N, C; bf16_t* xbar; float* u; };
+struct XbarProj { const crd_sum_t* chan; const crd_sum_t* stats; const float* gamma; const float* beta; const bf16_t* w; int N, C; bf16_t* xbar; float* u; };
 __device__ __forceinline__ void attn_xbar_proj_body(const XbarProj& x, int b) {
   __shared__ float sx[1024];
   const int C = x.C, N = x.N, nt = blockDim.x;
   for (int c = threadIdx.x; c < C; c += nt) {
     float mean, rstd;
     gn_mean_rstd(x.stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
-    const float mc = x.chan[((long long)b * C + c) * 2] / (float)N;
+    const float mc = stat_get(&x.chan[((long long)b * C + c) * 2]) / (float)N;
     const bf16_t q = f2bf(x.gamma[c] * (mc - mean) * rstd + x.beta[c]);
     x.xbar[(long long)b * C + c] = q;
     sx[c] = bf2f(q);
@@ -451,13 +451,13 @@ __global__ __launch_bounds__(1024) void k_attn_scores(const bf16_t* q, const bf1
 }
 
 // xbar[b][c] = mean_n GN(x)[b][n][c] = gamma_c*(mean_n x_c - mu_g)*rstd_g + beta_c   (bf16 out)
-__global__ void k_attn_xbar(const float* chan, const float* stats, const float* gamma, const float* beta, int N, int C,
+__global__ void k_attn_xbar(const crd_sum_t* chan, const crd_sum_t* stats, const float* gamma, const float* beta, int N, int C,
                             bf16_t* xbar) {
   const int b = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float mean, rstd;
     gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
-    float mc = chan[((long long)b * C + c) * 2] / (float)N;
+    float mc = stat_get(&chan[((long long)b * C + c) * 2]) / (float)N;
     xbar[(long long)b * C + c] = f2bf(gamma[c] * (mc - mean) * rstd + beta[c]);
   }
 }
@@ -470,12 +470,12 @@ __global__ __launch_bounds__(TPB) void k_attn_xbar_proj(XbarProj x) { attn_xbar_
 
 // Backward: tb = bf16(t); es[b][ci] = inv_n * sum_co W[co][ci] * tb[b][co], with wt the proj weight in its packed bf16
 // data-gradient form [C][Cpad] (row ci, contiguous over co).
-struct VecBwd { const float* t; const bf16_t* wt; int C, Cpad; float inv_n; bf16_t* tb; float* es; };
+struct VecBwd { const crd_sum_t* t; const bf16_t* wt; int C, Cpad; float inv_n; bf16_t* tb; float* es; };
 __device__ __forceinline__ void attn_vec_bwd_body(const VecBwd& v, int b) {
   __shared__ float st[1024];
   const int C = v.C;
   for (int c = threadIdx.x; c < C; c += TPB) {
-    const bf16_t q = f2bf(v.t[(long long)b * C + c]);
+    const bf16_t q = f2bf(grad_get(&v.t[(long long)b * C + c]));
     v.tb[(long long)b * C + c] = q;
     st[c] = bf2f(q);
   }
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(TPB) void k_attn_out_residual(const float* x, const
 // folded over the wave's pixel lanes with shuffles and over the waves through LDS, then added with one atomic per value
 // and workgroup into PER-SAMPLE rows (chain depth = workgroups of the sample; crd_wgrad_unpack sums the rows of dbp).
 __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp,
-                                                      long long N, int C, int chunk, float* t, float* dbp_rows, float* dS) {
+                                                      long long N, int C, int chunk, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS) {
   extern __shared__ float sm[];  // [2][C]
   const int b = blockIdx.y;
   const int CG = C >> 3;
@@ -576,15 +576,15 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
     __syncthreads();
   }
   for (int i = threadIdx.x; i < C; i += TPB) {
-    atomicAdd(&t[(long long)b * C + i], sm[i]);
-    atomicAdd(&dbp_rows[(long long)b * C + i], sm[C + i]);
+    grad_add(&t[(long long)b * C + i], sm[i]);
+    grad_add(&dbp_rows[(long long)b * C + i], sm[C + i]);
   }
 }
 
 // dq[b][n][c] = scale*dS[b][n]*k[b][idx[b][n][h(c)]][c] ; dk[b][m][c] += scale*dS[b][n]*q[b][n][c]
 __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const bf16_t* k, const float* dS, const short* idx,
                                                          long long N, int M, int heads, int d, float scale, int chunk,
-                                                         bf16_t* dq, float* dk, int use_lds, float* dk_part, VecBwd vec) {
+                                                         bf16_t* dq, crd_sum_t* dk, int use_lds, float* dk_part, VecBwd vec) {
   // LDS (use_lds): the workgroup's pixel chunk -- q rows [chunk][CG] (16-byte granules), g = scale*dS [chunk], and a
   // counting sort of the pixels by (head, arg-max key): count / offset / cursor [heads*M] ints, lists [heads][chunk] shorts
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -649,9 +649,9 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
         float qv[8];
         qv[0] = bf_lo(qraw[u].x); qv[1] = bf_hi(qraw[u].x); qv[2] = bf_lo(qraw[u].y); qv[3] = bf_hi(qraw[u].y);
         qv[4] = bf_lo(qraw[u].z); qv[5] = bf_hi(qraw[u].z); qv[6] = bf_lo(qraw[u].w); qv[7] = bf_hi(qraw[u].w);
-        float* dst = &dk[((long long)b * M + mv[u]) * C + cgv[u] * 8];
+        crd_sum_t* dst = &dk[((long long)b * M + mv[u]) * C + cgv[u] * 8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(dst + j, gv[u] * qv[j]);
+        for (int j = 0; j < 8; ++j) grad_add(dst + j, gv[u] * qv[j]);
       }
     }
   }
@@ -702,23 +702,30 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
     const int m = pr / CG, cg = pr - m * CG;
     const int h = (cg * 8) / d;
     const int beg = off[h * M + m], end = cnt[h * M + m];     // the cursor stopped at the end of the key's list
-    float acc[8];
+    // The order of a key's list is whatever the LDS cursor atomics above produced, so the products are added in fixed
+    // point: the sum is then independent of that order (run-to-run reproducible dK).
+    long long fx[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int j = 0; j < 8; ++j) fx[j] = 0;
     for (int p = beg; p < end; ++p) {
       const int n = lst[p];
       const uint4 u = sq[n * CG + cg];
-      const float g = sg[n];
-      acc[0] += g * bf_lo(u.x); acc[1] += g * bf_hi(u.x); acc[2] += g * bf_lo(u.y); acc[3] += g * bf_hi(u.y);
-      acc[4] += g * bf_lo(u.z); acc[5] += g * bf_hi(u.z); acc[6] += g * bf_lo(u.w); acc[7] += g * bf_hi(u.w);
+      const float g = sg[n] * GRAD_ONE;
+      fx[0] += __float2ll_rn(g * bf_lo(u.x)); fx[1] += __float2ll_rn(g * bf_hi(u.x));
+      fx[2] += __float2ll_rn(g * bf_lo(u.y)); fx[3] += __float2ll_rn(g * bf_hi(u.y));
+      fx[4] += __float2ll_rn(g * bf_lo(u.z)); fx[5] += __float2ll_rn(g * bf_hi(u.z));
+      fx[6] += __float2ll_rn(g * bf_lo(u.w)); fx[7] += __float2ll_rn(g * bf_hi(u.w));
     }
     if (outp) {
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = (float)fx[j] * (1.f / GRAD_ONE);
       store8_f32(outp, (long long)m * C + cg * 8, acc);
     } else {
-      float* dst = &dk[((long long)b * M + m) * C + cg * 8];
+      crd_sum_t* dst = &dk[((long long)b * M + m) * C + cg * 8];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (acc[j] != 0.f) atomicAdd(dst + j, acc[j]);
+        if (fx[j] != 0) fx_add(dst + j, fx[j]);
     }
   }
 }
@@ -738,12 +745,22 @@ __global__ __launch_bounds__(TPB) void k_sum_partials_bf16(const float* part, in
   }
 }
 
+// dst[i] = bf16(value of the fixed-point gradient sum src[i]), 8 elements per thread
+__global__ __launch_bounds__(TPB) void k_gsum_to_bf16(const crd_sum_t* src, bf16_t* dst, long long n8) {
+  for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n8; i += (long long)gridDim.x * TPB) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = grad_get(src + i * 8 + j);
+    store8_bf16(dst, i * 8, v);
+  }
+}
+
 }  // namespace
 
 extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
-                             int32_t flip, void* y, float* stats, const float* in_stats, int32_t in_gmul,
-                             const float* in_gamma, const float* in_beta, const void* red_x, const float* red_stats,
-                             const float* red_gamma, float* red_r, crd_stream_t stream) {
+                             int32_t flip, void* y, crd_sum_t* stats, const crd_sum_t* in_stats, int32_t in_gmul,
+                             const float* in_gamma, const float* in_beta, const void* red_x, const crd_sum_t* red_stats,
+                             const float* red_gamma, crd_sum_t* red_r, crd_stream_t stream) {
   CRD_CHECK_ARG(x && w9 && y, "crd_dwconv3x3: null pointer");
   CRD_CHECK_ARG(!red_x || (red_stats && red_gamma && red_r), "crd_dwconv3x3: incomplete fused-reduce arguments");
   const RedOut red{reinterpret_cast<const bf16_t*>(red_x), red_stats, red_gamma, red_r};
@@ -770,8 +787,8 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
   return CRD_OK;
 }
 
-extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw10,
-                                   int32_t replicas, const float* in_stats, int32_t in_gmul, const float* in_gamma,
+extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, crd_sum_t* dw10,
+                                   int32_t replicas, const crd_sum_t* in_stats, int32_t in_gmul, const float* in_gamma,
                                    const float* in_beta, crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && dw10 && replicas >= 1, "crd_dwconv3x3_wgrad: null pointer / replicas < 1");
   CRD_CHECK_ARG(!in_stats || (in_gamma && in_beta && in_gmul >= 1 && (C / 16) % in_gmul == 0), "crd_dwconv3x3_wgrad: bad input-norm arguments");
@@ -825,7 +842,7 @@ extern "C" int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t 
 }
 
 extern "C" int crd_attn_fwd(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d, float scale,
-                            float* S, int16_t* idx, const float* chan_sums, const float* stats, const float* gamma,
+                            float* S, int16_t* idx, const crd_sum_t* chan_sums, const crd_sum_t* stats, const float* gamma,
                             const float* beta, const void* w_fwd, void* xbar, float* u, crd_stream_t stream) {
   CRD_CHECK_ARG(chan_sums && stats && gamma && beta && w_fwd && xbar && u, "crd_attn_fwd: null pointer");
   const int C = heads * d;
@@ -835,7 +852,7 @@ extern "C" int crd_attn_fwd(const void* q, const void* k, int32_t B, int32_t N, 
                                      reinterpret_cast<bf16_t*>(xbar), u}, "crd_attn_fwd", stream);
 }
 
-extern "C" int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma, const float* beta, int32_t B,
+extern "C" int crd_attn_xbar(const crd_sum_t* chan_sums, const crd_sum_t* stats, const float* gamma, const float* beta, int32_t B,
                              int32_t N, int32_t C, void* xbar, crd_stream_t stream) {
   CRD_CHECK_ARG(chan_sums && stats && gamma && beta && xbar, "crd_attn_xbar: null pointer");
   hipLaunchKernelGGL(k_attn_xbar, dim3(B), dim3(256), 0, as_stream(stream), chan_sums, stats, gamma, beta, N, C,
@@ -844,7 +861,7 @@ extern "C" int crd_attn_xbar(const float* chan_sums, const float* stats, const f
   return CRD_OK;
 }
 
-extern "C" int crd_attn_xbar_proj(const float* chan_sums, const float* stats, const float* gamma, const float* beta, const void* w_fwd,
+extern "C" int crd_attn_xbar_proj(const crd_sum_t* chan_sums, const crd_sum_t* stats, const float* gamma, const float* beta, const void* w_fwd,
                                   int32_t B, int32_t N, int32_t C, void* xbar, float* u, crd_stream_t stream) {
   CRD_CHECK_ARG(chan_sums && stats && gamma && beta && w_fwd && xbar && u, "crd_attn_xbar_proj: null pointer");
   CRD_UNSUPPORTED(C % 16 == 0 && C <= 1024, "crd_attn_xbar_proj: C must be a multiple of 16, <= 1024");
@@ -854,7 +871,7 @@ extern "C" int crd_attn_xbar_proj(const float* chan_sums, const float* stats, co
   return CRD_OK;
 }
 
-extern "C" int crd_attn_vec_bwd(const float* t, const void* w_dgrad, int32_t B, int32_t C, int32_t Cpad, float inv_n, void* tb, float* es,
+extern "C" int crd_attn_vec_bwd(const crd_sum_t* t, const void* w_dgrad, int32_t B, int32_t C, int32_t Cpad, float inv_n, void* tb, float* es,
                                 crd_stream_t stream) {
   CRD_CHECK_ARG(t && w_dgrad && tb && es, "crd_attn_vec_bwd: null pointer");
   CRD_UNSUPPORTED(C % 8 == 0 && C <= 1024 && Cpad >= C && Cpad % 8 == 0, "crd_attn_vec_bwd: C must be a multiple of 8, <= 1024");
@@ -877,7 +894,7 @@ extern "C" int crd_attn_out_residual(const float* x, const float* u, const float
 }
 
 extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
-                                int32_t C, float* t, float* dbp_rows, float* dS, crd_stream_t stream) {
+                                int32_t C, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, crd_stream_t stream) {
   CRD_CHECK_ARG(dx1 && u && S && t && dbp_rows && dS, "crd_attn_out_bwd: null pointer");
   CRD_UNSUPPORTED(C % 8 == 0 && C <= 512, "crd_attn_out_bwd: C must be a multiple of 8 and <= 512");
   static int small = -1;
@@ -921,7 +938,7 @@ extern "C" int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int
 }
 
 static int attn_scores_bwd_launch(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
-                                  int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
+                                  int32_t M, int32_t heads, int32_t d, float scale, void* dq, crd_sum_t* dk, float* dk_partials,
                                   const VecBwd& vec, const char* who, crd_stream_t stream) {
   CRD_CHECK_ARG(q && k && dS && idx && dq && (dk || dk_partials), "%s: null pointer", who);
   CRD_CHECK_ARG(d % 8 == 0, "%s: head dim must be a multiple of 8", who);
@@ -953,13 +970,13 @@ static int attn_scores_bwd_launch(const void* q, const void* k, const float* dS,
 }
 
 extern "C" int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
-                                   int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
+                                   int32_t M, int32_t heads, int32_t d, float scale, void* dq, crd_sum_t* dk, float* dk_partials,
                                    crd_stream_t stream) {
   return attn_scores_bwd_launch(q, k, dS, idx, B, N, M, heads, d, scale, dq, dk, dk_partials, VecBwd{}, "crd_attn_scores_bwd", stream);
 }
 
 extern "C" int crd_attn_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N, int32_t M,
-                            int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials, const float* t,
+                            int32_t heads, int32_t d, float scale, void* dq, crd_sum_t* dk, float* dk_partials, const crd_sum_t* t,
                             const void* w_dgrad, int32_t Cpad, float inv_n, void* tb, float* es, crd_stream_t stream) {
   CRD_CHECK_ARG(t && w_dgrad && tb && es, "crd_attn_bwd: null pointer");
   const int C = heads * d;
@@ -977,5 +994,15 @@ extern "C" int crd_sum_partials_bf16(const float* part, int32_t replicas, int64_
   hipLaunchKernelGGL(k_sum_partials_bf16, dim3((unsigned)nb), dim3(TPB), 0, as_stream(stream), part, replicas, (long long)replica_stride,
                      reinterpret_cast<bf16_t*>(dst), (long long)(n / 8));
   CRD_LAUNCH_CHECK("crd_sum_partials_bf16");
+  return CRD_OK;
+}
+
+extern "C" int crd_gsum_to_bf16(const crd_sum_t* src, void* dst, int64_t n, crd_stream_t stream) {
+  CRD_CHECK_ARG(src && dst && n > 0 && n % 8 == 0, "crd_gsum_to_bf16: bad argument");
+  long long nb = (n / 8 + TPB - 1) / TPB;
+  if (nb > 2048) nb = 2048;
+  hipLaunchKernelGGL(k_gsum_to_bf16, dim3((unsigned)nb), dim3(TPB), 0, as_stream(stream), src, reinterpret_cast<bf16_t*>(dst),
+                     (long long)(n / 8));
+  CRD_LAUNCH_CHECK("crd_gsum_to_bf16");
   return CRD_OK;
 }

@@ -30,7 +30,7 @@ constexpr int BK = 64;
 
 struct GnIn {
   const void* x; int x_f32;               // raw input [B][IH*IW][x_ld] (+ channel offset applied), fp32 or bf16
-  const float* stats; int gmul;           // [B][Cin/16][2] slab sums of x; a group = gmul slabs
+  const crd_sum_t* stats; int gmul;       // [B][Cin/16][2] slab sums of x; a group = gmul slabs
   const float* gamma; const float* beta;  // [Cin]
   float inv_count;                        // 1 / (pixels per sample * channels per group)
   bf16_t* xn; int xn_ld; long long xn_bstride;    // optional store of act(GN(x)) (bf16), nullptr = none
@@ -39,7 +39,7 @@ struct GnIn {
 
 // (scale, shift) of every input channel of sample b -> tab[Cin]
 __device__ __forceinline__ void build_table(const ConvK& a, const GnIn& gi, int b, float2* tab) {
-  const float* stb = gi.stats + (long long)b * (a.Cin >> 4) * 2;
+  const crd_sum_t* stb = gi.stats + (long long)b * (a.Cin >> 4) * 2;
   for (int c = threadIdx.x; c < a.Cin; c += 256) {
     float mean, rstd;
     gn_mean_rstd(stb, ((c >> 4) / gi.gmul) * gi.gmul, gi.gmul, gi.inv_count, mean, rstd);

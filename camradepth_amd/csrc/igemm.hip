@@ -14,7 +14,7 @@ using namespace crdk;
 int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_cap);   // conv3x3.hip
 
 namespace crdk {
-__global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, float* stats) {
+__global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, crd_sum_t* stats) {
   const int g = blockIdx.x, b = blockIdx.y;
   float s = 0.f, ss = 0.f;
   for (int t = threadIdx.x; t < n_tiles; t += 64) {
@@ -22,7 +22,8 @@ __global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, flo
     s += p[0]; ss += p[1];
   }
   s = wave_sum(s); ss = wave_sum(ss);
-  if (threadIdx.x == 0) { stats[((long long)b * G16 + g) * 2] += s; stats[((long long)b * G16 + g) * 2 + 1] += ss; }
+  // fixed summation order (lane-strided, then the butterfly), one workgroup per value: reproducible
+  if (threadIdx.x == 0) { stats[((long long)b * G16 + g) * 2] += to_fx(s, STAT_ONE); stats[((long long)b * G16 + g) * 2 + 1] += to_fx(ss, STAT_ONE); }
 }
 }  // namespace crdk
 

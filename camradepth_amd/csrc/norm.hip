@@ -37,7 +37,7 @@ __device__ __forceinline__ void fold_rows(float* sm, int n, int rows) {
 
 template <int XF>
 __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
-                                                  float* stats, float* chan) {
+                                                  crd_sum_t* stats, crd_sum_t* chan) {
   extern __shared__ float sm[];  // [PL][C][2]: one row of channel sums per pixel lane, folded after the barrier
   const int b = blockIdx.y;
   Map m(C);
@@ -69,14 +69,14 @@ __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int 
   __syncthreads();
   fold_rows(sm, 2 * C, m.PL);
   if (chan)
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) atomicAdd(&chan[(long long)b * C * 2 + i], sm[i]);
+    for (int i = threadIdx.x; i < 2 * C; i += TPB) stat_add(&chan[(long long)b * C * 2 + i], sm[i]);
   if (stats)
     for (int g = threadIdx.x; g < (C >> 4) * 2; g += TPB) {
       int slab = g >> 1, which = g & 1;
       float a = 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) a += sm[(slab * 16 + j) * 2 + which];
-      atomicAdd(&stats[((long long)b * (C >> 4) + slab) * 2 + which], a);
+      stat_add(&stats[((long long)b * (C >> 4) + slab) * 2 + which], a);
     }
 }
 
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(TPB) void k_gn_stats(const void* x, int x_f32, int 
 // k_gn_stats.
 __global__ __launch_bounds__(TPB) void k_attn_out_residual_stats(const float* x, const float* u, const float* S, const float* bp,
                                                                  const float* dp, long long P, int C, int chunk, float* x1,
-                                                                 float* stats) {
+                                                                 crd_sum_t* stats) {
   extern __shared__ float sm[];  // [PL][C][2]
   const int b = blockIdx.y;
   Map m(C);
@@ -129,13 +129,13 @@ __global__ __launch_bounds__(TPB) void k_attn_out_residual_stats(const float* x,
     float a = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) a += sm[(slab * 16 + j) * 2 + which];
-    atomicAdd(&stats[((long long)b * (C >> 4) + slab) * 2 + which], a);
+    stat_add(&stats[((long long)b * (C >> 4) + slab) * 2 + which], a);
   }
 }
 
 template <int XF, int YF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int x_ld, long long P, int C, int chunk,
-                                                  const float* stats, int gmul, const float* gamma, const float* beta,
+                                                  const crd_sum_t* stats, int gmul, const float* gamma, const float* beta,
                                                   int act, const float* mask, void* y, int y_ld, int y_f32, float y_inv_scale,
                                                   void* y2, int y2_ld) {
   const int b = blockIdx.y;
@@ -200,9 +200,9 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
 // r[b][c] = (sum_p g, sum_p g*xhat), g = dy*mask*act'(u)
 template <int XF, int DF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32, int x_ld, const void* dy, int dy_f32,
-                                                       int dy_ld, long long P, int C, int chunk, const float* stats,
+                                                       int dy_ld, long long P, int C, int chunk, const crd_sum_t* stats,
                                                        int gmul, const float* gamma, const float* beta, int act,
-                                                       const float* mask, float* r, float* partial) {
+                                                       const float* mask, crd_sum_t* r, float* partial) {
   extern __shared__ float sm[];  // [PL][C][2]
   const int b = blockIdx.y;
   Map m(C);
@@ -265,24 +265,24 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
   // per channel, was 5 us of this kernel's 13 us floor
   for (int i = threadIdx.x; i < 2 * C; i += TPB) {
     const float v = sm[i];
-    atomicAdd(&r[(long long)b * C * 2 + i], v);
+    grad_add(&r[(long long)b * C * 2 + i], v);
     sm[i] = v * gamma[i >> 1];
   }
   __syncthreads();
   // per-group sums S1 = sum_c gamma_c r0, S2 = sum_c gamma_c r1 (stored after the [B][C][2] block of r)
   const int cpg = 16 * gmul, G = C / cpg;
-  float* rg = r + (long long)gridDim.y * C * 2 + (long long)b * G * 2;
+  crd_sum_t* rg = r + (long long)gridDim.y * C * 2 + (long long)b * G * 2;
   for (int gi = threadIdx.x; gi < 2 * G; gi += TPB) {
     const int grp = gi >> 1, which = gi & 1;
     float acc = 0.f;
     for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) acc += sm[c * 2 + which];
-    atomicAdd(&rg[grp * 2 + which], acc);
+    grad_add(&rg[grp * 2 + which], acc);
   }
 }
 
 // r[b][c][0..1] = sum over workgroup partials; rg[b][grp] += sum_c gamma_c r[b][c]  (64 channels per workgroup)
 __global__ __launch_bounds__(TPB) void k_gn_bwd_finalize(const float* partial, int nblk, int C, int gmul, const float* gamma,
-                                                         float* r, int B) {
+                                                         crd_sum_t* r, int B) {
   __shared__ float sm[4][64][2];
   const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), lane = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
@@ -296,8 +296,8 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_finalize(const float* partial, i
   if (lane == 0 && c < C) {
     s0 = sm[0][threadIdx.x][0] + sm[1][threadIdx.x][0] + sm[2][threadIdx.x][0] + sm[3][threadIdx.x][0];
     s1 = sm[0][threadIdx.x][1] + sm[1][threadIdx.x][1] + sm[2][threadIdx.x][1] + sm[3][threadIdx.x][1];
-    r[((long long)b * C + c) * 2] = s0;
-    r[((long long)b * C + c) * 2 + 1] = s1;
+    r[((long long)b * C + c) * 2] = to_fx(s0, GRAD_ONE);          // fixed summation order above: reproducible
+    r[((long long)b * C + c) * 2 + 1] = to_fx(s1, GRAD_ONE);
     const float g = gamma[c];
     sm[0][threadIdx.x][0] = g * s0; sm[0][threadIdx.x][1] = g * s1;
   }
@@ -309,16 +309,16 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_finalize(const float* partial, i
       float a = 0.f;
       for (int j = 0; j < 16; ++j) a += sm[0][slab * 16 + j][which];
       const int cpg = 16 * gmul;
-      atomicAdd(r + (long long)B * C * 2 + ((long long)b * (C / cpg) + c0 / cpg) * 2 + which, a);
+      grad_add(r + (long long)B * C * 2 + ((long long)b * (C / cpg) + c0 / cpg) * 2 + which, a);
     }
   }
 }
 
 template <int XF, int DF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, int x_ld, const void* dy, int dy_f32,
-                                                      int dy_ld, long long P, int C, int chunk, const float* stats,
+                                                      int dy_ld, long long P, int C, int chunk, const crd_sum_t* stats,
                                                       int gmul, const float* gamma, const float* beta, int act,
-                                                      const float* mask, const float* r, float* dgamma, float* dbeta,
+                                                      const float* mask, const crd_sum_t* r, float* dgamma, float* dbeta,
                                                       void* dx, int dx_f32, int dx_ld, int dx_acc, int B, void* dx2, int dx2_ld,
                                                       const float* scale2) {
   const int b = blockIdx.y;
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
   if (b == 0 && dgamma) {     // parameter gradients: the workgroups of sample 0 share the channels (one workgroup doing all
                               // of them put B x C dependent loads in front of its own pixels: +5 us on the small grids)
     for (int c = blockIdx.x * TPB + threadIdx.x; c < C; c += gridDim.x * TPB) {
-      float g0 = 0.f, g1 = 0.f;
+      long long g0 = 0, g1 = 0;
       for (int bb = 0; bb < B; ++bb) { g0 += r[((long long)bb * C + c) * 2]; g1 += r[((long long)bb * C + c) * 2 + 1]; }
-      dbeta[c] += g0;
-      dgamma[c] += g1;
+      dbeta[c] += (float)g0 * (1.f / GRAD_ONE);
+      dgamma[c] += (float)g1 * (1.f / GRAD_ONE);
     }
   }
   if (!m.active) return;
@@ -360,8 +360,8 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
   const int grp = (c0 >> 4) / gmul;
   const int cpg = 16 * gmul;
   const float inv_m = 1.f / ((float)P * cpg);
-  const float* rg = r + (long long)B * C * 2 + ((long long)b * (C / cpg) + grp) * 2;
-  const float S1 = rg[0] * inv_m, S2 = rg[1] * inv_m;
+  const crd_sum_t* rg = r + (long long)B * C * 2 + ((long long)b * (C / cpg) + grp) * 2;
+  const float S1 = grad_get(rg) * inv_m, S2 = grad_get(rg + 1) * inv_m;
   float mean, rstd;
   gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, inv_m, mean, rstd);
   const float sc2 = (dx2 && scale2) ? scale2[b] : 1.f;
@@ -451,7 +451,7 @@ inline const void* off_ptr(const void* p, int f32, int coff) {
 }  // namespace
 
 extern "C" int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
-                            float* stats, float* chan_sums, crd_stream_t stream) {
+                            crd_sum_t* stats, crd_sum_t* chan_sums, crd_stream_t stream) {
   CRD_CHECK_ARG(x && (stats || chan_sums), "crd_gn_stats: null pointer");
   int rc = check_common("crd_gn_stats", x_ld, x_coff, C, x_f32);
   if (rc) return rc;
@@ -466,7 +466,7 @@ extern "C" int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
 }
 
 extern "C" int crd_attn_out_residual_stats(const float* x, const float* u, const float* S, const float* bp, const float* dp,
-                                           int32_t B, int32_t N, int32_t C, float* x1, float* stats, crd_stream_t stream) {
+                                           int32_t B, int32_t N, int32_t C, float* x1, crd_sum_t* stats, crd_stream_t stream) {
   CRD_CHECK_ARG(x && u && S && bp && x1 && stats, "crd_attn_out_residual_stats: null pointer");
   int rc = check_common("crd_attn_out_residual_stats", C, 0, C, 1);
   if (rc) return rc;
@@ -479,7 +479,7 @@ extern "C" int crd_attn_out_residual_stats(const float* x, const float* u, const
 }
 
 extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
-                            const float* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
+                            const crd_sum_t* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
                             const float* mask, void* y, int32_t y_f32, int32_t y_ld, int32_t y_coff, crd_stream_t stream) {
   CRD_CHECK_ARG(x && stats && gamma && beta && y, "crd_gn_apply: null pointer");
   CRD_CHECK_ARG(gmul >= 1 && (C / 16) % gmul == 0, "crd_gn_apply: bad gmul %d for C=%d", gmul, C);
@@ -505,7 +505,7 @@ extern "C" int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t 
 }
 
 extern "C" int crd_gn_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
-                                const float* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
+                                const crd_sum_t* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
                                 const float* mask, void* y_fp8, int32_t y_ld, int32_t y_coff, float y_scale, void* y_bf16,
                                 int32_t yb_ld, int32_t yb_coff, crd_stream_t stream) {
   CRD_CHECK_ARG(x && stats && gamma && beta && y_fp8 && y_scale > 0.f, "crd_gn_apply_fp8: null pointer / bad scale");
@@ -532,9 +532,9 @@ extern "C" int crd_gn_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int3
 }
 
 extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
-                                 int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
+                                 int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
                                  int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
-                                 float* r, float* scratch, int64_t scratch_capacity, crd_stream_t stream) {
+                                 crd_sum_t* r, float* scratch, int64_t scratch_capacity, crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && stats && gamma && beta && r, "crd_gn_bwd_reduce: null pointer");
   CRD_CHECK_ARG(gmul >= 1 && (C / 16) % gmul == 0, "crd_gn_bwd_reduce: bad gmul");
   CRD_CHECK_ARG(dy_ld % 8 == 0 && dy_coff % 8 == 0, "crd_gn_bwd_reduce: dy_ld/dy_coff must be multiples of 8");
@@ -562,9 +562,9 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
 }
 
 extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
-                                int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
+                                int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
                                 int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
-                                const float* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
+                                const crd_sum_t* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
                                 int32_t dx_coff, int32_t dx_accumulate, void* dx2, int32_t dx2_ld, const float* scale2,
                                 crd_stream_t stream) {
   CRD_CHECK_ARG(x && dy && stats && gamma && beta && r && dx, "crd_gn_bwd_apply: null pointer");

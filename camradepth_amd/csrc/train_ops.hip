@@ -8,21 +8,22 @@ namespace {
 
 constexpr int TPB = 256;
 
-__device__ __forceinline__ void block_atomic3(float a, float b, float c, float* acc) {
+// workgroup sums -> the fixed-point accumulators (order-independent: the loss value and its gradient scale reproduce)
+__device__ __forceinline__ void block_atomic3(float a, float b, float c, crd_sum_t* acc) {
   a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
   __shared__ float sm[3][4];
   const int l = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (l == 0) { sm[0][w] = a; sm[1][w] = b; sm[2][w] = c; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    atomicAdd(acc + 0, sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]);
-    atomicAdd(acc + 1, sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
-    atomicAdd(acc + 2, sm[2][0] + sm[2][1] + sm[2][2] + sm[2][3]);
+    stat_add(acc + 0, sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]);
+    stat_add(acc + 1, sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
+    stat_add(acc + 2, sm[2][0] + sm[2][1] + sm[2][2] + sm[2][3]);
   }
 }
 
 // MaskedSmoothL1Loss / MaskedMSELoss partial sums (loss_funcs.py:40-46, 83-91)
-__global__ __launch_bounds__(TPB) void k_masked_l1_fwd(const float* pred, const float* target, long long n, float* acc) {
+__global__ __launch_bounds__(TPB) void k_masked_l1_fwd(const float* pred, const float* target, long long n, crd_sum_t* acc) {
   float s = 0.f, cnt = 0.f, sq = 0.f;
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
     const float t = target[i];
@@ -39,7 +40,7 @@ __global__ __launch_bounds__(TPB) void k_masked_l1_fwd(const float* pred, const 
 // Trainer.test metrics (runner.py:443-465), per frame f: pred clipped to [0,1] and both scaled by max_depth, ground truth
 // beyond max_distance dropped; acc[f] = (sum |e|, sum e^2, sum |e|/gt, count)
 __global__ __launch_bounds__(TPB) void k_test_metrics(const float* pred, const float* gt, long long n, float max_depth,
-                                                      float max_distance, float* acc) {
+                                                      float max_distance, crd_sum_t* acc) {
   const int f = blockIdx.y;
   const float* p = pred + (long long)f * n;
   const float* g = gt + (long long)f * n;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(TPB) void k_test_metrics(const float* pred, const f
   if (threadIdx.x < 4) {
     float v = 0.f;
     for (int w = 0; w < TPB / 64; ++w) v += sm[w][threadIdx.x];
-    atomicAdd(&acc[f * 4 + threadIdx.x], v);
+    stat_add(&acc[f * 4 + threadIdx.x], v);
   }
 }
 
@@ -92,9 +93,9 @@ __global__ __launch_bounds__(TPB) void k_seg_confusion(const float* logits, cons
   if (threadIdx.x == 0 && hist[C * C]) atomicAdd(&oor[f], (unsigned long long)hist[C * C]);
 }
 
-__global__ __launch_bounds__(TPB) void k_masked_l1_bwd(const float* pred, const float* target, long long n, const float* acc,
+__global__ __launch_bounds__(TPB) void k_masked_l1_bwd(const float* pred, const float* target, long long n, const crd_sum_t* acc,
                                                        const float* gout, float gmul, float* dpred) {
-  const float g = gmul * (gout ? gout[0] : 1.f) / acc[1];
+  const float g = gmul * (gout ? gout[0] : 1.f) / stat_get(acc + 1);
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n; i += (long long)gridDim.x * TPB) {
     const float t = target[i];
     float d = 0.f;
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(TPB) void k_masked_l1_bwd(const float* pred, const 
 
 // Cross entropy over NCHW fp32 logits, labels int64 [B][HW], ignore_index 255 (loss_funcs.py:22,27)
 __global__ __launch_bounds__(TPB) void k_ce_fwd(const float* logits, const long long* labels, int C, long long HW, long long rows,
-                                                float* acc) {
+                                                crd_sum_t* acc) {
   float s = 0.f, cnt = 0.f;
   for (long long r = (long long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long long)gridDim.x * TPB) {
     const long long lab = labels[r];
@@ -127,12 +128,13 @@ __global__ __launch_bounds__(TPB) void k_ce_fwd(const float* logits, const long 
 
 // focal on the scalar mean CE: F=(1-e^-ce)^2 ce ; dF/dce = 2(1-pt)pt ce + (1-pt)^2
 __global__ __launch_bounds__(TPB) void k_ce_focal_bwd(const float* logits, const long long* labels, int C, long long HW,
-                                                      long long rows, const float* acc, const float* gout, float gmul,
+                                                      long long rows, const crd_sum_t* acc, const float* gout, float gmul,
                                                       float* dlogits) {
-  const float ce = acc[0] / acc[1];
+  const float cnt = stat_get(acc + 1);
+  const float ce = stat_get(acc) / cnt;
   const float pt = expf(-ce);
   const float dF = 2.f * (1.f - pt) * pt * ce + (1.f - pt) * (1.f - pt);
-  const float g = gmul * (gout ? gout[0] : 1.f) * dF / acc[1];
+  const float g = gmul * (gout ? gout[0] : 1.f) * dF / cnt;
   for (long long r = (long long)blockIdx.x * TPB + threadIdx.x; r < rows; r += (long long)gridDim.x * TPB) {
     const long long lab = labels[r];
     const long long b = r / HW, p = r - b * HW;
@@ -176,19 +178,39 @@ __global__ __launch_bounds__(TPB) void k_dgn_norm(const float* p, const float* g
   __shared__ float sm[4];
   if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(&norm_sq[t], sm[0] + sm[1] + sm[2] + sm[3]);
+  if (threadIdx.x == 0) norm_sq[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];     // this workgroup's part (plain store)
 }
 
-// per tensor: e <- 0.95 e + 0.05 n ; factor = e > n ? e/(n+1e-8) : 1 ; norm_sq reset for the next step
-__global__ void k_dgn_scalar(float* exp_grad_norm, float* norm_sq, float* factor, const unsigned char* active, int n) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// per tensor: ||g||^2 = its workgroups' parts added in a FIXED order (lane-strided, then the butterfly), so the e > n
+// branch below sees the same norm on every run; e <- 0.95 e + 0.05 n ; factor = e > n ? e/(n+1e-8) : 1.
+// One wave per tensor.  The tensor's first workgroup is found by a 64-ary search in blk2seg (non-decreasing): two or
+// three dependent loads for the ~6000 workgroups of the model.
+__global__ __launch_bounds__(256) void k_dgn_scalar(float* exp_grad_norm, const float* norm_part, float* factor, const unsigned char* active,
+                                                    int n, const long long* seg_off, const int* blk2seg, int n_blocks) {
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (t >= n) return;
-  if (active && !active[t]) { factor[t] = 1.f; norm_sq[t] = 0.f; return; }
-  const float nrm = sqrtf(norm_sq[t]);
-  const float e = 0.95f * exp_grad_norm[t] + 0.05f * nrm;
-  factor[t] = e > nrm ? e / (nrm + 1e-8f) : 1.f;
-  exp_grad_norm[t] = e;
-  norm_sq[t] = 0.f;
+  if (active && !active[t]) { if (lane == 0) factor[t] = 1.f; return; }
+  int lo = 0, len = n_blocks;                      // the first workgroup of tensor t lies in [lo, lo + len]
+  while (len > 0) {
+    const int stride = (len + 63) >> 6;
+    const int pos = lo + lane * stride;
+    const bool less = pos < lo + len && blk2seg[pos] < t;
+    const int k = __popcll(__ballot(less));        // blk2seg is sorted: the probes below t are the first k lanes
+    if (k == 0) break;
+    const int end = lo + len;
+    lo += (k - 1) * stride + 1;
+    len = min(stride - 1, end - lo);
+  }
+  const int cnt = (int)((seg_off[2 * t + 1] - seg_off[2 * t] + OPT_CHUNK - 1) / OPT_CHUNK);
+  float s = 0.f;
+  for (int i = lane; i < cnt; i += 64) s += norm_part[lo + i];
+  s = wave_sum(s);
+  if (lane == 0) {
+    const float nrm = sqrtf(s);
+    const float e = 0.95f * exp_grad_norm[t] + 0.05f * nrm;
+    factor[t] = e > nrm ? e / (nrm + 1e-8f) : 1.f;
+    exp_grad_norm[t] = e;
+  }
 }
 
 __global__ __launch_bounds__(TPB) void k_dgn_update(float* p, const float* g, float* m, float* v, float* pg, const float* factor,
@@ -272,6 +294,8 @@ __global__ __launch_bounds__(TPB) void k_weight_pack(const crd_pack_entry* tab) 
   }
 }
 
+// Copies of a replicated accumulator are added in index order (fixed: reproducible); fixed-point sources (src_sum) are
+// added as integers and converted once.
 __global__ __launch_bounds__(TPB) void k_wgrad_unpack(const crd_unpack_entry* tab, int accumulate) {
   const crd_unpack_entry e = tab[blockIdx.y];
   const long long n = (long long)e.Cout * e.taps * e.Cin_pad;
@@ -282,16 +306,31 @@ __global__ __launch_bounds__(TPB) void k_wgrad_unpack(const crd_unpack_entry* ta
     const int cr = e.cmap ? e.cmap[ci] : (ci < e.Cin_ref ? ci : -1);
     if (cr < 0) continue;
     float* d = e.dst + ((long long)co * e.Cin_ref + cr) * e.taps + tap;
-    // copies of a replicated accumulator: four independent partial sums keep several loads in flight
-    float v = e.src[i], v1 = 0.f, v2 = 0.f, v3 = 0.f;
-    int rp = 1;
-    for (; rp + 3 <= e.replicas; rp += 3) {
-      v1 += e.src[(long long)rp * e.replica_stride + i];
-      v2 += e.src[(long long)(rp + 1) * e.replica_stride + i];
-      v3 += e.src[(long long)(rp + 2) * e.replica_stride + i];
+    float v;
+    if (e.src_sum) {
+      const crd_sum_t* src = reinterpret_cast<const crd_sum_t*>(e.src);
+      long long q = src[i], q1 = 0, q2 = 0, q3 = 0;          // independent chains keep several loads in flight
+      int rp = 1;
+      for (; rp + 3 <= e.replicas; rp += 3) {
+        q1 += src[(long long)rp * e.replica_stride + i];
+        q2 += src[(long long)(rp + 1) * e.replica_stride + i];
+        q3 += src[(long long)(rp + 2) * e.replica_stride + i];
+      }
+      for (; rp < e.replicas; ++rp) q += src[(long long)rp * e.replica_stride + i];
+      v = (float)(q + q1 + q2 + q3) * (1.f / GRAD_ONE);
+    } else {
+      const float* src = reinterpret_cast<const float*>(e.src);
+      float v1 = 0.f, v2 = 0.f, v3 = 0.f;
+      v = src[i];
+      int rp = 1;
+      for (; rp + 3 <= e.replicas; rp += 3) {
+        v1 += src[(long long)rp * e.replica_stride + i];
+        v2 += src[(long long)(rp + 1) * e.replica_stride + i];
+        v3 += src[(long long)(rp + 2) * e.replica_stride + i];
+      }
+      for (; rp < e.replicas; ++rp) v += src[(long long)rp * e.replica_stride + i];
+      v += (v1 + v2) + v3;
     }
-    for (; rp < e.replicas; ++rp) v += e.src[(long long)rp * e.replica_stride + i];
-    v += (v1 + v2) + v3;
     *d = accumulate ? *d + v : v;
   }
 }
@@ -327,7 +366,7 @@ inline int blocks_for(long long total, int cap = 2048) {
 
 }  // namespace
 
-extern "C" int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, float* acc, crd_stream_t stream) {
+extern "C" int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, crd_sum_t* acc, crd_stream_t stream) {
   CRD_CHECK_ARG(pred && target && acc && n > 0, "crd_masked_l1_fwd: bad argument");
   hipLaunchKernelGGL(k_masked_l1_fwd, dim3(blocks_for(n, 512)), dim3(TPB), 0, as_stream(stream), pred, target, (long long)n, acc);
   CRD_LAUNCH_CHECK("crd_masked_l1_fwd");
@@ -335,7 +374,7 @@ extern "C" int crd_masked_l1_fwd(const float* pred, const float* target, int64_t
 }
 
 extern "C" int crd_test_metrics(const float* pred, const float* gt, int32_t frames, int64_t n, float max_depth, float max_distance,
-                                float* acc, crd_stream_t stream) {
+                                crd_sum_t* acc, crd_stream_t stream) {
   CRD_CHECK_ARG(pred && gt && acc && frames > 0 && n > 0, "crd_test_metrics: bad argument");
   hipLaunchKernelGGL(k_test_metrics, dim3(blocks_for(n, 64), frames), dim3(TPB), 0, as_stream(stream), pred, gt, (long long)n,
                      max_depth, max_distance, acc);
@@ -353,7 +392,7 @@ extern "C" int crd_seg_confusion(const float* logits, const int64_t* labels, int
   return CRD_OK;
 }
 
-extern "C" int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const float* acc, const float* gout,
+extern "C" int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const crd_sum_t* acc, const float* gout,
                                  float gmul, float* dpred, crd_stream_t stream) {
   CRD_CHECK_ARG(pred && target && acc && dpred && n > 0, "crd_masked_l1_bwd: bad argument");
   hipLaunchKernelGGL(k_masked_l1_bwd, dim3(blocks_for(n)), dim3(TPB), 0, as_stream(stream), pred, target, (long long)n, acc, gout,
@@ -362,7 +401,7 @@ extern "C" int crd_masked_l1_bwd(const float* pred, const float* target, int64_t
   return CRD_OK;
 }
 
-extern "C" int crd_ce_fwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, float* acc,
+extern "C" int crd_ce_fwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, crd_sum_t* acc,
                           crd_stream_t stream) {
   CRD_CHECK_ARG(logits && labels && acc && B > 0 && C > 0 && HW > 0, "crd_ce_fwd: bad argument");
   const long long rows = (long long)B * HW;
@@ -372,7 +411,7 @@ extern "C" int crd_ce_fwd(const float* logits, const int64_t* labels, int32_t B,
   return CRD_OK;
 }
 
-extern "C" int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, const float* acc,
+extern "C" int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, const crd_sum_t* acc,
                                 const float* gout, float gmul, float* dlogits, crd_stream_t stream) {
   CRD_CHECK_ARG(logits && labels && acc && dlogits && B > 0 && C > 0 && HW > 0, "crd_ce_focal_bwd: bad argument");
   const long long rows = (long long)B * HW;
@@ -393,7 +432,8 @@ extern "C" int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, f
   hipStream_t st = as_stream(stream);
   const long long* so = reinterpret_cast<const long long*>(seg_off);
   hipLaunchKernelGGL(k_dgn_norm, dim3(n_blocks), dim3(TPB), 0, st, p, g, so, blk2seg, blk2chunk, weight_decay, hp_dev, norm_sq);
-  hipLaunchKernelGGL(k_dgn_scalar, dim3(cdiv(n_tensors, 256)), dim3(256), 0, st, exp_grad_norm, norm_sq, factor, active, n_tensors);
+  hipLaunchKernelGGL(k_dgn_scalar, dim3(cdiv(n_tensors, 4)), dim3(256), 0, st, exp_grad_norm, norm_sq, factor, active, n_tensors, so, blk2seg,
+                     n_blocks);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const float step_size = (float)((double)lr * sqrt(bc2) / (bc1 + 1e-8));
   hipLaunchKernelGGL(k_dgn_update, dim3(n_blocks), dim3(TPB), 0, st, p, g, exp_avg, exp_avg_sq, prev_grad, factor, so, blk2seg,

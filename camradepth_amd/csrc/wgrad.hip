@@ -7,7 +7,8 @@
 // read from the row-major [pixel][channel] LDS tiles with ds_read_b64_tr_b16 (the gfx950
 // transposing LDS read: a 16-lane group fetches a 4x16 block and lane i receives column i),
 // which costs the same as a plain read and removes any explicit transpose.  The pixel range is
-// split across workgroups (split-K); partial tiles are combined with fp32 atomics.
+// split across workgroups (split-K); partial tiles meet in a 64-bit fixed-point accumulator (integer
+// atomics: the sum does not depend on the order of arrival, see crd_sum_t).
 #include <stdlib.h>
 #include "common.h"
 
@@ -23,8 +24,8 @@ struct WgK {
   long long P;           // B*OH*OW
   long long x_bytes, dy_bytes;
   int chunk;             // pixels per split (multiple of 32)
-  float* dw;
-  float* dbias;          // or nullptr; accumulated by the workgroups of the first kf tile
+  crd_sum_t* dw;         // fixed-point sums (CRD_GRAD_FRAC_BITS): split-K partial tiles meet here in any order
+  crd_sum_t* dbias;      // or nullptr; accumulated by the workgroups of the first kf tile
   int dbg;               // developer experiments (CRD_DBG): 1 skip output atomics, 2 skip loads
 };
 
@@ -171,12 +172,9 @@ __device__ __forceinline__ void wgrad_tile(const WgK& a, const int bx, const int
     if (kt + 1 < nK) lstore(cur ^ 1);
     __syncthreads();
   }
-  // The grouped kernel loads its descriptor from memory, so the compiler no longer knows that dw / dbias are global
-  // pointers and would emit FLAT atomics; say so explicitly.
-  typedef __attribute__((address_space(1))) float gfloat;
-  gfloat* gdw = (gfloat*)a.dw;
-  gfloat* gdb = (gfloat*)a.dbias;
-  if (do_bias && m0 + t < a.Cout) __hip_atomic_fetch_add(gdb + m0 + t, bsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // (fx_add casts to address space 1: the grouped kernel loads its descriptor from memory, so the compiler no longer knows
+  // that dw / dbias are global pointers and would emit FLAT atomics)
+  if (do_bias && m0 + t < a.Cout) grad_add(a.dbias + m0 + t, bsum);
 
   // D layout (16x16): col = lane&15 -> kf, row = (lane>>4)*4 + r -> co
 #pragma unroll
@@ -187,7 +185,7 @@ __device__ __forceinline__ void wgrad_tile(const WgK& a, const int bx, const int
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = m0 + (wm * TMc + i) * 16 + (l >> 4) * 4 + r;
-        if (co < a.Cout && kfo < a.Ktot && (!(a.dbg & 1) || acc[i][j][r] == 123.456f)) __hip_atomic_fetch_add(gdw + (long long)co * a.Ktot + kfo, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (co < a.Cout && kfo < a.Ktot && (!(a.dbg & 1) || acc[i][j][r] == 123.456f)) grad_add(a.dw + (long long)co * a.Ktot + kfo, acc[i][j][r]);
       }
     }
 }
@@ -205,19 +203,6 @@ __global__ __launch_bounds__(256) void k_wgrad_grouped(const WgK* __restrict__ p
   const int4 it = items[blockIdx.x];
   const WgK a = probs[it.x];
   wgrad_tile<WMc, WNc, TMc, TNc>(a, it.y, it.z, it.w);
-}
-
-// dbias[c] += sum over rows of a bf16 [rows][C] slice
-__global__ __launch_bounds__(256) void k_colsum_bf16(const bf16_t* x, int ld, long long rows, int C, float* out) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rl = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < C)
-    for (long long r = (long long)blockIdx.y * 4 + rl; r < rows; r += (long long)gridDim.y * 4) s += bf2f(x[r * ld + c]);
-  __shared__ float sm[256];
-  sm[threadIdx.x] = s;
-  __syncthreads();
-  if (rl == 0 && c < C) atomicAdd(out + c, sm[threadIdx.x] + sm[threadIdx.x + 64] + sm[threadIdx.x + 128] + sm[threadIdx.x + 192]);
 }
 
 // Split-K plan: sets k.chunk, returns the number of splits.  `want` = splits that would fill the chip, `min_steps` =

@@ -24,7 +24,7 @@ struct Wg3K {
   int rows_per_wg;                               // strip rows per workgroup
   long long total_rows;                          // B * strips_x * H
   long long x_bytes, dy_bytes;
-  float* dw; float* dbias;
+  crd_sum_t* dw; crd_sum_t* dbias;
   float* dw_part;                                // per-row-split copies [gridDim.x][Cout][9][Cin] (plain stores) or nullptr -> atomics into dw
 };
 
@@ -176,12 +176,15 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
       // a wave whose 16 x NT input channels all lie beyond Cin (the tail chunk of Cin = 136 / 144 / 240: 3, 3, 1 of the 4
       // ci-waves) only takes part in the DMA and the barriers: its MFMAs would multiply zeros -- at the chip's power limit
       // they still cost time
-      if (c0 + wci * NT * 16 >= a.Cin) continue;
+      // (the dy column sums of the bias gradient below are still theirs to add: threads t < Cout of chunk 0)
+      const bool mfma_on = c0 + wci * NT * 16 < a.Cin;
+      if (!mfma_on && !do_bias) continue;
 #pragma unroll
       for (int rr = 0; rr < RPS; ++rr) {
         const int yy = y + rr;
         if (rr > 0 && yy >= y1) break;                 // odd segment length: the last step has one row
         const bf16_t* yrow = sY + (yy % YSr) * 32 * COT;
+        if (mfma_on) {
         bf16x8 af[TCO];
 #pragma unroll
         for (int i = 0; i < TCO; ++i) {
@@ -206,6 +209,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
             }
           }
         }
+        }   // mfma_on
         if (do_bias) {
 #pragma unroll 8
           for (int r = 0; r < 32; ++r) bsum += bf2f(yrow[r * COT + ((((t >> 4) ^ swz_y<COT>(r)) << 4) | (t & 15))]);
@@ -232,11 +236,11 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
             // every (row split, chunk) workgroup owns its block of its split's copy: plain stores, the caller sums the
             // copies (crd_wgrad_unpack); otherwise Cout x 9 x Cin atomics per row split (19 M per launch, ~0.1 ms)
             if (a.dw_part) a.dw_part[(long long)blockIdx.x * a.Cout * Ktot + off] = acc[tp][i][j][r];
-            else atomicAdd(a.dw + off, acc[tp][i][j][r]);
+            else grad_add(a.dw + off, acc[tp][i][j][r]);
           }
         }
       }
-  if (do_bias) atomicAdd(a.dbias + t, bsum);
+  if (do_bias) grad_add(a.dbias + t, bsum);
 }
 
 // row splits (workgroups along x) and strip rows per workgroup.  cap > 0 (the number of partial copies the caller

@@ -60,6 +60,7 @@ DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (sprea
 HEAD_ROWS = 64        # same for Depth_Activation.conv_2 (2048 workgroups x 289 sums)
 
 BF16, F32 = torch.bfloat16, torch.float32
+SUM = torch.int64    # crd_sum_t: the 64-bit fixed-point accumulators every multi-workgroup "+=" goes through (include/camradepth_hip.h)
 
 
 def rup(x, m=8):
@@ -222,20 +223,20 @@ class Plan:
         return PM(self.new((self.B, H * W, ld or C_), dtype), C_, H, W)
 
     def zf(self, *shape):
-        """fp32 scratch that must be zero at the start of every forward."""
+        """crd_sum_t accumulators (GroupNorm / channel sums) that must be zero at the start of every forward."""
         v = _Lazy(shape)
         self._zf_views.append(v)
         return v
 
     def zb(self, *shape):
-        """fp32 scratch that must be zero at the start of every backward."""
+        """crd_sum_t accumulators (gradient sums) that must be zero at the start of every backward."""
         v = _Lazy(shape)
         self._zb_views.append(v)
         return v
 
     def _materialise(self, views):
         n = sum(v.numel for v in views)
-        arena = torch.zeros(max(n, 1), dtype=F32, device=self.dev)
+        arena = torch.zeros(max(n, 1), dtype=SUM, device=self.dev)
         off = 0
         for v in views:
             v.t = arena[off:off + v.numel].view(v.shape)
@@ -335,8 +336,14 @@ class Plan:
         return op
 
     def wgrad(self, lst, x, dy, cw, k, stride, pad, OH, OW, dbias=None, cin=None):
+        """dbias: NAME of the bias parameter.  Weight and bias gradients are accumulated as crd_sum_t (order-independent
+        integer atomics) in backward scratch; the segment's crd_wgrad_unpack converts and adds them into the flat gradient."""
         if cw.frozen:                 # no trainable parameter behind this launch
             return
+        if dbias is not None:
+            rows = self.zb(cw.cout)
+            self.row_grads.append((dbias, cw.cout, rows, 1, cw.tag, 0, cw.cout))
+            dbias = rows
         spec = dict(wg=True, x=x, dy=dy, cw=cw, k=k, stride=stride, pad=pad, OH=OH, OW=OW, dbias=dbias,
                     cin=cin if cin is not None else x.C)
         stream3 = k == 3 and stride == 1 and OW >= 32 and OH >= 8
@@ -432,7 +439,7 @@ class Plan:
             d.accumulate, d.stats = sp["accumulate"], P(sp["stats"])
             if sp.get("stats") is not None and persistent_conv3(sp, self.B):
                 # GroupNorm sums of the persistent 3x3 kernel: per-(tile, wave) partial rows + a finalize launch
-                need = self.B * -(-sp["OH"] * sp["OW"] // 64) * (sp["cout"] // 16) * 2
+                need = self.B * -(-sp["OW"] // 32) * -(-sp["OH"] // 16) * 8 * (sp["cout"] // 16) * 2
                 if self.stats_scratch is None or self.stats_scratch.numel() < need:
                     self.stats_scratch = self.new((need,), F32)      # produced and consumed inside one crd_conv_igemm call
                 d.stats_partial, d.stats_partial_capacity = self.stats_scratch.data_ptr(), self.stats_scratch.numel()
@@ -592,7 +599,7 @@ class Plan:
             grp = []
             draw = self.act(Cs, Hs, Ws)
             self.gn_bwd(grp, raw, st, 1, pe + ".norm", 0, None, DX, draw)
-            self.wgrad(grp, src, draw, cw, k, stride, k // 2, Hs, Ws, dbias=self.g(pe + ".proj.bias"))
+            self.wgrad(grp, src, draw, cw, k, stride, k // 2, Hs, Ws, dbias=pe + ".proj.bias")
             if s > 0:
                 self.conv(grp, self.conv_desc(draw, ("dgrad", cw), src.C, k, stride, k // 2, src.H, src.W, d_enc_out[s - 1],
                                               gather=1), region=("dxs", s - 1, 0, src.C))
@@ -740,7 +747,7 @@ class Plan:
             self._emit(grp, "crd_head_conv2_bwd_data", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t])
             if not self.is_frozen(name + ".conv_2.weight", name + ".conv_2.bias"):
                 self._emit(grp, "crd_head_conv2_wgrad", [gd.t, add[0], add[1], add[2], A.t, B, Hj, Wj, rows, HEAD_ROWS]).stream = LATE
-            self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=self.g(name + ".conv_1.bias"))
+            self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=name + ".conv_1.bias")
             self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
                       region=("ds", id(dsrc), 0, 128))
             self._push(grp)
@@ -802,7 +809,7 @@ class Plan:
                 DL = self.act(rup(cfg.num_classes), H, W)
                 grp = []
                 self._emit(grp, "crd_nchw_to_pm", [self.seg_grad_in, B, cfg.num_classes, H, W, DL.t, DL.ld, 0, DL.ld])
-                self.wgrad(grp, SF1, DL, cw, 3, 1, 1, H, W, dbias=self.g("seg_conv_final.bias"))
+                self.wgrad(grp, SF1, DL, cw, 3, 1, 1, H, W, dbias="seg_conv_final.bias")
                 self.conv(grp, self.conv_desc(DL, ("dgrad", cw), 128, 3, 1, 1, H, W, dSF1, gather=1, cin=DL.ld),
                           region=("ds", id(dSF1), 0, 128))
                 self._push(grp)
@@ -934,7 +941,7 @@ class Plan:
             dh_out = (DH, dp)        # d(X2) arrives in bf16 from the next block's norm1 backward
         else:
             self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
-        self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc2.bias"))
+        self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=ml + ".fc2.bias")
         # fc2's data gradient also runs the reduce phase of Mlp.norm2's backward on its own output (FUSE_GN_RED)
         r2 = self.zb(B * hid * 2 + B * (hid // (16 * ratio)) * 2) if hid > 160 and (FUSE_GN_RED or N <= FUSE_GN_RED_MAXPIX) else None
         red = None if r2 is None else (H2, sth2, self.p(ml + ".norm2.weight"), self.p(ml + ".norm2.bias"), ratio, 1, r2)
@@ -951,7 +958,7 @@ class Plan:
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None,
                                         H1.t, sth1, self.p(ml + ".norm1.weight"), r1])
         self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2, r=r1)             # in place: d(H1)
-        self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=self.g(ml + ".fc1.bias"))
+        self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=ml + ".fc1.bias")
         self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1))
         self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1)              # DX = d(X1)
         # attention branch
@@ -976,26 +983,26 @@ class Plan:
             dK = self.zb(B, M, Cs)
             self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None] + vec)
         self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
-        self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".q.bias"))
+        self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=a + ".q.bias")
         self.conv(g, self.conv_desc(DQ, ("dgrad", cq), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, bias=Es.t, bias_bstride=Cs))
         DKb = self.act(Cs, Hs // sr, Ws // sr)
         if dK is None:
             self._emit(g, "crd_sum_partials_bf16", [self.attn_parts, nparts, B * M * Cs, DKb.t, B * M * Cs])
         else:
-            self._emit(g, "crd_f32_to_bf16_rows", [dK, Cs, DKb.t, Cs, 0, B * M, Cs, None, 1, None, 0, 0])
+            self._emit(g, "crd_gsum_to_bf16", [dK, DKb.t, B * M * Cs])
         if sr > 1:
-            self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=self.g(a + ".k.bias"))
+            self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=a + ".k.bias")
             DKR = self.act(Cs, Hs // sr, Ws // sr)
             # k's data gradient also runs the reduce phase of attn.norm's backward on its own output (a launch less)
             rk = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if FUSE_STATS else None
             redk = None if rk is None else (KR, stk, self.p(a + ".norm.weight"), self.p(a + ".norm.bias"), 1, 0, rk)
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs // sr, Ws // sr, DKR, gather=1, red=redk))
             self.gn_bwd(g, KR, stk, 1, a + ".norm", 0, None, DKR, DKR, r=rk)
-            self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=self.g(a + ".sr.bias"))
+            self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=a + ".sr.bias")
             self.conv(g, self.conv_desc(DKR, ("scatter", csr), sr * sr * Cs, 1, 1, 0, Hs // sr, Ws // sr, DXN, out_mode=1,
                                         patch_k=sr, patch_c=Cs, accumulate=1))
         else:
-            self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=self.g(a + ".k.bias"))
+            self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=a + ".k.bias")
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=1))
         self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1,                # DX = d(X)
                     dx2=dh_prev[0] if dh_prev else None, scale2=dh_prev[1] if dh_prev else None)
@@ -1040,7 +1047,7 @@ class Plan:
             e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad, cw.cout_pad, 0
             entries.append(e)
             max_elems = max(max_elems, cw.cout * cw.taps * cw.cin_pad, cw.cin_pad * cw.taps * cw.cout_pad)
-            # weight-gradient destination: direct into the flat gradient for identity layouts, else scratch + unpack.
+            # weight-gradient destination: a crd_sum_t scratch block (order-independent integer atomics) + unpack.
             # The streaming 3x3 kernel splits the pixels S ways; each split stores its block into its own copy (no
             # atomics, nothing to zero) and the segment's unpack kernel sums the copies.
             if cw.frozen:                  # no weight-gradient launch was recorded: nothing to accumulate or un-pack
@@ -1057,8 +1064,6 @@ class Plan:
                 cw.dw_parts = self.new((cw.dw_S, cw.cout, cw.taps, cw.cin_pad), F32)
                 cw.dw = cw.dw_parts
                 unpack.append(cw)
-            elif cw.identity:
-                cw.dw = self.g(cw.name + ".weight")
             else:
                 cw.dw = self.zb(cw.cout, cw.taps, cw.cin_pad)
                 unpack.append(cw)
@@ -1088,15 +1093,17 @@ class Plan:
                 u.dst = self.g(cw.name + ".weight").data_ptr()
                 u.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
                 u.Cout, u.Cin_ref, u.taps, u.Cin_pad = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad
-                if cw.dw_parts is not None:
+                if cw.dw_parts is not None:          # fp32 partial copies (plain stores), added in index order
                     u.replicas, u.replica_stride = cw.dw_S, cw.cout * cw.taps * cw.cin_pad
+                else:
+                    u.src_sum = 1
                 nel = cw.cout * cw.taps * cw.cin_pad
             else:
                 name, hid, dw10, _, which = dwt
                 if isinstance(which, tuple):           # per-sample rows of a vector gradient
-                    u.src, u.dst, u.cmap = dw10.t.data_ptr() + 4 * which[2], self.g(name).data_ptr(), None
+                    u.src, u.dst, u.cmap = dw10.t.data_ptr() + 8 * which[2], self.g(name).data_ptr(), None
                     u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, 1, hid
-                    u.replicas, u.replica_stride = which[1], which[3]
+                    u.replicas, u.replica_stride, u.src_sum = which[1], which[3], 1
                     nel = hid
                     lo, hi, mx = self.unpack_ranges.get(order[seg_i], (len(uentries), len(uentries), 1))
                     self.unpack_ranges[order[seg_i]] = (lo, len(uentries) + 1, max(mx, nel))
@@ -1104,10 +1111,10 @@ class Plan:
                     max_unpack = max(max_unpack, nel)
                     continue
                 taps = 9 if which == "weight" else 1
-                u.src = dw10.t.data_ptr() + (0 if which == "weight" else 9 * hid * 4)
+                u.src = dw10.t.data_ptr() + (0 if which == "weight" else 9 * hid * 8)
                 u.dst, u.cmap = self.g(name + "." + which).data_ptr(), None
                 u.Cout, u.Cin_ref, u.taps, u.Cin_pad = 1, hid, taps, hid
-                u.replicas, u.replica_stride = DW_REPLICAS, 10 * hid
+                u.replicas, u.replica_stride, u.src_sum = DW_REPLICAS, 10 * hid, 1
                 nel = taps * hid
             lo, hi, mx = self.unpack_ranges.get(order[seg_i], (len(uentries), len(uentries), 1))
             self.unpack_ranges[order[seg_i]] = (lo, len(uentries) + 1, max(mx, nel))

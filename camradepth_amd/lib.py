@@ -68,7 +68,7 @@ class UnpackEntry(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("dst", C.c_void_p), ("cmap", C.c_void_p),
         ("Cout", C.c_int32), ("Cin_ref", C.c_int32), ("taps", C.c_int32), ("Cin_pad", C.c_int32),
-        ("replicas", C.c_int32), ("reserved", C.c_int32), ("replica_stride", C.c_int64),
+        ("replicas", C.c_int32), ("src_sum", C.c_int32), ("replica_stride", C.c_int64),
     ]
 
 
@@ -106,7 +106,7 @@ _SIGS = {
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiipipp",
     "crd_dwconv3x3": "piiiippipppippppppp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",
     "crd_attn_scores": "ppiiiiifppp", "crd_attn_fwd": "ppiiiiifpppppppppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_xbar_proj": "pppppiiippp", "crd_attn_vec_bwd": "ppiiifppp", "crd_attn_out_residual": "pppppiiipp", "crd_attn_out_residual_stats": "pppppiiippp",
-    "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_bwd": "ppppiiiiifpppppifppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp",
+    "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_bwd": "ppppiiiiifpppppifppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp", "crd_gsum_to_bf16": "pplp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_fp8": "piiiiiipiifpiip", "crd_gn_apply_fp8": "piiiiiipippippiifpiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
     "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiiip", "crd_scale_f32": "pplfp",
     "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp", "crd_head_conv2_fwd": "pppiiippiip", "crd_head_conv2_bwd": "ppiippiiippip", "crd_head_conv2_bwd_data": "ppiippiiipp", "crd_head_conv2_wgrad": "ppiipiiipip",
@@ -119,6 +119,21 @@ _SIGS = {
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "L": C.c_uint64, "f": C.c_float}
 EXPORTS = list(_SIGS)
+
+
+# crd_sum_t (include/camradepth_hip.h): 64-bit fixed-point accumulators, value = integer * 2^-FRAC_BITS
+STAT_FRAC_BITS, GRAD_FRAC_BITS = 20, 44
+SUM_DTYPE = torch.int64
+
+
+def stat_value(t):
+    """float64 value of forward-statistic / loss sums (CRD_STAT_FRAC_BITS)."""
+    return t.double() * 2.0 ** -STAT_FRAC_BITS
+
+
+def grad_value(t):
+    """float64 value of gradient sums (CRD_GRAD_FRAC_BITS)."""
+    return t.double() * 2.0 ** -GRAD_FRAC_BITS
 
 
 def check(rc, what=""):

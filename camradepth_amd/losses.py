@@ -25,13 +25,14 @@ class _MaskedL1(torch.autograd.Function):
     def forward(ctx, pred, target, mode):
         lb = L.load()
         pred_c, target_c = pred.contiguous().float(), target.contiguous().float()
-        acc = torch.zeros(4, dtype=torch.float32, device=pred.device)
+        acc = torch.zeros(4, dtype=L.SUM_DTYPE, device=pred.device)     # crd_sum_t: order-independent, exact under all-reduce
         L.check(lb.crd_masked_l1_fwd(pred_c.data_ptr(), target_c.data_ptr(), pred_c.numel(), acc.data_ptr(), L.stream()),
                 "crd_masked_l1_fwd")
         _allreduce_acc(acc)
         ctx.save_for_backward(pred_c, target_c, acc)
         ctx.mode = mode
-        return (acc[0] if mode == "smooth_l1" else acc[2]) / acc[1]
+        a = L.stat_value(acc)
+        return ((a[0] if mode == "smooth_l1" else a[2]) / a[1]).float()
 
     @staticmethod
     def backward(ctx, gout):
@@ -71,11 +72,12 @@ class _Focal(torch.autograd.Function):
         tg = target.contiguous().to(torch.int64)
         B, Cc = lg.shape[0], lg.shape[1]
         HW = lg.numel() // (B * Cc)
-        acc = torch.zeros(4, dtype=torch.float32, device=lg.device)
+        acc = torch.zeros(4, dtype=L.SUM_DTYPE, device=lg.device)
         L.check(lb.crd_ce_fwd(lg.data_ptr(), tg.data_ptr(), B, Cc, HW, acc.data_ptr(), L.stream()), "crd_ce_fwd")
         _allreduce_acc(acc)
         ctx.save_for_backward(lg, tg, acc)
-        ce = acc[0] / acc[1]
+        a = L.stat_value(acc)
+        ce = (a[0] / a[1]).float()
         pt = torch.exp(-ce)
         return (1 - pt) ** 2 * ce
 

@@ -24,13 +24,13 @@ class DepthMetrics:
         gt = gt.detach().contiguous().float()
         frames = pred.shape[0]
         n = pred.numel() // frames
-        acc = torch.zeros(frames, 4, device=pred.device)
+        acc = torch.zeros(frames, 4, dtype=L.SUM_DTYPE, device=pred.device)      # crd_sum_t (reproducible sums)
         L.check(L.load().crd_test_metrics(pred.data_ptr(), gt.data_ptr(), frames, n, self.max_depth, self.max_distance,
                                           acc.data_ptr(), L.stream()), "crd_test_metrics")
         self.rows.append(acc)
 
     def per_frame(self):
-        a = torch.cat(self.rows).cpu()
+        a = L.stat_value(torch.cat(self.rows).cpu())
         out = []
         for sa, sq, sr, cnt in a.tolist():
             out.append(None if cnt == 0 else {"MAE": sa / cnt, "RMSE": math.sqrt(sq / cnt), "REL": sr / cnt})

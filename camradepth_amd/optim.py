@@ -56,7 +56,7 @@ class diffGradNorm(Optimizer):
         st["flat_g"] = torch.zeros(span, dtype=torch.float32, device=dev)
         st["m"], st["v"], st["pg"] = (torch.zeros(span, dtype=torch.float32, device=dev) for _ in range(3))
         nt = len(ps)
-        st["egn"], st["nsq"], st["fac"] = (torch.zeros(nt, dtype=torch.float32, device=dev) for _ in range(3))
+        st["egn"], st["fac"] = (torch.zeros(nt, dtype=torch.float32, device=dev) for _ in range(2))
         seg = torch.tensor([[o, o + p.numel()] for o, p in zip(offs, ps)], dtype=torch.int64)
         # kernel wants seg_off[t], seg_off[t+1]: store begin/end pairs as 2*t, 2*t+1 and index tensors by 2*t
         b2s, b2c = [], []
@@ -65,6 +65,7 @@ class diffGradNorm(Optimizer):
                 b2s.append(t)
                 b2c.append(c)
         st["seg"], st["nblk"] = seg.to(dev), len(b2s)
+        st["nsq"] = torch.zeros(len(b2s), dtype=torch.float32, device=dev)      # per-workgroup parts of ||g||^2
         st["b2s"] = torch.tensor(b2s, dtype=torch.int32, device=dev)
         st["b2c"] = torch.tensor(b2c, dtype=torch.int32, device=dev)
         st["active"] = torch.ones(nt, dtype=torch.uint8, device=dev)

@@ -116,13 +116,13 @@ class TrainStep:
         self.gt = {"full": torch.zeros((B, 1, H, W), device=self.dev), "half": torch.zeros((B, 1, H // 2, W // 2), device=self.dev),
                    "quarter": torch.zeros((B, 1, H // 4, W // 4), device=self.dev),
                    "seg": torch.zeros((B, H, W), dtype=torch.int64, device=self.dev)}
-        self.acc = torch.zeros(16, device=self.dev)     # 4 x (sum, count, sum sq, -) for full/half/quarter/ce
+        self.acc = torch.zeros(16, dtype=L.SUM_DTYPE, device=self.dev)     # crd_sum_t: 4 x (sum, count, sum sq, -) for full/half/quarter/ce
         self.update_interval = update_interval
         # optimizer state over the flat buffers
         n = model.flat.numel()
         self.m, self.v, self.pg = (torch.zeros(n, device=self.dev) for _ in range(3))
         nt = len(model._names)
-        self.egn, self.nsq, self.fac = (torch.zeros(nt, device=self.dev) for _ in range(3))
+        self.egn, self.fac = (torch.zeros(nt, device=self.dev) for _ in range(2))
         seg, b2s, b2c = [], [], []
         for t, (name, o) in enumerate(zip(model._names, model._offsets)):
             numel = model._param(name).numel()
@@ -134,6 +134,7 @@ class TrainStep:
         self.b2s = torch.tensor(b2s, dtype=torch.int32, device=self.dev)
         self.b2c = torch.tensor(b2c, dtype=torch.int32, device=self.dev)
         self.nt, self.nblk = nt, len(b2s)
+        self.nsq = torch.zeros(self.nblk, device=self.dev)        # per-workgroup parts of ||g||^2 (summed in a fixed order)
         trainable = torch.tensor([1 if model._param(n_).requires_grad else 0 for n_ in model._names], dtype=torch.uint8)
         self.frozen_names = [n_ for n_ in model._names if not model._param(n_).requires_grad]
         self.trainable_mask = trainable.to(self.dev) if self.frozen_names else None
@@ -174,22 +175,22 @@ class TrainStep:
         p.forward()
         for i, (j, key) in enumerate(((5, "full"), (4, "half"), (3, "quarter"))):
             pred, tgt = p.out_depth[j].t, self.gt[key]
-            L.check(self.lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), pred.numel(), self.acc.data_ptr() + 16 * i, st()),
+            L.check(self.lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), pred.numel(), self.acc.data_ptr() + 32 * i, st()),
                     "crd_masked_l1_fwd")
         if self.sup:
             L.check(self.lib.crd_ce_fwd(p.seg_out.data_ptr(), self.gt["seg"].data_ptr(), self.B, self.model.cfg.num_classes,
-                                        self.H * self.W, self.acc.data_ptr() + 48, st()), "crd_ce_fwd")
+                                        self.H * self.W, self.acc.data_ptr() + 96, st()), "crd_ce_fwd")
 
     def _loss_backward(self):
         p, st = self.plan, L.stream
         scale = 1.0 / sum(LOSS_W) / self.update_interval
         for i, (j, key) in enumerate(((5, "full"), (4, "half"), (3, "quarter"))):
             pred, tgt, d = p.out_depth[j].t, self.gt[key], p.out_depth[("grad", j)].t
-            L.check(self.lib.crd_masked_l1_bwd(pred.data_ptr(), tgt.data_ptr(), pred.numel(), self.acc.data_ptr() + 16 * i, None,
+            L.check(self.lib.crd_masked_l1_bwd(pred.data_ptr(), tgt.data_ptr(), pred.numel(), self.acc.data_ptr() + 32 * i, None,
                                                LOSS_W[i] * scale, d.data_ptr(), st()), "crd_masked_l1_bwd")
         if self.sup:
             L.check(self.lib.crd_ce_focal_bwd(p.seg_out.data_ptr(), self.gt["seg"].data_ptr(), self.B, self.model.cfg.num_classes,
-                                              self.H * self.W, self.acc.data_ptr() + 48, None, LOSS_W[3] * scale,
+                                              self.H * self.W, self.acc.data_ptr() + 96, None, LOSS_W[3] * scale,
                                               p.seg_grad_in.data_ptr(), st()), "crd_ce_focal_bwd")
 
     def _optimizer(self, key=None):
@@ -197,7 +198,7 @@ class TrainStep:
         m = self.model
         b0, nb, mask = (0, self.nblk, self.trainable_mask) if key is None else self.opt_parts[key]
         L.check(self.lib.crd_diffgradnorm_step(m.flat.data_ptr(), m.flat_grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr(),
-                                               self.pg.data_ptr(), self.egn.data_ptr(), self.nsq.data_ptr(), self.fac.data_ptr(),
+                                               self.pg.data_ptr(), self.egn.data_ptr(), self.nsq.data_ptr() + 4 * b0, self.fac.data_ptr(),
                                                self.seg.data_ptr(), self.b2s.data_ptr() + 4 * b0, self.b2c.data_ptr() + 4 * b0,
                                                self.nt, nb, None if mask is None else mask.data_ptr(),
                                                0.0, 0.0, 0.0, 0.0, 0.0, 1, self.hp.data_ptr(), L.stream()),
@@ -377,7 +378,7 @@ class TrainStep:
 
     def losses(self):
         """Host view of the last iteration's loss terms (synchronises)."""
-        a = self.acc.cpu()
+        a = L.stat_value(self.acc.cpu())
         full, half, quarter = (float(a[4 * i] / a[4 * i + 1]) for i in range(3))
         rmse = math.sqrt(float(a[2] / a[1]))
         seg = 0.0

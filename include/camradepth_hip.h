@@ -33,6 +33,20 @@ typedef void* crd_stream_t; /* hipStream_t */
 #define CRD_E_UNSUPPORTED (-2) /* shape outside what the kernels implement */
 #define CRD_E_LAUNCH (-3)      /* HIP launch failure */
 
+/* Order-independent sums.  Every accumulator that several workgroups add into -- GroupNorm statistics, per-channel sums,
+ * loss / metric sums, the reduce sums of the GroupNorm backward, weight- and bias-gradient accumulators -- is a 64-bit
+ * FIXED-POINT integer added to with integer atomics: integer addition is associative, so the result does not depend on
+ * the order in which the workgroups arrive and two runs on the same inputs are bit-identical (fp32 atomics are not:
+ * VERDICT r2 measured 1-3 % run-to-run spread downstream of them).  value = acc * 2^-FRAC_BITS.
+ *   CRD_STAT_FRAC_BITS (20): forward statistics and loss sums -- range +-8.8e12, every partial rounded to 2^-21
+ *     (<= 1e-9 absolute on a mean / mean square of >= 64 elements, against GroupNorm's eps = 1e-5);
+ *   CRD_GRAD_FRAC_BITS (44): gradient-magnitude sums -- range +-5.2e5, partials rounded to 2^-45 (2.8e-14; operands are
+ *     bf16, i.e. 4e-3 relative, and diffGradNorm's eps = 1e-8 swamps gradients below 1e-9).
+ * Buffers of this type are zeroed by the caller (all-zero bits = 0.0). */
+typedef int64_t crd_sum_t;
+#define CRD_STAT_FRAC_BITS 20
+#define CRD_GRAD_FRAC_BITS 44
+
 const char* crd_last_error(void);
 int crd_version(void);          /* ABI version, currently 1 */
 const char* crd_arch(void);     /* "gfx950" */
@@ -67,7 +81,7 @@ typedef struct {
   int32_t res_ld;
   const float* res_scale; /* [B] or NULL (=1) */
   int32_t accumulate;           /* 1: y += v (read-modify-write in y's dtype) */
-  float* stats;       /* [B][Cout/16][2] += (sum, sum of squares) of the ROUNDED outputs, or NULL */
+  crd_sum_t* stats;   /* [B][Cout/16][2] += (sum, sum of squares) of the ROUNDED outputs (CRD_STAT_FRAC_BITS), or NULL */
   float* stats_partial;           /* optional scratch: per-tile partial sums are written here with plain stores and
                                      folded into `stats` by a small second kernel (avoids contended atomics) */
   int64_t stats_partial_capacity; /* floats available in stats_partial; needs B*ceil(OH*OW/64)*(Cout/16)*2 */
@@ -75,16 +89,16 @@ typedef struct {
    * of a GroupNorm (+GELU) backward -- e.g. the data gradient of Mlp.fc2 feeding Mlp.norm2 -- and also computes that
    * backward's reduce phase: red_x is the GroupNorm's raw bf16 input laid out like y (pixel-major, red_x_ld channels per
    * pixel, same pixel grid), red_stats its g16 sums, red_gmul its slabs per group, red_act 1 for GELU; red_r is the
-   * buffer crd_gn_bwd_reduce would fill (float [B*Cout*2 + B*(Cout/(16*red_gmul))*2], zeroed by the caller).  Only
+   * buffer crd_gn_bwd_reduce would fill (crd_sum_t [B*Cout*2 + B*(Cout/(16*red_gmul))*2], zeroed by the caller).  Only
    * crd_gn_bwd_apply remains to be called. */
   const void* red_x;
   int32_t red_x_ld, red_gmul, red_act, red_reserved;
-  const float* red_stats;
+  const crd_sum_t* red_stats;
   const float* red_gamma;
   const float* red_beta;
-  float* red_r;
-  float* chan_sums;               /* optional, with stats and an fp32 or residual output: per-channel (sum, sumsq) of the
-                                     stored output, float [B][Cout][2], accumulated with atomics (what crd_gn_stats'
+  crd_sum_t* red_r;            /* CRD_GRAD_FRAC_BITS */
+  crd_sum_t* chan_sums;               /* optional, with stats and an fp32 or residual output: per-channel (sum, sumsq) of the
+                                     stored output, crd_sum_t [B][Cout][2] (CRD_STAT_FRAC_BITS) (what crd_gn_stats'
                                      chan_sums would hold for the output tensor) */
 } crd_conv_desc;
 
@@ -95,7 +109,7 @@ int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);
  * -- nn.GroupNorm followed by Conv1d / Conv2d in Block / Attention_MaxPool / Mlp (simplified_attention.py:34-43 Mlp.norm2 +
  * GELU + fc2, :96-100 attn.sr behind Block.norm1 and attn.k behind attn.norm, :142-145 fc1 behind Block.norm2) without
  * the pass that would store the normalised tensor first.  d->x is the RAW tensor (fp32 when x_f32, else bf16); statistics
- * as raw sums per 16-channel slab, float [B][Cin/16][2] (what crd_gn_stats / a producer's `stats` epilogue leave), a
+ * as raw sums per 16-channel slab, crd_sum_t [B][Cin/16][2] (what crd_gn_stats / a producer's `stats` epilogue leave), a
  * group being `gmul` consecutive slabs.  xn != NULL: act(GroupNorm(x)) is also stored as bf16 [B][IH*IW][xn_ld] (the
  * operand a later weight-gradient call needs).  Pointwise (1x1) and non-overlapping patch convolutions only
  * (KH == KW == stride, pad 0, gather_mode 0, out_mode 0); every epilogue option of crd_conv_desc except red_x and
@@ -103,7 +117,7 @@ int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream);
 typedef struct {
   int32_t x_f32;            /* d->x holds fp32 (1) or bf16 (0) */
   int32_t gmul;             /* 16-channel slabs per group */
-  const float* stats;       /* [B][Cin/16][2] */
+  const crd_sum_t* stats;   /* [B][Cin/16][2] */
   const float* gamma;       /* [Cin] */
   const float* beta;        /* [Cin] */
   int32_t act;              /* 0 none, 1 exact GELU (after the affine) */
@@ -133,7 +147,7 @@ int crd_quant_fp8(const void* x, int64_t rows, int32_t ld, int32_t coff, int32_t
  * GroupNorm(+GELU) of a ConvLayer (utils.py:210-228) and the decoder's 2x bicubic upsample (utils.py:249-257).  Arguments as
  * crd_gn_apply / crd_bicubic2x with y an fp8 tensor (y_ld, y_coff in bytes = channels).  y_bf16 (optional, NULL = none):
  * the bf16 output itself as well -- a training step keeps it for the backward pass. */
-int crd_gn_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C, const float* stats,
+int crd_gn_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
                      int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask, void* y_fp8, int32_t y_ld,
                      int32_t y_coff, float y_scale, void* y_bf16, int32_t yb_ld, int32_t yb_coff, crd_stream_t stream);
 int crd_bicubic2x_fp8(const void* x, int32_t x_ld, int32_t x_coff, int32_t B, int32_t H, int32_t W, int32_t C, void* y_fp8,
@@ -145,14 +159,14 @@ int crd_weight_quant_fp8(const void* w_bf16, int32_t Cout, int32_t taps, int32_t
                          crd_stream_t stream);
 
 /* Weight gradient of the same convolutions: dw[co][tap][ci] += sum_{b,oy,ox} dy[b,oy,ox,co] *
- * x[b, oy*s-p+ky, ox*s-p+kx, ci]  (fp32 atomics; caller zeroes dw).  Optionally also
+ * x[b, oy*s-p+ky, ox*s-p+kx, ci]  (fixed-point atomics, see crd_sum_t; caller zeroes dw).  Optionally also
  * dbias[co] += sum dy.  (autograd of the conv calls listed above.) */
 typedef struct {
   const void* x; int32_t x_ld, x_coff; int32_t B, IH, IW, Cin;
   const void* dy; int32_t dy_ld, dy_coff; int32_t OH, OW, Cout;
   int32_t KH, KW, stride, pad;
-  float* dw;          /* fp32 [Cout][KH*KW][Cin] */
-  float* dbias;       /* fp32 [Cout] or NULL */
+  crd_sum_t* dw;      /* [Cout][KH*KW][Cin], CRD_GRAD_FRAC_BITS (untouched when dw_partials is used) */
+  crd_sum_t* dbias;   /* [Cout] or NULL, CRD_GRAD_FRAC_BITS */
   float* dw_partials; /* optional, only where crd_conv_wgrad_splits(d) = S > 0 (the streaming 3x3 kernel): fp32
                          [S][Cout][9][Cin], contents don't-care.  Every pixel-range split stores its weight-gradient
                          block into its own copy with plain stores and dw is NOT touched: the gradient is the sum of the
@@ -186,39 +200,39 @@ int crd_conv_wgrad_grouped(const void* dev_table, const crd_wgrad_group_info* in
 
 /* ---------------------------------------------------------------------------------------------
  * GroupNorm family.  Statistics are kept as raw sums over 16-channel slabs ("g16 stats":
- * float [B][C/16][2] = sum, sum of squares); a GroupNorm group is `gmul` consecutive slabs, so
+ * crd_sum_t [B][C/16][2] = sum, sum of squares, CRD_STAT_FRAC_BITS); a GroupNorm group is `gmul` consecutive slabs, so
  * the reference's GroupNorm(C/16, C) has gmul = 1 and Mlp.norm2 (groups from out_features,
  * simplified_attention.py:24) has gmul = hidden/dim.  Replaces torch group_norm + GELU:
  * simplified_attention.py:23-24,37-40,70,117-118,142,144,162,186; utils.py:213-214,225.
  * ------------------------------------------------------------------------------------------- */
 /* stats[b][c/16] += sums over pixels of x (bf16 or fp32); optional per-channel sums chan[b][c][2]. */
 int crd_gn_stats(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
-                 float* stats, float* chan_sums, crd_stream_t stream);
+                 crd_sum_t* stats, crd_sum_t* chan_sums, crd_stream_t stream);
 
 /* y = act((x-mean)*rstd*gamma+beta) * mask[b][c];  act: 0 none, 1 exact GELU.  mask may be NULL.
  * y is a bf16 (y_f32=0) or fp32 (y_f32=1) pixel-major slice.  eps = 1e-5. */
 int crd_gn_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, int32_t B, int32_t P, int32_t C,
-                 const float* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
+                 const crd_sum_t* stats, int32_t gmul, const float* gamma, const float* beta, int32_t act,
                  const float* mask, void* y, int32_t y_f32, int32_t y_ld, int32_t y_coff, crd_stream_t stream);
 
 /* Backward, phase 1: per (b, c) sums  r[b][c] = (sum g, sum g*xhat), g = dy*mask*act'(u),
  * u = xhat*gamma+beta, followed by the per-group sums rg[b][grp] = (sum_c gamma_c r[b][c][0], sum_c gamma_c r[b][c][1]).
- * r is float[B*C*2 + B*(C/(16*gmul))*2], zeroed by the caller.  dy is bf16 or fp32 pixel-major.
+ * r is crd_sum_t[B*C*2 + B*(C/(16*gmul))*2] (CRD_GRAD_FRAC_BITS), zeroed by the caller.  dy is bf16 or fp32 pixel-major.
  * scratch (optional, >= B*1024*2*C floats is always enough): per-workgroup partial sums go there with plain stores and
  * a second small kernel folds them, instead of ~1M contended atomics on large tensors. */
 int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
-                      int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
+                      int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
                       int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
-                      float* r, float* scratch, int64_t scratch_capacity, crd_stream_t stream);
+                      crd_sum_t* r, float* scratch, int64_t scratch_capacity, crd_stream_t stream);
 /* Backward, phase 2: dgamma[c] += sum_b r[b][c][1], dbeta[c] += sum_b r[b][c][0];
  * dx = (gamma*g - mean_grp(gamma*g) - xhat*mean_grp(gamma*g*xhat)) * rstd, written as bf16
  * (dx_f32=0) or ADDED into an fp32 tensor (dx_f32=1, accumulate).  dx2 (optional): a bf16 copy [B][P][dx2_ld] of the
  * finished dx, scaled per sample by scale2[b] when scale2 is given (the drop-path-scaled gradient the previous block's
  * fc2 backward consumes, simplified_attention.py:144). */
 int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
-                     int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const float* stats,
+                     int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
                      int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
-                     const float* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
+                     const crd_sum_t* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
                      int32_t dx_coff, int32_t dx_accumulate, void* dx2, int32_t dx2_ld, const float* scale2,
                      crd_stream_t stream);
 
@@ -229,21 +243,21 @@ int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff,
  * Optional g16 stats of the rounded output.
  * ------------------------------------------------------------------------------------------- */
 int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
-                  int32_t flip, void* y, float* stats, const float* in_stats, int32_t in_gmul, const float* in_gamma,
-                  const float* in_beta, const void* red_x, const float* red_stats, const float* red_gamma, float* red_r,
+                  int32_t flip, void* y, crd_sum_t* stats, const crd_sum_t* in_stats, int32_t in_gmul, const float* in_gamma,
+                  const float* in_beta, const void* red_x, const crd_sum_t* red_stats, const float* red_gamma, crd_sum_t* red_r,
                   crd_stream_t stream);
 /* red_x != NULL: the first phase of the backward of the GroupNorm (gmul = 1, no activation) whose dy this call produces
  * is fused in -- red_x is that GroupNorm's raw input (bf16 [B][H][W][C]), red_stats its g16 sums, red_gamma its weight,
- * red_r the buffer crd_gn_bwd_reduce would fill (float [B*C*2 + B*(C/16)*2], zeroed by the caller); only
+ * red_r the buffer crd_gn_bwd_reduce would fill (crd_sum_t [B*C*2 + B*(C/16)*2], zeroed by the caller); only
  * crd_gn_bwd_apply remains to be called (Mlp.norm1's backward after the depthwise data gradient). */
 /* in_stats != NULL (both functions): the input is GroupNorm-ed on load -- xn = bf16((x-mean)*rstd*gamma+beta) with the g16
  * sums in_stats[B][C/16][2] of x and groups of in_gmul slabs, zero padding applied after the normalisation -- i.e.
  * crd_gn_apply (Mlp.norm1, simplified_attention.py:37-38) fused into the consumer; the normalised tensor is never stored. */
-/* dw10: float [replicas][10][C], zeroed by the caller.  Rows 0..8: dw[tap][c] += sum dy*x_shifted; row 9: the bias
- * gradient sum dy.  Workgroups spread their fp32 atomics over the `replicas` copies (contended atomics on one copy
+/* dw10: crd_sum_t [replicas][10][C] (CRD_GRAD_FRAC_BITS), zeroed by the caller.  Rows 0..8: dw[tap][c] += sum dy*x_shifted; row 9: the bias
+ * gradient sum dy.  Workgroups spread their atomics over the `replicas` copies (contended atomics on one copy
  * were the whole cost of this kernel); the true gradient is the sum of the copies (crd_wgrad_unpack does that). */
-int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, float* dw10,
-                        int32_t replicas, const float* in_stats, int32_t in_gmul, const float* in_gamma,
+int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int32_t W, int32_t C, crd_sum_t* dw10,
+                        int32_t replicas, const crd_sum_t* in_stats, int32_t in_gmul, const float* in_gamma,
                         const float* in_beta, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -258,50 +272,55 @@ int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t 
 /* crd_attn_scores and crd_attn_xbar_proj in ONE launch (the value path is one extra workgroup per sample; it only needs
  * norm1's sums, so it rides along with the scores): arguments as in the two calls, C = heads * d. */
 int crd_attn_fwd(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d, float scale,
-                 float* S, int16_t* idx, const float* chan_sums, const float* stats, const float* gamma, const float* beta,
+                 float* S, int16_t* idx, const crd_sum_t* chan_sums, const crd_sum_t* stats, const float* gamma, const float* beta,
                  const void* w_fwd, void* xbar, float* u, crd_stream_t stream);
 /* xbar[b][c] (bf16) from per-channel sums chan[b][c][2] and g16 stats of x (gmul = 1). */
-int crd_attn_xbar(const float* chan_sums, const float* stats, const float* gamma, const float* beta, int32_t B,
+int crd_attn_xbar(const crd_sum_t* chan_sums, const crd_sum_t* stats, const float* gamma, const float* beta, int32_t B,
                   int32_t N, int32_t C, void* xbar, crd_stream_t stream);
 /* crd_attn_xbar followed by u[b][co] = sum_ci Wp[co][ci] * xbar[b][ci] (the `proj` Conv1d applied to the rank-one value,
  * simplified_attention.py:103-107) in one launch; w_fwd is Wp in its packed bf16 forward form [C][C].  u: fp32 [B][C]. */
-int crd_attn_xbar_proj(const float* chan_sums, const float* stats, const float* gamma, const float* beta, const void* w_fwd,
+int crd_attn_xbar_proj(const crd_sum_t* chan_sums, const crd_sum_t* stats, const float* gamma, const float* beta, const void* w_fwd,
                        int32_t B, int32_t N, int32_t C, void* xbar, float* u, crd_stream_t stream);
 /* Backward of that path: tb = bf16(t) (bf16 [B][C], the dy operand of proj's weight gradient) and
  * es[b][ci] = inv_n * sum_co Wp[co][ci] * tb[b][co] (fp32 [B][C]); w_dgrad is Wp in its packed bf16 data-gradient form
  * [C][Cpad]. */
-int crd_attn_vec_bwd(const float* t, const void* w_dgrad, int32_t B, int32_t C, int32_t Cpad, float inv_n, void* tb, float* es,
+int crd_attn_vec_bwd(const crd_sum_t* t, const void* w_dgrad, int32_t B, int32_t C, int32_t Cpad, float inv_n, void* tb, float* es,
                      crd_stream_t stream);
 /* x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])   (fp32 residual stream; Block.forward :143; dp may be NULL) */
 int crd_attn_out_residual(const float* x, const float* u, const float* S, const float* bp, const float* dp,
                           int32_t B, int32_t N, int32_t C, float* x1, crd_stream_t stream);
 /* crd_attn_out_residual that also accumulates the g16 GroupNorm sums of x1 (what crd_gn_stats(x1) would add to `stats`,
- * float [B][C/16][2], zeroed by the caller): Block.norm2 reads x1 next (simplified_attention.py:143-144). */
+ * crd_sum_t [B][C/16][2], zeroed by the caller): Block.norm2 reads x1 next (simplified_attention.py:143-144). */
 int crd_attn_out_residual_stats(const float* x, const float* u, const float* S, const float* bp, const float* dp,
-                                int32_t B, int32_t N, int32_t C, float* x1, float* stats, crd_stream_t stream);
+                                int32_t B, int32_t N, int32_t C, float* x1, crd_sum_t* stats, crd_stream_t stream);
 /* with dy = dp[b]*dx1:  t[b][c] += sum_n dy*S ; dbp_rows[b][c] += sum_n dy ; dS[b][n] = sum_c dy*u[b][c].
- * The bias gradient is the sum of the B rows of dbp_rows (float [B][C], zeroed by the caller): per-sample rows keep the
+ * t and dbp_rows are crd_sum_t [B][C] (CRD_GRAD_FRAC_BITS), zeroed by the caller; the bias gradient is the sum of the B rows of dbp_rows: per-sample rows keep the
  * chain of contended atomics at the workgroups of one sample; crd_wgrad_unpack (replicas = B) folds them. */
 int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
-                     int32_t C, float* t, float* dbp_rows, float* dS, crd_stream_t stream);
-/* dq[b][n][c] = scale*dS[b][n]*k[b][idx][c] (bf16) ; dk[b][m][c] += scale*dS*q (fp32, caller zeroes).
+                     int32_t C, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, crd_stream_t stream);
+/* dq[b][n][c] = scale*dS[b][n]*k[b][idx][c] (bf16) ; dk[b][m][c] += scale*dS*q (caller zeroes).
  * Every workgroup accumulates its share of dk in LDS (when [M][C] fp32 fits: always at the reference's sizes).  With
  * dk_partials != NULL (float [P][B][M][C], P = crd_attn_scores_bwd_partials(B,N,M,heads,d) > 0; contents don't-care)
  * the workgroups store their accumulators there with plain stores and dk is not touched: dk = sum over P, which
  * crd_sum_partials_bf16 folds together with the bf16 conversion the next layer needs.  With dk_partials == NULL they add
- * into dk with fp32 atomics (2.7 M of them per launch at stage 1: ~16 us at the ~170 G/s the L2s sustain). */
+ * into dk (crd_sum_t [B][M][C], CRD_GRAD_FRAC_BITS) with atomics (2.7 M of them per launch at stage 1: ~16 us at the
+ * ~170 G/s the L2s sustain).  Inside a workgroup the contributions to one key are added in fixed point, so the partial
+ * does not depend on the order in which the LDS counting sort listed them. */
 int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d);
 int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
-                        int32_t M, int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials,
+                        int32_t M, int32_t heads, int32_t d, float scale, void* dq, crd_sum_t* dk, float* dk_partials,
                         crd_stream_t stream);
 /* crd_attn_scores_bwd and crd_attn_vec_bwd in ONE launch (both consume crd_attn_out_bwd's outputs; one extra workgroup per
  * sample runs the vector path): arguments as in the two calls, C = heads * d. */
 int crd_attn_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N, int32_t M,
-                 int32_t heads, int32_t d, float scale, void* dq, float* dk, float* dk_partials, const float* t,
+                 int32_t heads, int32_t d, float scale, void* dq, crd_sum_t* dk, float* dk_partials, const crd_sum_t* t,
                  const void* w_dgrad, int32_t Cpad, float inv_n, void* tb, float* es, crd_stream_t stream);
 /* dst[i] = bf16(sum_{r < replicas} part[r*replica_stride + i]), i < n (n, replica_stride multiples of 8) */
 int crd_sum_partials_bf16(const float* part, int32_t replicas, int64_t replica_stride, void* dst, int64_t n,
                           crd_stream_t stream);
+/* dst[i] = bf16(src[i] * 2^-CRD_GRAD_FRAC_BITS), i < n (n a multiple of 8): the dk accumulator of crd_attn_scores_bwd's
+ * global path as the bf16 operand the next layer needs */
+int crd_gsum_to_bf16(const crd_sum_t* src, void* dst, int64_t n, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bicubic x2 up-sampling, A=-0.75, align_corners=False, clamped borders (nn.Upsample, utils.py:241,
@@ -341,17 +360,17 @@ int crd_f32_to_bf16_rows(const float* src, int32_t s_ld, void* dst, int32_t d_ld
 int crd_head_conv2_fwd(const void* a, const float* w, const float* bias, int32_t B, int32_t H, int32_t W, float* depth,
                        void* copy, int32_t copy_ld, int32_t copy_coff, crd_stream_t stream);
 /* Backward of the above fused with the sigmoid backward: dy = gd (+ add, a bf16 channel);
- * dz = a(1-a) * conv2^T(dy) (bf16 [B][H][W][32]).  Parameter gradients: dw_rows is float [replicas][289], zeroed by the
+ * dz = a(1-a) * conv2^T(dy) (bf16 [B][H][W][32]).  Parameter gradients: dw_rows is crd_sum_t [replicas][289] (CRD_GRAD_FRAC_BITS), zeroed by the
  * caller; every row holds dw[1][32][3][3] (288 values, reference order) followed by dbias, workgroups spread their
  * fp32 atomics over the rows and the gradient is the sum of the rows (crd_wgrad_unpack, replicas = rows). */
 int crd_head_conv2_bwd(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
-                       int32_t B, int32_t H, int32_t W, void* dz, float* dw_rows, int32_t replicas, crd_stream_t stream);
+                       int32_t B, int32_t H, int32_t W, void* dz, crd_sum_t* dw_rows, int32_t replicas, crd_stream_t stream);
 /* The two halves of crd_head_conv2_bwd as calls of their own (the weight-gradient half is not on the backward pass's
  * dependency chain: the graph step replays it on its late stream). */
 int crd_head_conv2_bwd_data(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, const float* w,
                             int32_t B, int32_t H, int32_t W, void* dz, crd_stream_t stream);
 int crd_head_conv2_wgrad(const float* gd, const void* add, int32_t add_ld, int32_t add_coff, const void* a, int32_t B, int32_t H,
-                         int32_t W, float* dw_rows, int32_t replicas, crd_stream_t stream);
+                         int32_t W, crd_sum_t* dw_rows, int32_t replicas, crd_stream_t stream);
 /* da <- da * a * (1-a)   (bf16, n elements, n % 8 == 0): backward of the sigmoid in Depth_Activation */
 int crd_sigmoid_bwd(const void* a, void* da, int64_t n, crd_stream_t stream);
 
@@ -371,12 +390,13 @@ typedef struct {
 int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int64_t max_elems, crd_stream_t stream);
 /* grad_ref[co][ci_ref][tap] (+)= dw_packed[co][tap][ci_pad] */
 typedef struct {
-  const float* src;    /* fp32 [Cout][taps][Cin_pad] */
+  const void* src;     /* [Cout][taps][Cin_pad]: fp32 (src_sum = 0) or crd_sum_t with CRD_GRAD_FRAC_BITS (src_sum = 1) */
   float* dst;          /* fp32 [Cout][Cin_ref][taps] */
   const int32_t* cmap;
   int32_t Cout, Cin_ref, taps, Cin_pad;
-  int32_t replicas;        /* > 1: the source is the sum of `replicas` copies, replica_stride floats apart */
-  int32_t reserved;
+  int32_t replicas;        /* > 1: the source is the sum of `replicas` copies, replica_stride ELEMENTS apart (summed in
+                              index order: fixed, so reproducible) */
+  int32_t src_sum;
   int64_t replica_stride;
 } crd_unpack_entry;
 int crd_wgrad_unpack(const crd_unpack_entry* table_dev, int32_t n, int64_t max_elems, int32_t accumulate,
@@ -415,14 +435,16 @@ int crd_resize_labels_nearest(const void* src_u8, int32_t B, int32_t SH, int32_t
 /* ---------------------------------------------------------------------------------------------
  * Losses (src/utils/loss_funcs.py:14-46,77-91; combination src/main/runner.py:197-218).
  * ------------------------------------------------------------------------------------------- */
-/* acc[0] += sum smooth_l1(pred-target), acc[1] += #(target>0), acc[2] += sum (target-pred)^2 ; caller zeroes acc */
-int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, float* acc, crd_stream_t stream);
+/* acc[0] += sum smooth_l1(pred-target), acc[1] += #(target>0), acc[2] += sum (target-pred)^2 ; crd_sum_t with
+ * CRD_STAT_FRAC_BITS (so that a SUM all-reduce over ranks stays exact); caller zeroes acc */
+int crd_masked_l1_fwd(const float* pred, const float* target, int64_t n, crd_sum_t* acc, crd_stream_t stream);
 /* Trainer.test metrics (runner.py:443-465) for `frames` fp32 maps of n pixels each, without a host sync per frame:
  * p = clip(pred,0,1)*max_depth, g = gt*max_depth with g > max_distance dropped; on g > 0:
- * acc[f][0] += sum |p-g|, acc[f][1] += sum (p-g)^2, acc[f][2] += sum |p-g|/g, acc[f][3] += count   (caller zeroes acc;
+ * acc[f][0] += sum |p-g|, acc[f][1] += sum (p-g)^2, acc[f][2] += sum |p-g|/g, acc[f][3] += count   (crd_sum_t,
+ * CRD_STAT_FRAC_BITS; caller zeroes acc;
  * MAE = acc0/acc3, RMSE = sqrt(acc1/acc3), REL = acc2/acc3; frames with acc3 == 0 are skipped by the reference) */
 int crd_test_metrics(const float* pred, const float* gt, int32_t frames, int64_t n, float max_depth, float max_distance,
-                     float* acc, crd_stream_t stream);
+                     crd_sum_t* acc, crd_stream_t stream);
 /* Per-frame confusion matrices for the Jaccard index of Trainer.test (runner.py:432-436, torchmetrics 0.10.2
  * JaccardIndex(num_classes=C, ignore_index=255)): prediction = arg-max over the C fp32 logits [frames][C][HW],
  * confmat[f][target][pred] += 1 (int64 [frames][C][C], caller zeroes); labels outside [0, C) are skipped and counted
@@ -430,21 +452,23 @@ int crd_test_metrics(const float* pred, const float* gt, int32_t frames, int64_t
 int crd_seg_confusion(const float* logits, const int64_t* labels, int32_t frames, int32_t C, int64_t HW, int64_t* confmat,
                       int64_t* out_of_range, crd_stream_t stream);
 /* dpred = gmul * gout[0] * clamp(pred-target,-1,1) / acc[1] on target>0, else 0   (gout may be NULL = 1) */
-int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const float* acc, const float* gout,
+int crd_masked_l1_bwd(const float* pred, const float* target, int64_t n, const crd_sum_t* acc, const float* gout,
                       float gmul, float* dpred, crd_stream_t stream);
 /* NCHW fp32 logits [B][C][HW], int64 labels [B][HW], ignore_index 255:
  * acc[0] += sum -log softmax[label], acc[1] += #valid */
-int crd_ce_fwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, float* acc,
+int crd_ce_fwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, crd_sum_t* acc,
                crd_stream_t stream);
 /* focal on the scalar mean CE (loss_funcs.py:27-29): dlogits = gmul*gout[0]*dF/dce*(softmax-onehot)/acc[1] */
-int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, const float* acc,
+int crd_ce_focal_bwd(const float* logits, const int64_t* labels, int32_t B, int32_t C, int64_t HW, const crd_sum_t* acc,
                      const float* gout, float gmul, float* dlogits, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * diffGradNorm.step (src/models/diffGradNorm.py:41-113) over flat fp32 buffers.
  * Tensor t occupies [seg_off[2t], seg_off[2t+1]) of every flat buffer (int64 pairs; gaps allowed).  Workgroup w processes chunk
- * blk2chunk[w] (4096 elements) of tensor blk2seg[w].  exp_grad_norm / norm_sq / factor are
- * float[n_tensors] (norm_sq must be zero on entry and is left zero).  active[t]=0 skips tensor t
+ * blk2chunk[w] (4096 elements) of tensor blk2seg[w]; the workgroups of a tensor are consecutive and in chunk order.
+ * exp_grad_norm / factor are float[n_tensors]; norm_sq is scratch, float[n_blocks]: workgroup w stores its part of
+ * ||g||^2 in norm_sq[w] and one wave per tensor adds its workgroups' parts in a fixed order (reproducible; the e > n
+ * branch of diffGradNorm.py:84 turns rounding noise into a discrete jump).  active[t]=0 skips tensor t
  * (`p.grad is None`, :54-55).  `step` is the 1-based step count used for the bias corrections.
  * hp_dev (optional, device float[5] = beta1, beta2, eps, weight_decay, lr*sqrt(1-beta2^t)/(1-beta1^t+1e-8))
  * overrides the scalar arguments so that a captured HIP graph can follow a per-iteration schedule.

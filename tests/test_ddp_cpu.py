@@ -45,7 +45,7 @@ def _worker(rank, world, port, q):
         g = m._param("depth_activation_5.conv_2.bias").grad          # param.grad is a view of the reduced buffer
         ok = ok and torch.allclose(g, expect[m._offsets[m._index["depth_activation_5.conv_2.bias"]]:][:1])
         # global masked mean: (sum, count) partials are summed across ranks before the division
-        acc = torch.tensor([2.0 * (rank + 1), 3.0 + rank, 0.0, 0.0])
+        acc = torch.tensor([2 * (rank + 1), 3 + rank, 0, 0], dtype=torch.int64)      # crd_sum_t partials: exact under SUM
         _allreduce_acc(acc)
         ok = ok and float(acc[0] / acc[1]) == pytest.approx((2.0 + 4.0) / (3.0 + 4.0))
         q.put((rank, bool(ok)))
@@ -83,15 +83,15 @@ def _worker_step(rank, world, port, q):
         ts.schedule, ts.lr, ts.betas, ts.eps, ts.wd = None, 1e-3, (0.9, 0.999), 1e-8, 0.0
         ts.iter_count = ts.epoch_iter = ts.sched_steps = ts.step_count = 0
         ts._window_open, ts._window_pos, ts._zero, ts._opt = False, 0, True, True
-        ts.hp, ts.hp_ring, ts.acc = torch.zeros(8), [torch.zeros(8) for _ in range(4)], torch.zeros(16)
+        ts.hp, ts.hp_ring, ts.acc = torch.zeros(8), [torch.zeros(8) for _ in range(4)], torch.zeros(16, dtype=torch.int64)
         seen, accs = [], []
 
         def fwd():
             if ts._zero:
                 m.flat_grad.zero_()
             ts.acc.zero_()
-            ts.acc[0] += rank + 1.0
-            ts.acc[1] += 1.0
+            ts.acc[0] += rank + 1
+            ts.acc[1] += 1
 
         def bwd(key):
             lo, hi = ts.sync.ranges[key]

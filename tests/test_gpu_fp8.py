@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from tests.test_gpu_igemm import assert_close, bf, pack_w, to_pm
+from tests.util import sval, to_stat, zsum
 
 pytestmark = pytest.mark.gpu
 E4M3 = torch.float8_e4m3fn
@@ -90,7 +91,7 @@ def test_conv3x3_fp8_matches_dequantised_reference(case):
     ws = torch.zeros(Co, device="cuda")
     lib.check(L.crd_weight_quant_fp8(wp.data_ptr(), Co, 9, (Ci + 7) // 8 * 8, Ci16, w8.data_ptr(), ws.data_ptr(), lib.stream()), "wquant")
     y = torch.zeros(B, H, W, Co + 8, dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros(B, Co // 16, 2, device="cuda")
+    stats = zsum(B, Co // 16, 2)
     partial = torch.full((B * (-(-W // 32)) * (-(-H // 16)) * 4 * (Co // 16) * 2,), float("nan"), device="cuda")
     d = lib.ConvDesc()
     d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x8.data_ptr(), ldx, 0, B, H, W, Ci16
@@ -106,7 +107,7 @@ def test_conv3x3_fp8_matches_dequantised_reference(case):
     assert_close(got, ref, f"fp8 conv {case}")
     assert float(y[..., :8].float().abs().max()) == 0.0
     gq = got.reshape(B, Co // 16, 16, H * W)
-    assert_close(stats.cpu(), torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1), "fp8 conv GroupNorm sums", rel=1e-3, elem=2e-3)
+    assert_close(sval(stats), torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1), "fp8 conv GroupNorm sums", rel=1e-3, elem=2e-3)
     # and the quantisation error itself against the un-quantised convolution: e4m3 has 3 mantissa bits
     full = F.conv2d(x, w, None, padding=1)
     rel = float((got - full).norm() / full.norm())
@@ -122,7 +123,7 @@ def test_fused_fp8_producers_equal_quantised_bf16_outputs():
     B, H, W, Cc = 2, 12, 20, 96
     x = bf(torch.randn(B, H * W, Cc, generator=g) * 2).to(torch.bfloat16).cuda()
     v = x.float().reshape(B, -1, Cc // 16, 16)
-    stats = torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1).contiguous()
+    stats = to_stat(torch.stack([v.sum((1, 3)), (v * v).sum((1, 3))], -1)).contiguous()
     gamma, beta = (1 + 0.2 * torch.randn(Cc, generator=g)).cuda(), (0.1 * torch.randn(Cc, generator=g)).cuda()
     scale = 0.013
     y16 = torch.zeros(B, H * W, Cc, dtype=torch.bfloat16, device="cuda")

@@ -11,6 +11,7 @@ import torch
 import torch.nn.functional as F
 
 from tests.test_gpu_igemm import assert_close, bf, pack_w
+from tests.util import sval, to_stat, zsum
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +68,7 @@ def test_gn_conv_matches_groupnorm_then_conv(case):
     OH, OW = H // k, W // k
     xpm = x.permute(0, 2, 3, 1).contiguous()
     xpm = (xpm if x_f32 else xpm.to(torch.bfloat16)).cuda()
-    stats = slab_sums(x).cuda()
+    stats = to_stat(slab_sums(x)).cuda()
     wp = pack_w(w)
     xn_out = torch.zeros(B, H * W, Cin, dtype=torch.bfloat16, device="cuda")
     d, n = lib.ConvDesc(), lib.GnInput()
@@ -79,13 +80,13 @@ def test_gn_conv_matches_groupnorm_then_conv(case):
     gam_d, bet_d = gamma.cuda(), beta.cuda()
     n.stats, n.gamma, n.beta = stats.data_ptr(), gam_d.data_ptr(), bet_d.data_ptr()
     n.xn, n.xn_ld = xn_out.data_ptr(), Cin
-    ostats = torch.zeros(B, Cout // 16, 2, device="cuda")
+    ostats = zsum(B, Cout // 16, 2)
     if epi == "res":
         y = torch.zeros(B, OH * OW, Cout, device="cuda")
         res = torch.randn(B, OH * OW, Cout, generator=g)
         scale = torch.tensor([1.0 / 0.9, 0.0] * B)[:B]
         res_d, scale_d = res.cuda(), scale.cuda()
-        chan = torch.zeros(B, Cout, 2, device="cuda")
+        chan = zsum(B, Cout, 2)
         d.y, d.y_ld, d.y_f32 = y.data_ptr(), Cout, 1
         d.res, d.res_ld, d.res_scale = res_d.data_ptr(), Cout, scale_d.data_ptr()
         d.stats, d.chan_sums = ostats.data_ptr(), chan.data_ptr()
@@ -105,11 +106,11 @@ def test_gn_conv_matches_groupnorm_then_conv(case):
     assert_close(xn_out.float().cpu(), xn_ref, "stored normalised operand", rel=3e-3, elem=1.6e-2)
     if epi in ("stats", "res"):
         stored = y.float().cpu().reshape(B, OH * OW, Cout).permute(0, 2, 1).reshape(B, Cout, OH, OW)
-        assert_close(ostats.cpu(), slab_sums(stored), "output GroupNorm sums", rel=2e-3, elem=5e-3)
+        assert_close(sval(ostats), slab_sums(stored), "output GroupNorm sums", rel=2e-3, elem=5e-3)
     if epi == "res":
         v = stored.reshape(B, Cout, -1).double()
         cref = torch.stack([v.sum(-1), (v * v).sum(-1)], -1).float()
-        assert_close(chan.cpu(), cref, "output channel sums", rel=2e-3, elem=5e-3)
+        assert_close(sval(chan), cref, "output channel sums", rel=2e-3, elem=5e-3)
 
 
 def test_gn_conv_rejects_what_it_does_not_cover():

@@ -8,6 +8,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from tests.util import gval, sval, zsum  # noqa: E402
+
 pytestmark = pytest.mark.gpu
 
 
@@ -128,7 +130,7 @@ def test_conv_forward(case):
     wp = pack_w(w, Cp)
     ld_y = ((Co + 7) // 8) * 8 + 8
     y = torch.zeros(B, OH, OW, ld_y, dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros(B, Co // 16, 2, device="cuda") if Co % 16 == 0 else None
+    stats = zsum(B, Co // 16, 2) if Co % 16 == 0 else None
     # odd-sized cases use the atomic statistics path, the others the per-tile partials + finalize path
     partial = torch.full((B * (-(-OH * OW // 64)) * max(Co // 16, 1) * 2,), 7.0, device="cuda") if (H * W) % 2 == 0 else None
     run_conv(xpm, Cp + 16, 8, B, H, W, Cp, wp, Co, k, k, s, p, OH, OW, y, ld_y, 8 if Co % 8 == 0 else 0,
@@ -142,7 +144,7 @@ def test_conv_forward(case):
     if stats is not None:
         gq = got.reshape(B, Co // 16, 16, OH * OW)
         ref_s = torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1)
-        assert_close(stats.cpu(), ref_s, f"stats {case}", rel=1e-3, elem=2e-3)
+        assert_close(sval(stats), ref_s, f"stats {case}", rel=1e-3, elem=2e-3)
 
 
 def test_epilogues_sigmoid_residual_accumulate():
@@ -168,14 +170,14 @@ def test_epilogues_sigmoid_residual_accumulate():
     # the same with the GroupNorm sums of the stored fp32 output: g16 (sum, sumsq) and per-channel (sum, sumsq)
     if Co % 16 == 0:
         yf2 = torch.zeros(B, H, W, Co, device="cuda")
-        st, ch = torch.zeros(B, Co // 16, 2, device="cuda"), torch.zeros(B, Co, 2, device="cuda")
+        st, ch = zsum(B, Co // 16, 2), zsum(B, Co, 2)
         run_conv(xpm, Ci, 0, B, H, W, Ci, wp, Co, 1, 1, 1, 0, H, W, yf2, Co, 0, y_f32=1, bias=bias.cuda(), res=res.cuda(),
                  res_ld=Co, res_scale=scale.cuda(), stats=st, chan=ch)
         assert torch.equal(yf2, yf)
         yd = yf2.double().cpu().view(B, H * W, Co)
         chr_ = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
-        assert_close(ch.cpu(), chr_, "channel sums", rel=1e-5, elem=1e-5)
-        assert_close(st.cpu(), chr_.view(B, Co // 16, 16, 2).sum(2), "g16 sums", rel=1e-5, elem=1e-5)
+        assert_close(sval(ch), chr_, "channel sums", rel=1e-5, elem=1e-5)
+        assert_close(sval(st), chr_.view(B, Co // 16, 16, 2).sum(2), "g16 sums", rel=1e-5, elem=1e-5)
     # accumulate into bf16
     y0 = bf(torch.randn(B, H, W, Co, generator=g))
     y = y0.to(torch.bfloat16).cuda()
@@ -199,15 +201,15 @@ def test_fp32_residual_epilogue_with_sums(Ci, Co, H, W, acc):
     scale = torch.tensor([0.5, 1.25])
     y0 = torch.randn(B, H, W, Co, generator=g) if acc else torch.zeros(B, H, W, Co)
     yf = y0.clone().cuda()
-    st, ch = torch.zeros(B, Co // 16, 2, device="cuda"), torch.zeros(B, Co, 2, device="cuda")
+    st, ch = zsum(B, Co // 16, 2), zsum(B, Co, 2)
     run_conv(xpm, Ci, 0, B, H, W, Ci, wp, Co, 1, 1, 1, 0, H, W, yf, Co, 0, y_f32=1, bias=bias.cuda(), res=res.cuda(),
              res_ld=Co, res_scale=scale.cuda(), accumulate=acc, stats=st, chan=ch)
     ref = res + scale.view(B, 1, 1, 1) * bf(conv).permute(0, 2, 3, 1) + y0
     assert_close(yf.cpu(), ref, "fp32 residual output", rel=2e-3, elem=6e-3)
     yd = yf.double().cpu().view(B, H * W, Co)
     chr_ = torch.stack([yd.sum(1), (yd * yd).sum(1)], -1)
-    assert_close(ch.cpu(), chr_, "channel sums", rel=1e-5, elem=1e-5)
-    assert_close(st.cpu(), chr_.view(B, Co // 16, 16, 2).sum(2), "g16 sums", rel=1e-5, elem=1e-5)
+    assert_close(sval(ch), chr_, "channel sums", rel=1e-5, elem=1e-5)
+    assert_close(sval(st), chr_.view(B, Co // 16, 16, 2).sum(2), "g16 sums", rel=1e-5, elem=1e-5)
 
 
 DGRAD_CASES = [
@@ -256,19 +258,19 @@ def test_conv_dgrad_with_fused_groupnorm_backward_reduce(Ci, Co, H, W, gmul, act
     dypm = to_pm(dy)
     xg = to_pm(bf(torch.randn(B, Ci, H, W, generator=g) * 1.3 + 0.2))       # the GroupNorm's raw input, [B, H*W, Ci]
     gam, bet = (1 + 0.1 * torch.randn(Ci, generator=g)).cuda(), (0.1 * torch.randn(Ci, generator=g)).cuda()
-    stats = torch.zeros(B, Ci // 16, 2, device="cuda")
+    stats = zsum(B, Ci // 16, 2)
     lib.check(L.crd_gn_stats(xg.data_ptr(), 0, Ci, 0, B, H * W, Ci, stats.data_ptr(), None, lib.stream()), "gn_stats")
     G = Ci // (16 * gmul)
     dx0 = torch.zeros(B, H, W, Ci, dtype=torch.bfloat16, device="cuda")
     run_conv(dypm, Co, 0, B, H, W, Co, wd, Ci, 1, 1, 1, 0, H, W, dx0, Ci, 0, gather_mode=1)
-    r_ref = torch.zeros(B * Ci * 2 + B * G * 2, device="cuda")
+    r_ref = zsum(B * Ci * 2 + B * G * 2)
     lib.check(L.crd_gn_bwd_reduce(xg.data_ptr(), 0, Ci, 0, dx0.data_ptr(), 0, Ci, 0, B, H * W, Ci, stats.data_ptr(), gmul,
                                   gam.data_ptr(), bet.data_ptr(), act, None, r_ref.data_ptr(), None, 0, lib.stream()), "gn_bwd_reduce")
     dx1 = torch.zeros_like(dx0)
     r = torch.zeros_like(r_ref)
     run_conv(dypm, Co, 0, B, H, W, Co, wd, Ci, 1, 1, 1, 0, H, W, dx1, Ci, 0, gather_mode=1, red=(xg, stats, gam, bet, gmul, act, r))
     assert torch.equal(dx0, dx1)
-    assert_close(r.cpu(), r_ref.cpu(), "fused gn-bwd reduce", rel=3e-4, elem=3e-4)
+    assert_close(gval(r), gval(r_ref), "fused gn-bwd reduce", rel=3e-4, elem=3e-4)
 
 
 @pytest.mark.parametrize("k,C", [(8, 64), (4, 128), (2, 160)])
@@ -325,17 +327,17 @@ def test_conv3x3_persistent_forward(case):
     wp = pack_w(w, Cp)
     ld_y = Co + 8
     y = torch.zeros(B, H, W, ld_y, dtype=torch.bfloat16, device="cuda")
-    stats = torch.zeros(B, Co // 16, 2, device="cuda")
-    # the persistent kernel writes its GroupNorm sums as per-(tile, wave) partial rows (poisoned here: every row it reads must
-    # have been written) that a finalize kernel folds into `stats`
-    partial = torch.full((B * (-(-H * W // 64)) * (Co // 16) * 2,), float("nan"), device="cuda")
+    stats = zsum(B, Co // 16, 2)
+    # the persistent kernel writes its GroupNorm sums as per-(16 x 32 tile, wave) partial rows (poisoned here: every row it
+    # reads must have been written) that a finalize kernel folds into `stats`
+    partial = torch.full((B * -(-W // 32) * -(-H // 16) * 8 * (Co // 16) * 2,), float("nan"), device="cuda")
     run_conv(xpm, Cp + 16, 8, B, H, W, Cp, wp, Co, 3, 3, 1, 1, H, W, y, ld_y, 8, stats=stats, partial=partial)
     got = y[..., 8:8 + Co].float().cpu().permute(0, 3, 1, 2)
     assert_close(got, ref, f"persistent conv {case}")
     assert float(y[..., :8].float().abs().max()) == 0.0
     gq = got.reshape(B, Co // 16, 16, H * W)
     ref_s = torch.stack([gq.sum((2, 3)), (gq ** 2).sum((2, 3))], -1)
-    assert_close(stats.cpu(), ref_s, f"persistent stats {case}", rel=1e-3, elem=2e-3)
+    assert_close(sval(stats), ref_s, f"persistent stats {case}", rel=1e-3, elem=2e-3)
     # the same launch through the two-workgroup kernel (CRD_CONV3P=0 is read once per process: compare with the torch
     # reference only) -- and a second call must give the same result (the persistent loop leaves no state behind)
     y2 = torch.zeros_like(y)

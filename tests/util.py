@@ -38,3 +38,30 @@ def rel_err(a, b):
 
 def max_err(a, b):
     return float(np.max(np.abs(np.asarray(a, dtype=np.float64) - np.asarray(b, dtype=np.float64))))
+
+
+# ---- crd_sum_t accumulators (include/camradepth_hip.h): 64-bit fixed point, value = integer * 2^-FRAC_BITS ----
+STAT_BITS, GRAD_BITS = 20, 44
+
+
+def zsum(*shape):
+    """A zeroed crd_sum_t buffer on the GPU."""
+    return torch.zeros(*shape, dtype=torch.int64, device="cuda")
+
+
+def sval(t):
+    """Value of forward-statistic / loss sums as fp32 on the host."""
+    return (t.double() * 2.0 ** -STAT_BITS).float().cpu()
+
+
+def gval(t):
+    """Value of gradient sums as fp32 on the host."""
+    return (t.double() * 2.0 ** -GRAD_BITS).float().cpu()
+
+
+def to_stat(x):
+    return (x.double() * 2.0 ** STAT_BITS).round().to(torch.int64)
+
+
+def to_grad(x):
+    return (x.double() * 2.0 ** GRAD_BITS).round().to(torch.int64)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: CamRaDepth training images/s at 256x416, bf16, on N MI355X (one process per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          # N > 1 without a launcher: starts its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A "step" is one full optimizer step (zero grads, forward, masked losses, backward, RCCL gradient
@@ -11,6 +11,8 @@ synthetic image + sparse-radar batch, random-init weights.  Rank 0 prints ONE JS
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -95,11 +97,10 @@ def pmc_traffic(kernel):
     if data.get("csrc_sha") != csrc_sha():
         return None
     ks = data["kernels"]
-    stem = kernel.replace("<*>", "<").rstrip(">").replace(" ", "")
+    prefix = kernel.rstrip("*").replace(" ", "")       # "k_conv3x3*": every instantiation of both 3x3 halo kernels
     n = tot = 0.0
     for name, v in ks.items():
-        nm = name.replace(" ", "")
-        if nm.startswith(stem + ",") or nm.rstrip(">") == stem or (stem.endswith("<") and nm.startswith(stem)):
+        if name.replace(" ", "").startswith(prefix):
             n += v["launches"]
             tot += v["hbm_bytes_per_launch"] * v["launches"]
     return round(tot / n) if n else None
@@ -127,11 +128,11 @@ def forward_only(model, batch, B, H, W, variant, reps=20):
             "mfma_frac": round(ips * FWD_GFLOP[variant] * scale / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
 
-def cpu_baseline(variant, B_gpu=8, H=256, W=416):
+def cpu_baseline(variant, B_gpu=8, H=256, W=416, timed_steps=3):
     """The CPU oracle (oracle/, a port of the reference verified against it) timed on this box's host cores on a
-    bounded sample of the same workload: one warm-up + timed fp32 train steps (forward, losses, backward, diffGradNorm)
-    at batch 2 and at the GPU's batch, and forward-only passes.  `value` is the train-step rate at the
-    GPU's batch; the other legs are listed beside it."""
+    bounded sample of the same workload: 1 warm-up + `timed_steps` timed fp32 train steps (forward, losses, backward,
+    diffGradNorm) at the GPU's per-device batch, and 1 warm-up + 2 timed forward-only passes.  `value` is
+    the train-step rate; torch's default intra-op thread count (the host's physical cores) is used and reported."""
     from camradepth_amd import synth
     from camradepth_amd.config import ModelConfig
     from camradepth_amd.params import param_specs
@@ -139,8 +140,7 @@ def cpu_baseline(variant, B_gpu=8, H=256, W=416):
     from oracle import model as om
     from oracle import optim as oo
     cores = os.cpu_count() or 1
-    threads = min(cores, 64)
-    torch.set_num_threads(threads)
+    threads = torch.get_num_threads()
     cfg = ModelConfig.variant(variant)
     sd = {k: v.clone().requires_grad_(True) for k, v in synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0).items()}
     states = {k: oo.new_state(v.detach()) for k, v in sd.items()}
@@ -166,20 +166,77 @@ def cpu_baseline(variant, B_gpu=8, H=256, W=416):
             fn()
         return (time.time() - t0) / n
     legs = {}
-    b2 = synth.make_batch(2, H, W, seed=1234)
-    m2 = synth.make_masks(cfg, 2, seed=4321)
-    train(b2, m2)                                    # warm-up (thread pool, oneDNN primitive cache)
-    legs["train_b2"] = round(2 / timed(lambda: train(b2, m2), 2), 3)
-    legs["forward_b2"] = round(2 / timed(lambda: fwd(b2), 2), 3)
     bB = synth.make_batch(B_gpu, H, W, seed=1234)
     mB = synth.make_masks(cfg, B_gpu, seed=4321)
-    dt = timed(lambda: train(bB, mB), 1)
-    legs[f"train_b{B_gpu}"] = round(B_gpu / dt, 3)
-    legs[f"forward_b{B_gpu}"] = round(B_gpu / timed(lambda: fwd(bB), 1), 3)
+    train(bB, mB)                                    # warm-up at the timed batch (thread pool, oneDNN primitive cache)
+    legs[f"train_b{B_gpu}"] = round(B_gpu / timed(lambda: train(bB, mB), timed_steps), 3)
+    fwd(bB)
+    legs[f"forward_b{B_gpu}"] = round(B_gpu / timed(lambda: fwd(bB), 2), 3)
     return {"value": legs[f"train_b{B_gpu}"], "unit": "images/s", "cores": threads, "kind": "port", "legs_images_per_s": legs,
-            "sample": f"fp32 CPU oracle, {variant}, 7x{H}x{W}: 1 train step (fwd+loss+bwd+diffGradNorm) at batch {B_gpu} [= value], "
-                      f"2 train steps at batch 2, forward-only 2x batch 2 and 1x batch {B_gpu}; {threads} torch threads of {cores} "
-                      f"host cores"}
+            "sample": f"fp32 CPU oracle, {variant}, 7x{H}x{W}: 1 warm-up + {timed_steps} timed train steps (fwd+loss+bwd+diffGradNorm) "
+                      f"at batch {B_gpu} [= value], 1 warm-up + 2 timed forward-only passes at batch {B_gpu}; {threads} torch "
+                      f"threads on {cores} host CPUs"}
+
+
+# ---- N ranks without a launcher ------------------------------------------------------------------------------------
+def rank_env(rank, world, port, base=None):
+    """Environment of rank `rank` of `world` single-node ranks (one per GPU; rendezvous on 127.0.0.1: the container's
+    host name may not resolve).  HSA_ENABLE_IPC_MODE_LEGACY=0: RCCL needs dmabuf IPC on this driver."""
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return env
+
+
+def free_port():
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def spawn_ranks(world, argv):
+    """`python bench.py --gpus N` started without torchrun: the reference's parallelism is one call (nn.DataParallel,
+    src/main/runner.py:135-136), so is this.  N fresh child processes are started BEFORE this process makes any HIP call
+    (a process that has touched the GPU must not exec another); rank 0's stdout -- the one JSON line -- is passed through,
+    the exit code is the worst of the ranks'."""
+    port = free_port()
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=rank_env(r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p_ in procs[1:]:
+        rc = rc or p_.wait()
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    return rc
+
+
+def stub_rank(a):
+    """--stub (tests): the launcher contract without a GPU -- gloo process group, K sleeps as 'steps' between the same
+    barriers, MAX over ranks of the elapsed time, one JSON line from rank 0."""
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        time.sleep(0.001 * (rank + 1))
+    if world > 1:
+        dist.barrier()
+    t = torch.tensor([time.perf_counter() - t0])
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": metric_name(a), "value": round(a.batch * world * a.steps / float(t), 2), "unit": "images/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "data": "stub"}), flush=True)
+
+
+def metric_name(a):
+    return f"training images/sec at {a.height}x{a.width} bf16"
 
 
 def main():
@@ -202,7 +259,12 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5 -- the ConvLayers of the two largest decoder stages on the fp8 (e4m3) MFMA, activation "
                          "scales calibrated on the bench batch (model.calibrate_fp8); in a training step: fp8 forward, bf16 backward")
+    ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # tests: launcher contract on CPU (gloo)
     a = ap.parse_args()
+    if a.gpus > 1 and "RANK" not in os.environ:       # no launcher: be the launcher (before any HIP call in this process)
+        raise SystemExit(spawn_ranks(a.gpus, sys.argv[1:]))
+    if a.stub:
+        return stub_rank(a)
 
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,7 +335,7 @@ def main():
     ms = 1e3 * dt / a.steps
     value = a.batch * world * a.steps / dt
 
-    out = {"metric": "training images/sec at 256x416 bf16", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+    out = {"metric": metric_name(a), "value": round(value, 2), "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "fp8 forward (decoder stages 3-4) / bf16" if a.fp8 else "bf16", "data": "synthetic",
            "config": {"workload": f"CamRaDepth {a.variant}{' (seg branch frozen)' if a.freeze_seg else ''} (image+radar) train "
@@ -289,13 +351,17 @@ def main():
     if rank == 0 and not a.no_roofline:
         agg = per_kernel_timing(ts)
         # the dominant kernel is a kernel TEMPLATE (all its tile instantiations together): k_conv3x3<*>, k_igemm<*>, ...
+        # -- the 3x3 halo convolution is ONE family: the persistent kernel k_conv3x3p<...> and the two-workgroup kernel
+        # k_conv3x3<...> that takes the small grids and ragged column tails, i.e. every rocprof row `k_conv3x3*`
         fam = {}
         for k, (n_, ms_, fl_) in agg.items():
-            f = fam.setdefault(k.split("<")[0], [0.0, 0.0, 0.0])
+            key = k.split("<")[0]
+            key = "k_conv3x3" if key == "k_conv3x3p" else key
+            f = fam.setdefault(key, [0.0, 0.0, 0.0])
             f[0] += n_ * (1 + k.count("+")); f[1] += ms_; f[2] += fl_     # "a+b": one call, two device launches
         domf = max(fam, key=lambda k: fam[k][1])
         n, ms_tot, fl = fam[domf]
-        dom = domf + "<*>"
+        dom = domf + "*"
         ach = fl / (ms_tot * 1e-3) / 1e12
         out["roofline"] = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                            "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
@@ -310,7 +376,7 @@ def main():
         dist.barrier()
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         small = a.height * a.width <= 256 * 416        # bounded: at larger frames only the batch-2-sized legs fit the time budget
-        out["cpu_baseline"] = cpu_baseline(a.variant, a.batch if small else 1, a.height, a.width)
+        out["cpu_baseline"] = cpu_baseline(a.variant, a.batch if small else 1, a.height, a.width, timed_steps=3 if small else 1)
     if world > 1 or force_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -177,7 +177,18 @@ __device__ __forceinline__ void store8_f32(float* base, int64_t elem_off, const 
 constexpr float STAT_ONE = (float)(1 << CRD_STAT_FRAC_BITS);
 constexpr float GRAD_ONE = (float)(1ll << CRD_GRAD_FRAC_BITS);
 typedef __attribute__((address_space(1))) unsigned long long gsum_raw_t;
-__device__ __forceinline__ long long to_fx(float v, float one) { return __float2ll_rn(v * one); }
+// float -> fixed point, round to nearest even.  The general conversion (__float2ll_rn) expands to ~20 VALU operations; while
+// |v * one| < 2^50 the fp64 adder does the rounding: x + 1.5 * 2^52 has an ulp of exactly 1, so its mantissa bits are the
+// integer (the low dword of the magic constant's bit pattern is zero: taking it off again is one 32-bit subtract).  Both
+// paths round the exact product v * one to nearest even, so they agree bit for bit and the choice is invisible.
+__device__ __forceinline__ long long to_fx(float v, float one) {
+  const float s = v * one;                              // exact (power-of-two scale) unless it overflows to inf
+  if (fabsf(s) < 1125899906842624.f) {                  // 2^50
+    const double d = (double)s + 6755399441055744.0;    // 1.5 * 2^52
+    return __double_as_longlong(d) - 0x4338000000000000ll;
+  }
+  return __float2ll_rn(s);
+}
 __device__ __forceinline__ void fx_add(crd_sum_t* p, long long q) {
   // address space 1 stated explicitly: through a descriptor loaded from memory the compiler would emit a FLAT atomic
   __hip_atomic_fetch_add((gsum_raw_t*)p, (unsigned long long)q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -585,8 +585,8 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
 __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const bf16_t* k, const float* dS, const short* idx,
                                                          long long N, int M, int heads, int d, float scale, int chunk,
                                                          bf16_t* dq, crd_sum_t* dk, int use_lds, float* dk_part, VecBwd vec) {
-  // LDS (use_lds): the workgroup's pixel chunk -- q rows [chunk][CG] (16-byte granules), g = scale*dS [chunk], and a
-  // counting sort of the pixels by (head, arg-max key): count / offset / cursor [heads*M] ints, lists [heads][chunk] shorts
+  // LDS (use_lds): the workgroup's pixel chunk -- q rows [chunk][CG] (16-byte granules), g = scale*dS [chunk], and per
+  // (head, key) a BITMASK over the chunk's pixels: bit n set <=> pixel n's arg-max for that head is this key
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
   // one extra workgroup per sample runs the rank-one vector path of the same backward step (crd_attn_bwd: it depends on
@@ -596,14 +596,12 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > N) p1 = N;
   const int npx = (int)(p1 - p0);
-  const int HM = heads * M;
+  const int HM = heads * M, WPC = (chunk + 31) >> 5;                           // mask words per (head, key)
   uint4* sq = reinterpret_cast<uint4*>(smem);                                  // [chunk][CG]
   float* sg = reinterpret_cast<float*>(smem + (size_t)chunk * C * 2);          // [chunk]
-  int* cnt = reinterpret_cast<int*>(sg + chunk);                               // [HM] -> becomes the fill cursor
-  int* off = cnt + HM;                                                         // [HM + 1] exclusive offsets per head-major key
-  short* lst = reinterpret_cast<short*>(off + HM + 1);                         // [heads][chunk]
+  unsigned* mask = reinterpret_cast<unsigned*>(sg + chunk);                    // [HM][WPC]
   if (use_lds) {
-    for (int i = threadIdx.x; i < HM; i += TPB) cnt[i] = 0;
+    for (int i = threadIdx.x; i < HM * WPC; i += TPB) mask[i] = 0u;
     __syncthreads();
   }
   const long long total = (long long)npx * CG;
@@ -643,7 +641,8 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
         const int nl = (int)(nv[u] - p0);
         sq[nl * CG + cgv[u]] = qraw[u];
         const int h = (cgv[u] * 8) / d;
-        if (cgv[u] * 8 == h * d) atomicAdd(&cnt[h * M + mv[u]], 1);      // one count per (pixel, head): integer LDS atomic
+        // one bit per (pixel, head): integer LDS atomic, the result does not depend on the order
+        if (cgv[u] * 8 == h * d) atomicOr(&mask[(h * M + mv[u]) * WPC + (nl >> 5)], 1u << (nl & 31));
         if (cgv[u] == 0) sg[nl] = gv[u];
       } else {
         float qv[8];
@@ -657,75 +656,37 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
   }
   if (!use_lds) return;
   // dK of the chunk without float atomics (32 ds_add_f32 per thread were 20 of this kernel's 28 us: LDS fp32 atomics
-  // retire about one lane every few cycles): counting-sort the chunk's pixels by (head, key), then the thread that owns
-  // (key m, granule cg) adds up the q rows of the pixels routed to m.
-  __syncthreads();
-  {   // exclusive offsets: one wave per head, a lane owns `per` consecutive keys, shuffle scan over the lanes (the serial
-      // form -- one thread per head, M dependent LDS round trips -- was ~5 us of every launch)
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int per = (M + 63) >> 6;
-    for (int h = wave; h < heads; h += TPB / 64) {
-      int loc = 0;
-      for (int i = 0; i < per; ++i) {
-        const int m = lane * per + i;
-        if (m < M) loc += cnt[h * M + m];
-      }
-      int incl = loc;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const int v = __shfl_up(incl, o);
-        if (lane >= o) incl += v;
-      }
-      int run = h * chunk + incl - loc;              // head h's list occupies lst[h*chunk ...]
-      for (int i = 0; i < per; ++i) {
-        const int m = lane * per + i;
-        if (m < M) {
-          const int c = cnt[h * M + m];
-          off[h * M + m] = run;
-          cnt[h * M + m] = run;                      // fill cursor
-          run += c;
-        }
-      }
-    }
-  }
-  if (threadIdx.x == 0) off[HM] = 0;
-  __syncthreads();
-  for (int i = threadIdx.x; i < npx * heads; i += TPB) {
-    const int nl = i / heads, h = i - nl * heads;
-    const int m = idx[((long long)b * N + p0 + nl) * heads + h];
-    const int pos = atomicAdd(&cnt[h * M + m], 1);
-    lst[pos] = (short)nl;
-  }
+  // retire about one lane every few cycles) and in a FIXED order: the thread that owns (key m, granule cg) walks the set
+  // bits of the key's mask -- the pixels routed to m, in ascending order -- and adds up their q rows.  (Round 2 built
+  // per-key pixel lists with an LDS cursor atomic: a count pass, a scan and a fill pass more, and a summation order that
+  // changed from run to run.)
   __syncthreads();
   float* outp = dk_part ? dk_part + ((long long)blockIdx.x * gridDim.y + b) * M * C : nullptr;
   for (int pr = threadIdx.x; pr < M * CG; pr += TPB) {
     const int m = pr / CG, cg = pr - m * CG;
     const int h = (cg * 8) / d;
-    const int beg = off[h * M + m], end = cnt[h * M + m];     // the cursor stopped at the end of the key's list
-    // The order of a key's list is whatever the LDS cursor atomics above produced, so the products are added in fixed
-    // point: the sum is then independent of that order (run-to-run reproducible dK).
-    long long fx[8];
+    const unsigned* mk = mask + (h * M + m) * WPC;
+    float acc[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) fx[j] = 0;
-    for (int p = beg; p < end; ++p) {
-      const int n = lst[p];
-      const uint4 u = sq[n * CG + cg];
-      const float g = sg[n] * GRAD_ONE;
-      fx[0] += __float2ll_rn(g * bf_lo(u.x)); fx[1] += __float2ll_rn(g * bf_hi(u.x));
-      fx[2] += __float2ll_rn(g * bf_lo(u.y)); fx[3] += __float2ll_rn(g * bf_hi(u.y));
-      fx[4] += __float2ll_rn(g * bf_lo(u.z)); fx[5] += __float2ll_rn(g * bf_hi(u.z));
-      fx[6] += __float2ll_rn(g * bf_lo(u.w)); fx[7] += __float2ll_rn(g * bf_hi(u.w));
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int w = 0; w < WPC; ++w) {
+      unsigned bits = mk[w];
+      while (bits) {
+        const int n = (w << 5) + __builtin_ctz(bits);
+        bits &= bits - 1;
+        const uint4 u = sq[n * CG + cg];
+        const float g = sg[n];
+        acc[0] += g * bf_lo(u.x); acc[1] += g * bf_hi(u.x); acc[2] += g * bf_lo(u.y); acc[3] += g * bf_hi(u.y);
+        acc[4] += g * bf_lo(u.z); acc[5] += g * bf_hi(u.z); acc[6] += g * bf_lo(u.w); acc[7] += g * bf_hi(u.w);
+      }
     }
     if (outp) {
-      float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = (float)fx[j] * (1.f / GRAD_ONE);
       store8_f32(outp, (long long)m * C + cg * 8, acc);
     } else {
       crd_sum_t* dst = &dk[((long long)b * M + m) * C + cg * 8];
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        if (fx[j] != 0) fx_add(dst + j, fx[j]);
+        if (acc[j] != 0.f) grad_add(dst + j, acc[j]);
     }
   }
 }
@@ -910,9 +871,9 @@ extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S
   return CRD_OK;
 }
 
-// LDS of the chunked path: q rows + g + (count, offset) tables + per-head pixel lists of a `chunk`-pixel chunk
+// LDS of the chunked path: q rows + g + one pixel bitmask per (head, key) of a `chunk`-pixel chunk
 static size_t attn_bwd_lds(int chunk, int M, int heads, int C) {
-  return (size_t)chunk * C * 2 + (size_t)chunk * 4 + (size_t)(2 * heads * M + 1) * 4 + (size_t)heads * chunk * 2 + 16;
+  return (size_t)chunk * C * 2 + (size_t)chunk * 4 + (size_t)heads * M * ((chunk + 31) / 32) * 4 + 16;
 }
 // workgroups per sample of the chunked (LDS) path; 0: a chunk does not fit in LDS, the global-atomics path runs
 static int attn_bwd_blocks(int B, int N, int M, int heads, int C) {

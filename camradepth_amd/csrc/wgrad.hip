@@ -212,8 +212,10 @@ long long plan_splits(WgK& k, int tiles, long long want, int min_steps) {
   long long max_splits = (steps + min_steps - 1) / min_steps;
   long long splits = want < 1 ? 1 : want;
   if (splits > max_splits) splits = max_splits;
-  // every split adds Cout x Ktot fp32 atomics: keep the total around 2M per launch (L2 sustains ~170 G atomics/s)
-  const long long atom_cap = (2ll << 20) / ((long long)k.Cout * k.Ktot) + 1;
+  // every split adds Cout x Ktot 64-bit atomics: keep the total around 1M per launch (2M with the fp32 atomics of round 2: 19.90 vs 19.72 ms per step) (L2 sustains ~170 G atomics/s)
+  static long long atom_budget = -1;
+  if (atom_budget < 0) { const char* e = getenv("CRD_WGRAD_ATOMS"); atom_budget = e ? atoll(e) : (1ll << 20); }
+  const long long atom_cap = atom_budget / ((long long)k.Cout * k.Ktot) + 1;
   if (splits > atom_cap) splits = atom_cap;
   if (splits < 1) splits = 1;
   long long chunk_steps = (steps + splits - 1) / splits;

@@ -304,8 +304,8 @@ int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const flo
  * the workgroups store their accumulators there with plain stores and dk is not touched: dk = sum over P, which
  * crd_sum_partials_bf16 folds together with the bf16 conversion the next layer needs.  With dk_partials == NULL they add
  * into dk (crd_sum_t [B][M][C], CRD_GRAD_FRAC_BITS) with atomics (2.7 M of them per launch at stage 1: ~16 us at the
- * ~170 G/s the L2s sustain).  Inside a workgroup the contributions to one key are added in fixed point, so the partial
- * does not depend on the order in which the LDS counting sort listed them. */
+ * ~170 G/s the L2s sustain).  Inside a workgroup the pixels routed to a key are found through a per-key bitmask and added
+ * in ascending pixel order: the partials are reproducible bit for bit. */
 int crd_attn_scores_bwd_partials(int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d);
 int crd_attn_scores_bwd(const void* q, const void* k, const float* dS, const int16_t* idx, int32_t B, int32_t N,
                         int32_t M, int32_t heads, int32_t d, float scale, void* dq, crd_sum_t* dk, float* dk_partials,

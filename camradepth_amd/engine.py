@@ -50,6 +50,15 @@ def gn_conv_default():
     return int(os.environ.get("CRD_GN_CONV", "2") or 0)
 
 
+# Mlp of a Block as ONE launch per (sample, 64-channel hidden slab) + a reduce launch (csrc/mlp_fused.hip) wherever the
+# library covers the shape (Mlp.norm2 group == 64 hidden channels and the pixel grid fits in LDS: encoder stages 3 and 4
+# at 256 x 416).  CRD_MLP_FUSED=0 keeps the four launches (A/B).
+MLP_FUSED = os.environ.get("CRD_MLP_FUSED", "1") != "0"
+# ... up to this many pixels per sample.  One workgroup per (sample, slab) is hidden/64 x B workgroups: at 8 x 13 pixels
+# (stage 4: 128 workgroups) the fused launch takes 18 us against ~45 us for the four it replaces; at 16 x 26 (stage 3: 80
+# workgroups on 256 CUs) it is bound by the VALU work of the stencil / GELU phases on those 80 CUs -- 35 us + the 11 us
+# reduce against 41 us unfused (tools/prof_mlp.py) -- so stage 3 keeps the four launches.
+MLP_FUSED_MAXPIX = int(os.environ.get("CRD_MLP_FUSED_MAXPIX", "128"))
 GN_CONV_MAXROWS = int(os.environ.get("CRD_GN_CONV_MAXROWS", str(1 << 30)))   # pixels x batch up to which a Block's GEMMs are fused
 LATE_WGRAD = os.environ.get("CRD_NO_LATE_WGRAD") is None
 W3_LATE_WGS = int(os.environ.get("CRD_W3_LATE_WGS", "160"))
@@ -189,6 +198,7 @@ class Plan:
         self._side_streams = None
         self.split_late = False            # trainer: ops of stream LATE are skipped by backward() and run by run_late()
         self.attn_parts = None
+        self.mlp_parts = None              # fc2 partial tiles of the fused Mlp: produced and consumed back to back
         self.stats_scratch = None
         self.buffers = []
         # parameters with requires_grad=False (the reference's optimizer skips `grad is None`, diffGradNorm.py:54-55):
@@ -397,6 +407,13 @@ class Plan:
             n.xn, n.xn_ld = (P(sp["xn"]), sp["xn"].ld) if sp["xn"] is not None else (None, 0)
             self.keep.append(n)
             return C.byref(n)
+        if sp.get("mlp"):
+            d = L.MlpDesc()
+            for k_, v in sp["ptrs"].items():
+                setattr(d, k_, P(v))
+            d.B, d.H, d.W, d.C, d.hidden = sp["dims"]
+            self.keep.append(d)
+            return C.byref(d)
         if sp.get("fp8"):
             cw, y = sp["cw"], sp["y"]
             d = L.ConvDesc()
@@ -907,27 +924,46 @@ class Plan:
         H1, H2, H3 = (self.act(hid, Hs, Ws) for _ in range(3))
         sth1, sth2 = self.zf(B, hid // 16, 2), self.zf(B, hid // 16, 2)
         fc1_spec = self.conv_desc(XN2, c1, hid, 1, 1, 0, Hs, Ws, H1, bias=c1.bias, stats=sth1)
-        if fused:            # Block.norm2 applied while fc1 loads X1
-            fc1_spec["x"] = X1
-            self.gn_conv(F_, fc1_spec, st2, 1, name + ".norm2", 0, XN2 if tr else None)
-        else:
-            self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
-            self.conv(F_, fc1_spec)
-        # Mlp.norm1 is applied by the depthwise kernels while they stage H1 (the normalised tensor is never stored)
         n1 = [sth1, 1, self.p(ml + ".norm1.weight"), self.p(ml + ".norm1.bias")]
         w9 = self.new((9, hid), F32)
         self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9))
-        self._emit(F_, "crd_dwconv3x3", [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1 + [None, None, None, None])
         X2 = self.act(Cs, Hs, Ws, F32)
         nxt = (self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)) if (want_next and FUSE_STATS) else None
+        # Mlp.norm1 is applied by the depthwise kernels while they stage H1 (the normalised tensor is never stored)
+        dw_args = [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1 + [None, None, None, None]
         fc2_spec = self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp,
                                   stats=nxt[0] if nxt else None, chan=nxt[1] if nxt else None)
-        if fused and self.gn_conv_on == 1:   # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only)
-            fc2_spec["x"] = H2
-            self.gn_conv(F_, fc2_spec, sth2, ratio, ml + ".norm2", 1, H3 if tr else None)
+        slabs = int(self.lib.crd_mlp_fused_supported(Hs, Ws, Cs, hid)) if (MLP_FUSED and N <= MLP_FUSED_MAXPIX) else 0
+        if slabs > 0:
+            # the whole Mlp per (sample, 64-channel hidden slab) in one launch, its fc2 partial tiles folded (with bias, DropPath
+            # scale, residual and the next block's norm1 sums) by a second one
+            need = slabs * B * N * Cs
+            if self.mlp_parts is None or self.mlp_parts.numel() < need:
+                self.mlp_parts = self.new((need,), F32)
+            ptrs = dict(x1=X1.t, x1_stats=st2, norm_gamma=self.p(name + ".norm2.weight"), norm_beta=self.p(name + ".norm2.bias"),
+                        w_fc1=_WPtr(c1, "w_fwd"), b_fc1=c1.bias, norm1_gamma=n1[2], norm1_beta=n1[3], w9=w9,
+                        b_dw=self.p(ml + ".dwconv.dwconv.bias"), norm2_gamma=self.p(ml + ".norm2.weight"),
+                        norm2_beta=self.p(ml + ".norm2.bias"), w_fc2=_WPtr(c2, "w_fwd"), xn=XN2.t if tr else None,
+                        h1=H1.t if tr else None, h2=H2.t if tr else None, h3=H3.t if tr else None, h1_stats=sth1, h2_stats=sth2,
+                        fc2_partials=_BufPtr(self, "mlp_parts"))
+            op = self._emit(F_, "crd_mlp_fwd", [dict(mlp=True, ptrs=ptrs, dims=(B, Hs, Ws, Cs, hid))])
+            op.meta = {"kernel": "k_mlp_fwd", "flops": 2.0 * B * N * hid * Cs * 2, "shape": f"fused Mlp C{Cs} hid{hid} {Hs}x{Ws}"}
+            self._emit(F_, "crd_mlp_reduce", [_BufPtr(self, "mlp_parts"), slabs, X1.t, c2.bias, dp, B, N, Cs, X2.t,
+                                             nxt[0] if nxt else None, nxt[1] if nxt else None])
         else:
-            self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
-            self.conv(F_, fc2_spec)
+            if fused:            # Block.norm2 applied while fc1 loads X1
+                fc1_spec["x"] = X1
+                self.gn_conv(F_, fc1_spec, st2, 1, name + ".norm2", 0, XN2 if tr else None)
+            else:
+                self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
+                self.conv(F_, fc1_spec)
+            self._emit(F_, "crd_dwconv3x3", dw_args)
+            if fused and self.gn_conv_on == 1:   # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only)
+                fc2_spec["x"] = H2
+                self.gn_conv(F_, fc2_spec, sth2, ratio, ml + ".norm2", 1, H3 if tr else None)
+            else:
+                self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
+                self.conv(F_, fc2_spec)
 
         # ---- backward (executed after the later blocks'; DX holds d(X2) on entry, d(X) on exit) ----
         g = []
@@ -1160,7 +1196,7 @@ class Plan:
     def _resolve(self, a):
         if isinstance(a, dict):
             return self._make_desc(a)
-        if isinstance(a, (_Lazy, _WPtr, torch.Tensor)):
+        if isinstance(a, (_Lazy, _WPtr, _BufPtr, torch.Tensor)):
             return a.data_ptr()
         return a
 
@@ -1298,6 +1334,17 @@ class _WPtr:
 
     def data_ptr(self):
         return getattr(self.cw, self.kind).data_ptr()
+
+
+class _BufPtr:
+    """A plan-owned scratch buffer that may still be re-allocated (grown) while the plan is built, as a raw-pointer op argument."""
+    __slots__ = ("plan", "attr")
+
+    def __init__(self, plan, attr):
+        self.plan, self.attr = plan, attr
+
+    def data_ptr(self):
+        return getattr(self.plan, self.attr).data_ptr()
 
 
 class _Lazy:

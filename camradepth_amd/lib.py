@@ -64,6 +64,13 @@ class PackEntry(C.Structure):
     ]
 
 
+class MlpDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("x1", "x1_stats", "norm_gamma", "norm_beta", "w_fc1", "b_fc1", "norm1_gamma", "norm1_beta",
+                                          "w9", "b_dw", "norm2_gamma", "norm2_beta", "w_fc2", "xn", "h1", "h2", "h3", "h1_stats",
+                                          "h2_stats", "fc2_partials")] + \
+               [(n, C.c_int32) for n in ("B", "H", "W", "C", "hidden")]
+
+
 class UnpackEntry(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("dst", C.c_void_p), ("cmap", C.c_void_p),
@@ -116,6 +123,7 @@ _SIGS = {
     "crd_masked_l1_fwd": "pplpp", "crd_test_metrics": "ppilffpp", "crd_masked_l1_bwd": "pplppfpp", "crd_ce_fwd": "ppiilpp",
     "crd_ce_focal_bwd": "ppiilppfpp",
     "crd_diffgradnorm_step": "pppppppppppiipfffffipp",
+    "crd_mlp_fused_supported": "iiii", "crd_mlp_fwd": "pp", "crd_mlp_reduce": "pipppiiipppp",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "L": C.c_uint64, "f": C.c_float}
 EXPORTS = list(_SIGS)

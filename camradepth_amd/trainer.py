@@ -276,7 +276,7 @@ class TrainStep:
                         segs[0][0]()
                     fn()
                 mains.append(g)
-            chain = []                                       # [(main graph, late graph, bucket key)]
+            chain = []                                       # [(main graph, late graph, bucket key, optimizer-slice graph)]
             for g, key in zip(mains, keys):
                 gl = torch.cuda.CUDAGraph()
                 self.late_stream.wait_stream(main)
@@ -284,14 +284,17 @@ class TrainStep:
                     self.plan.run_late(key)
                     if opt and not self.dist_active:    # this bucket's gradients are final: its optimizer slice follows at once
                         self._optimizer(key)
+                gopt = None
+                if opt and self.dist_active:
+                    # multi-GPU: the bucket's optimizer slice is a graph of its own, replayed on the late stream behind THAT
+                    # bucket's all-reduce (step()), so that the update of the decoder's parameters overlaps the encoder's
+                    # backward and only the last bucket's slice is exposed
+                    gopt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gopt, stream=self.late_stream):
+                        self._optimizer(key)
                 main.wait_stream(self.late_stream)
-                chain.append((g, gl, key))
-            go = None
-            if self.dist_active and opt:           # multi-GPU: the optimizer waits for the all-reduces
-                go = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(go):
-                    segs[-1][0]()
-            return [(("late", g0, chain, go), None)]
+                chain.append((g, gl, key, gopt))
+            return [(("late", g0, chain, None), None)]
         if not self.dist_active:      # no collective between the segments: the whole step is one graph (five fewer launches)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -345,16 +348,16 @@ class TrainStep:
                 if g0 is not None:
                     g0.replay()
                     dist.all_reduce(self.acc, group=self.sync.group)      # global loss denominators before the backward
-                for gm, gl, key in chain:
+                for gm, gl, key, gopt in chain:
                     gm.replay()
                     self.late_stream.wait_stream(main)
                     with torch.cuda.stream(self.late_stream):
                         gl.replay()
                         if self.dist_active and opt:
                             self.sync.launch(key)      # this bucket's all-reduce, behind the graph that finishes its gradients
+                            self.sync.wait()           # (the LATE stream waits for it; the main stream runs on)
+                            gopt.replay()              # ... and the bucket's optimizer slice follows at once
                 main.wait_stream(self.late_stream)
-                if self.dist_active and opt:
-                    self.sync.wait()
                 if go is not None:
                     go.replay()
             elif g is not None:

@@ -261,6 +261,38 @@ int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int32_t H, int
                         const float* in_beta, crd_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Fused Mlp of a Block (Block.forward / Mlp.forward, simplified_attention.py:34-43,141-145):
+ *   x2 = x1 + dp * bf16( fc2( GELU( norm2( dwconv3x3( norm1( fc1( Block.norm2(x1) ) ) ) ) ) ) + b_fc2 )
+ * for blocks whose Mlp.norm2 groups are exactly 64 hidden channels (hidden / (C / 16) == 64: ff_expansion 4, encoder stages
+ * 3 and 4) and whose pixel grid fits in LDS (H * W <= 416): one workgroup per (sample, 64-channel slab of the hidden tensor)
+ * runs the whole chain -- both GroupNorms are per sample and per slab, the depthwise conv per channel -- and leaves its fp32
+ * contribution to fc2 in fc2_partials [hidden/64][B][H*W][C]; crd_mlp_reduce adds the slabs in order and finishes the
+ * residual.  Two launches replace crd_gn_conv(fc1) + crd_dwconv3x3 + crd_gn_apply + crd_conv_igemm(fc2).
+ * x1: fp32 residual stream [B][H*W][C] with its g16 sums x1_stats (Block.norm2's statistics); weights in the packed bf16
+ * forms of crd_weight_pack (w_fc1 [hidden][C], w_fc2 [C][hidden]) and the depthwise fp32 [9][hidden] form.  Optional bf16
+ * outputs (NULL = not stored; the backward pass and the weight gradients read them): xn = Block.norm2(x1) [B][H*W][C],
+ * h1 = fc1 output, h2 = depthwise output, h3 = GELU(norm2(h2)), all [B][H*W][hidden].  h1_stats / h2_stats: their g16
+ * sums [B][hidden/16][2], written with plain stores.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const float* x1; const crd_sum_t* x1_stats; const float* norm_gamma; const float* norm_beta;
+  const void* w_fc1; const float* b_fc1; const float* norm1_gamma; const float* norm1_beta;
+  const float* w9; const float* b_dw; const float* norm2_gamma; const float* norm2_beta;
+  const void* w_fc2;
+  void* xn; void* h1; void* h2; void* h3;
+  crd_sum_t* h1_stats; crd_sum_t* h2_stats;
+  float* fc2_partials;
+  int32_t B, H, W, C, hidden;
+} crd_mlp_desc;
+/* number of 64-channel slabs (= first dimension of fc2_partials) if crd_mlp_fwd covers this shape, else 0 */
+int crd_mlp_fused_supported(int32_t H, int32_t W, int32_t C, int32_t hidden);
+int crd_mlp_fwd(const crd_mlp_desc* d, crd_stream_t stream);
+/* x2 = x1 + dp[b] * bf16(sum_s fc2_partials[s] + b_fc2) (slabs added in order: reproducible; dp may be NULL = 1); optional
+ * g16 sums `stats` [B][C/16][2] and per-channel sums `chan_sums` [B][C][2] of x2 (+=, the next block's norm1 statistics) */
+int crd_mlp_reduce(const float* fc2_partials, int32_t slabs, const float* x1, const float* b_fc2, const float* dp, int32_t B,
+                   int32_t N, int32_t C, float* x2, crd_sum_t* stats, crd_sum_t* chan_sums, crd_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Max-pool attention (Attention_MaxPool.forward, simplified_attention.py:90-109).
  * q: bf16 [B][N][C], k: bf16 [B][M][C], C = heads*d.
  *   S[b][n] = sum_h max_m bf16(bf16(q_h.k_h)*scale)      idx[b][n][h] = argmax m

@@ -87,15 +87,12 @@ def test_inference_graph_equals_eager_eval_forward(variant, B, H, W):
         out = ig.run(x)
         torch.cuda.synchronize()
 
-        def rel(a, b):
-            return float((a.double() - b.double()).norm() / b.double().norm())
-        # GroupNorm statistics are accumulated with fp32 atomics: two runs agree to rounding, not bitwise
-        assert rel(out["depth"]["final_depth"], ref["depth"]["final_depth"]) < 1e-2
-        assert rel(out["depth"]["intermediate_depths"][3], ref["depth"]["intermediate_depths"][3]) < 1e-2
-        assert rel(out["depth"]["intermediate_depths"][2], ref["depth"]["intermediate_depths"][2]) < 1e-2
+        # every multi-workgroup sum is order-independent (crd_sum_t): the graph replay gives the eager forward's bits
+        assert torch.equal(out["depth"]["final_depth"], ref["depth"]["final_depth"])
+        assert torch.equal(out["depth"]["intermediate_depths"][3], ref["depth"]["intermediate_depths"][3])
+        assert torch.equal(out["depth"]["intermediate_depths"][2], ref["depth"]["intermediate_depths"][2])
         if cfg.supervised_seg:
-            # the logits sit behind the non-differentiable arg-max feature of the first seg head: a flipped pixel moves them
-            assert rel(out["seg"]["final_seg"], ref["seg"]["final_seg"]) < 6e-2
+            assert torch.equal(out["seg"]["final_seg"], ref["seg"]["final_seg"])
         else:
             assert out["seg"]["final_seg"] is None
     assert not m.training

@@ -143,6 +143,112 @@ def test_forward_is_bit_reproducible_256x416(variant):
             assert torch.equal(o["seg"]["final_seg"], ref["seg"]["final_seg"])
 
 
+@pytest.mark.parametrize("variant", ["unsupervised_seg", "sup_unsup_seg"])
+def test_seg_variants_256x416_match_reference_golden(variant):
+    """The two remaining model variants (CamRaDepth.py:80-94) at BASELINE's frame size against the reference's own output
+    (tests/golden/make_extra_golden.py)."""
+    from camradepth_amd import losses as hl
+    cfg = ModelConfig.variant(variant)
+    g = load_npz(f"forward256x416_{variant}.npz")
+    model = build(cfg, golden_state_dict(cfg))
+    batch = synth.make_batch(1, 256, 416, seed=1234)
+    with torch.no_grad():
+        out = model(batch["image"].cuda())
+        rmse = float(torch.sqrt(hl.MaskedMSELoss()(out["depth"]["final_depth"], batch["gt_full"].cuda())))
+    r_full = rel(out["depth"]["final_depth"], torch.from_numpy(g["final_depth"]))
+    r_q = rel(out["depth"]["intermediate_depths"][2], torch.from_numpy(g["depth_quarter"]))
+    um = out["seg"]["unsup_map"].cpu().numpy()
+    miss_u = float((np.abs(um - g["unsup_map"].astype(np.float32)) > 1e-3).mean())
+    print(f"{variant} 256x416 vs reference: final {r_full:.4f} quarter {r_q:.4f} unsup-map mismatch {miss_u:.4f} rmse {rmse:.5f} / {float(g['rmse'][0]):.5f}")
+    assert r_full < 0.1 and r_q < 0.15
+    assert abs(rmse - float(g["rmse"][0])) < 3e-2 * float(g["rmse"][0])
+    assert miss_u < 0.25                    # arg-max over 5 near-tied logits of the ill-conditioned golden weights
+    if cfg.supervised_seg:
+        am = out["seg"]["final_seg"].argmax(1).cpu().numpy().astype(np.uint8)
+        assert (am != g["seg_argmax"]).mean() < 0.2
+    else:
+        assert out["seg"]["final_seg"] is None
+
+
+@pytest.mark.parametrize("tag", ["base", "sup_unsup_seg"])
+def test_rgb_only_variants_match_reference_golden(tag):
+    """`--model "base (rgb)"` / `"sup_unsup_seg (rgb)"` (src/utils/args.py:156,164-166): input_channels = 3 -- the camera
+    frame alone, inputs[:, :3] (runner.py:193).  Eval forward at 256x416 against the reference's output; a train-mode
+    iteration at 2x3x64x96 (injected masks): loss terms at bf16 tolerance and per-parameter gradient norms."""
+    from camradepth_amd import losses as hl
+    from camradepth_amd.model import CamRaDepth
+    g = load_npz(f"forward_rgb_{tag}.npz")
+    cfg = dataclasses.replace(ModelConfig.variant(tag), input_channels=3)
+    assert int(g["input_channels"][0]) == 3
+    sd = synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0)
+    m = CamRaDepth(input_channels=3, supervised_seg=cfg.supervised_seg, unsupervised_seg=cfg.unsupervised_seg)
+    assert sum(p.numel() for p in m.parameters()) == int(g["num_params"][0])
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    big = synth.make_batch(1, 256, 416, seed=1234)
+    with torch.no_grad():
+        out = m(big["image"][:, :3].cuda())
+        rmse = float(torch.sqrt(hl.MaskedMSELoss()(out["depth"]["final_depth"], big["gt_full"].cuda())))
+    r_full = rel(out["depth"]["final_depth"], torch.from_numpy(g["e256_final_depth"]))
+    print(f"rgb {tag} 256x416 vs reference: final {r_full:.4f} rmse {rmse:.5f} / {float(g['e256_rmse'][0]):.5f}")
+    assert r_full < 0.1
+    assert abs(rmse - float(g["e256_rmse"][0])) < 3e-2 * float(g["e256_rmse"][0])
+    with pytest.raises(ValueError):
+        m(big["image"].cuda())                       # a 7-channel batch is a caller error, as in the reference's conv
+    m.train()
+    b2 = synth.make_batch(2, 64, 96, seed=77)
+    masks = synth.make_masks(cfg, 2, seed=4321)
+    o = m(b2["image"][:, :3].cuda(), masks=masks)
+    loss, terms = hl.total_loss(o, {k: v.cuda() for k, v in b2.items()}, cfg.supervised_seg)
+    loss.backward()
+    assert abs(float(loss) - g["train_loss"][0]) < 2e-2 * abs(g["train_loss"][0]), (float(loss), g["train_loss"])
+    assert rel(o["depth"]["final_depth"], torch.from_numpy(g["train_final_depth"])) < 0.1
+    names = [n for n, _ in m.named_parameters()]
+    gn = np.array([float(p.grad.norm()) if p.grad is not None else -1.0 for _, p in m.named_parameters()])
+    ref = g["train_gradnorms"]
+    ok = (ref > 1e-12) & (gn >= 0)
+    enc = np.array([n.startswith("dest_encoder.") for n in names])
+    r_dec, r_enc = gn[ok & ~enc] / ref[ok & ~enc], gn[ok & enc] / ref[ok & enc]
+    print(f"rgb {tag}: loss {float(loss):.6f} / {g['train_loss'][0]:.6f}; gradient-norm ratio to the fp32 reference: decoder median "
+          f"{np.median(r_dec):.3f}, encoder median {np.median(r_enc):.3f}")
+    # the decoder's gradients sit in front of the bf16-chaotic encoder (arg-max routing, 34 blocks): tight there, loose behind it
+    # (the oracle itself moves by these amounts between bf16 and fp32, see the module docstring)
+    assert 0.9 < float(np.median(r_dec)) < 1.1 and float(np.percentile(r_dec, 10)) > 0.7 and float(np.percentile(r_dec, 90)) < 1.4
+    assert 0.5 < float(np.median(r_enc)) < 1.5
+
+
+def test_inference_graph_416x800_matches_reference_golden():
+    """SURVEY 8f N4 / VERDICT r2 item 6: the graph-replayed eval forward at the reference's native frame (416 x 800, one frame,
+    Trainer.test's runtime path, runner.py:402-420) against the reference's own output; identical bits to the eager module
+    forward and across replays; the results are fresh tensors (two kept results do not alias)."""
+    from camradepth_amd import losses as hl
+    from camradepth_amd.inference import InferenceGraph
+    cfg = ModelConfig.variant("base")
+    g = load_npz("forward416x800_base.npz")
+    model = build(cfg, golden_state_dict(cfg))
+    ig = InferenceGraph(model, 1, 416, 800)
+    b = synth.make_batch(1, 416, 800, seed=1234)
+    x = b["image"].cuda()
+    out = ig.run(x)
+    out2 = ig.run(synth.make_batch(1, 416, 800, seed=99)["image"].cuda())
+    out3 = ig.run(x)
+    with torch.no_grad():
+        ref = model(x)
+    torch.cuda.synchronize()
+    assert torch.equal(out["depth"]["final_depth"], out3["depth"]["final_depth"])
+    assert not torch.equal(out["depth"]["final_depth"], out2["depth"]["final_depth"])         # kept results do not alias
+    assert torch.equal(out["depth"]["final_depth"], ref["depth"]["final_depth"])
+    assert torch.equal(out["depth"]["intermediate_depths"][3], ref["depth"]["intermediate_depths"][3])
+    rmse = float(torch.sqrt(hl.MaskedMSELoss()(out["depth"]["final_depth"], b["gt_full"].cuda())))
+    r_full = rel(out["depth"]["final_depth"], torch.from_numpy(g["final_depth"].astype(np.float32)))
+    r_half = rel(out["depth"]["intermediate_depths"][3], torch.from_numpy(g["depth_half"].astype(np.float32)))
+    r_q = rel(out["depth"]["intermediate_depths"][2], torch.from_numpy(g["depth_quarter"]))
+    print(f"416x800 graph forward vs reference: final {r_full:.4f} half {r_half:.4f} quarter {r_q:.4f} rmse {rmse:.5f} / {float(g['rmse'][0]):.5f}")
+    assert r_full < 0.1 and r_half < 0.1 and r_q < 0.15          # measured 0.033 / 0.020 / 0.100
+    assert abs(rmse - float(g["rmse"][0])) < 3e-2 * float(g["rmse"][0])
+    assert not model.training
+
+
 def test_rmse_within_1e3_of_fp32_oracle_at_reference_init():
     """North-star accuracy gate: depth RMSE (normalised units, runner.py:208) within 1e-3 of the fp32 reference
     restatement on the fixed synthetic batch (seed 1234), with the reference's own initialisation scheme."""

@@ -388,6 +388,78 @@ def _free_port():
     return str(port)
 
 
+def _train_step_vs_oracle(cfg, B, H, W, freeze_prefix=None, seed=2024):
+    """One training iteration (graph step) of the full-depth model against the CPU oracle in bf16 mode on the same weights,
+    batch and masks: loss terms, total gradient norm and the per-parameter gradient norms (the per-ELEMENT gradients of the
+    full-depth model are chaotic in bf16 -- module docstring of test_gpu_model.py -- their norms are not)."""
+    from camradepth_amd.trainer import TrainStep
+    from oracle import losses as ol
+    from oracle import model as om
+    m = build(cfg)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    frozen = set()
+    if freeze_prefix:
+        for n, p in m.named_parameters():
+            if n.startswith(freeze_prefix):
+                p.requires_grad_(False)
+                frozen.add(n)
+    batch_h = synth.make_batch(B, H, W, seed=seed)
+    masks = synth.make_masks(cfg, B, seed=seed + 1)
+    ts = TrainStep(m, B, H, W, lr=6e-5, use_graph=True)
+    fix_masks(ts, masks)
+    ts.set_batch({k: v.cuda() for k, v in batch_h.items()})
+    p0 = m.flat.clone()
+    ts.step()
+    torch.cuda.synchronize()
+    got = ts.losses()
+    sdo = {k: v.clone().requires_grad_(k not in frozen) for k, v in sd.items()}
+    o = om.forward(sdo, batch_h["image"], cfg, quant="bf16", masks=masks)
+    lo, terms = ol.total_loss(o, batch_h, cfg.supervised_seg)
+    lo.backward()
+    assert abs(got["loss"] - float(lo)) < 3e-3 * abs(float(lo)), (got, float(lo))
+    for k in ("full", "half", "quarter"):
+        assert abs(got[k] - float(terms[k])) < 5e-3 * abs(float(terms[k])), (k, got[k], float(terms[k]))
+    if cfg.supervised_seg:
+        assert abs(got["seg"] - float(terms["seg"])) < 2e-2 * abs(float(terms["seg"])) + 1e-4, (got["seg"], float(terms["seg"]))
+    named = dict(m.named_parameters())
+    tot = ref = 0.0
+    ratios = []
+    for n, _ in param_specs(cfg):
+        go = sdo[n].grad
+        g = named[n].grad
+        if n in frozen:
+            assert g is None, n
+            o_, numel = m._offsets[m._index[n]], named[n].numel()
+            assert torch.equal(m.flat[o_:o_ + numel], p0[o_:o_ + numel]), f"frozen parameter {n} moved"
+            continue
+        if go is None:
+            continue
+        a, b_ = float((g.double() ** 2).sum()), float((go.double() ** 2).sum())
+        tot += a
+        ref += b_
+        if b_ > 1e-16:
+            ratios.append((a / b_) ** 0.5)
+    tot, ref = tot ** 0.5, ref ** 0.5
+    r = np.array(ratios)
+    print(f"{H}x{W} B={B}: loss {got['loss']:.6f} / {float(lo):.6f}; |grad| {tot:.5e} / {ref:.5e}; per-parameter norm ratio median "
+          f"{np.median(r):.3f}, 5-95 % {np.percentile(r, 5):.3f}-{np.percentile(r, 95):.3f}")
+    assert abs(tot - ref) < 0.08 * ref, (tot, ref)
+    assert 0.9 < float(np.median(r)) < 1.1
+    assert float(np.percentile(r, 5)) > 0.6 and float(np.percentile(r, 95)) < 1.6
+
+
+def test_config3_supervised_seg_train_step_at_size_vs_oracle():
+    """BASELINE config 3's per-GPU workload shape (supervised seg branch, full depth, 256 x 416; batch 2 keeps the CPU oracle
+    within seconds): losses incl. the focal term, total and per-parameter gradient norms."""
+    _train_step_vs_oracle(ModelConfig.variant("supervised_seg"), 2, 256, 416)
+
+
+def test_config4_fullres_frozen_seg_train_step_vs_oracle():
+    """BASELINE config 4: one 928 x 1600 frame (900 x 1600 padded to multiples of 32), transfer learning with the seg_* branch
+    frozen: losses, gradient norms, frozen parameters untouched and without gradient."""
+    _train_step_vs_oracle(ModelConfig.variant("supervised_seg"), 1, 928, 1600, freeze_prefix="seg_")
+
+
 def test_distributed_control_flow_single_rank_rccl_equals_plain_step():
     """The distributed branch of TrainStep (g0 / loss all-reduce / per-bucket asynchronous all-reduce on the late stream /
     optimizer graph) in an RCCL group of one, in a fresh child process, applies the same update as the plain step."""

@@ -18,9 +18,10 @@
 // of every (chunk, tap) through a ring requested D steps ahead, counted vmcnt waits, one raw s_barrier per half-step.
 // Plain bf16 output (store or accumulate) with optional GroupNorm sums -- everything the decoder's 3x3 ConvLayers and
 // their data gradients need; bias / activation / fp32 / residual epilogues stay with k_conv3x3.
-// What bounds it (profiles/r02_pmc_kernels.md): the chip's power limit -- 1.5 GHz while it
-// runs, MFMA pipe busy 59 % of those clocks; ring depth, wave count, barriers, waits, the weights' path and the tile order
-// (the compile-time experiments below) all measure the same.
+// What bounds it (profiles/r02_pmc_kernels.md): MFMA pipe busy 59 % of the clocks at an
+// effective 1.5 GHz; ring depth, wave count, barriers, waits, the weights' path (registers + ds_write instead of LDS-DMA),
+// XCD-aware tile order, non-temporal stores and rolled tap loops were all built and measured the same (round 2; the
+// experiment code is in the history of this file up to commit 871691a, not here).
 #include "conv_common.h"
 #include <cstdlib>
 #include <type_traits>
@@ -44,24 +45,6 @@ typedef __attribute__((address_space(3))) void* lds_ptr;
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-// -DCRD_CONV3_ABLATE=bits: parts of the main loop compiled out (timing experiments; results are wrong).  256 no DMA,
-// 16 no vmcnt wait, 32 no barrier, 64 no fragment reads, 128 no MFMA   (tools/ablate_conv.sh FILE=conv3x3p)
-#ifdef CRD_CONV3_ABLATE
-#define ABL(bit) ((CRD_CONV3_ABLATE) & (bit))
-#else
-#define ABL(bit) false
-#endif
-
-// -DCRD_CONV3_PROF: cycles wave 0 of workgroup 0 spends in the main loops and in the epilogues (crd_dbg_conv3p_prof)
-#ifdef CRD_CONV3_PROF
-__device__ unsigned long long g_profp[4];
-#endif
-
-#ifdef CRD_C3P_WCLASSIC        // experiment (see WCL below): measured the same as the LDS-DMA ring, 0.639 ms on 304 -> 128
-constexpr bool WCL = true;
-#else
-constexpr bool WCL = false;
-#endif
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4w;
 #ifndef CRD_C3P_WS
 #define CRD_C3P_WS 5
@@ -72,16 +55,7 @@ template <int TN, int MODE, int WS, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles_x, int tiles_y, int tiles_total) {
   constexpr int TM = TH / NW;                     // 32-pixel row tiles per wave (rows TM w .. TM w + TM - 1 of the tile)
   constexpr int HT = (HG + NW - 1) / NW;          // halo pieces per wave
-  // WCL: the weight slabs take the classic path -- buffer_load to registers (three steps ahead, three register sets used in
-  // turn: nine taps = 3 x 3), ds_write into one of TWO LDS slots a step before they are read -- and only the halo uses
-  // LDS-DMA.  An LDS-DMA instruction lands at ~16 B/clk per CU (64 lanes x 16 B in ~64 cycles; the request stream alone,
-  // with no reads and no MFMAs, takes 0.32 of this kernel's 0.64 ms on 304 -> 128) and the wave that issues it waits when
-  // that queue is full -- with its MFMAs behind it.  Two thirds of the requests were weight slabs.  Result: no change
-  // (0.639 ms either way, 19.7 ms/step either way), so the limit is not the DMA landing rate; the counters (profiles/
-  // r02_pmc_kernels.txt) show 64-byte L2 requests at ~305 cycles, the L1 miss queue stalled 40 % of the time and the
-  // waves 42 % of theirs in s_waitcnt.  Left in as -DCRD_C3P_WCLASSIC.
-  constexpr int D = WCL ? 3 : WS - 1;
-  constexpr int WSL = WCL ? 2 : WS;
+  constexpr int D = WS - 1;
   static_assert(D >= 2 && D <= 8, "slab prefetch distance");
   constexpr int BN = TN * 32;
   constexpr int WGROUPS = BN / 16;                // weight-slab DMA pieces (16 rows x 64 B)
@@ -107,38 +81,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
     const int g = NW * j + wv;
     const int n = 16 * g + (l >> 2), ng = n0 + n;
     wvo[j] = (g < WGROUPS && ng < a.Cout) ? (unsigned)((ng * a.Ktot + wch) * 2) : OOB;
-    if (ABL(8192)) wvo[j] = (unsigned)((n * QK + wch) * 2);     // timing experiment: every slab one contiguous 64 B x BN block
   }
-  u32x4w wq[3][WJ];                                   // WCL: slabs in flight (set = tap % 3)
   auto stage_weights = [&](int chunk, int tap, int slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const int tail = Cin - chunk * QK;
     const bool lane_ok = wch < tail;
-    if (WCL) {                                        // slot = register set; every wave issues WJ loads (uniform wait counts)
-#pragma unroll
-      for (int j = 0; j < WJ; ++j)
-        wq[slot][j] = __builtin_amdgcn_raw_buffer_load_b128(rw, lane_ok ? wvo[j] : OOB, (tap * Cin + chunk * QK) * 2, 0);
-      return;
-    }
 #pragma unroll
     for (int j = 0; j < WJ; ++j) {
       const int g = NW * j + wv;
       bf16_t* dst = g < WGROUPS ? sW + slot * BN * QK + 16 * g * QK : sD;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr)dst, 16, lane_ok ? wvo[j] : OOB,
-                                               ABL(8192) ? (chunk * 9 + tap) * BN * QK * 2 : (tap * Cin + chunk * QK) * 2, 0, 0);
+                                               (tap * Cin + chunk * QK) * 2, 0, 0);
     }
 #else
     (void)chunk; (void)tap; (void)slot;
 #endif
   };
-  auto commit_weights = [&](int set, int slot) {      // WCL: register set -> LDS slot (the lane-linear image the DMA would leave)
-#pragma unroll
-    for (int j = 0; j < WJ; ++j) {
-      const int g = NW * j + wv;
-      if (g < WGROUPS) *reinterpret_cast<u32x4w*>(sW + slot * BN * QK + 16 * g * QK + l * 8) = wq[set][j];
-    }
-  };
-
   // halo pieces of one tile: lane l of piece G stages halo row 16 G + (l>>2), slot l&3 <- granule (l&3) ^ ((row>>2)&3)
   unsigned hvo[HT];
   auto halo_offsets = [&](int tile) {             // tile >= tiles_total: everything out of range (zero fill)
@@ -206,19 +164,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   };
 
-  // Tile order.  Workgroups are dealt to the 8 XCDs round-robin, each XCD has its own L2: in round k workgroup i takes
-  // tile k G + (i % 8) (G / 8) + i / 8, so that the 32 workgroups of an XCD work on 32 NEIGHBOURING tiles (shared halo rows
-  // and columns are fetched into that L2 once).  The last, partial round keeps the plain order (every index stays valid).
-  auto map_tile = [&](int q) {
-#ifdef CRD_C3P_XCD
-    const int G = gridDim.x;
-    if ((G & 7) == 0) {
-      const int k = q / G, i = q - k * G;
-      if ((k + 1) * G <= tiles_total) return k * G + (i & 7) * (G >> 3) + (i >> 3);
-    }
-#endif
-    return q;
-  };
+  // (plain tile order: an XCD-aware order -- the 32 workgroups of an XCD on neighbouring tiles -- measured the same)
+  auto map_tile = [&](int q) { return q; };
   int q = blockIdx.x;
   if (q >= tiles_total) return;
   int tile = map_tile(q);
@@ -233,7 +180,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
     if (++pt == 9) { pt = 0; if (++pc == nChunks) pc = 0; }
   }
   wait_vm<(D - 1) * WJ>();                            // halo + slab 0 have landed
-  if (WCL) { commit_weights(0, 0); __builtin_amdgcn_s_waitcnt(0xC07F); }
   asm volatile("s_barrier" ::: "memory");
   int gchunk = 0;                                     // chunks done so far (all tiles): parity = halo buffer
   int wb = 0, wnext = D % WS;
@@ -247,9 +193,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
     const int tyi = rem / tiles_x, txi = rem - tyi * tiles_x;
     const int ty0 = tyi * TH, tx0 = txi * TW;
     zero_acc();
-#ifdef CRD_CONV3_PROF
-    const unsigned long long pt0 = __builtin_readcyclecounter();
-#endif
     for (int chunk = 0; chunk < nChunks; ++chunk, ++gchunk) {
       const int hb = gchunk & 1;
       const bool last = chunk + 1 == nChunks;
@@ -279,7 +222,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
       // region, and a branch around its reads makes the compiler's lgkmcnt bookkeeping stall the next MFMAs.
       auto step = [&](int tap) __attribute__((always_inline)) {
         // ---- at tap 0 the next halo (next chunk, or chunk 0 of the next tile) ----
-        if (tap == 0 && !ABL(256)) {
+        if (tap == 0) {
           if (last) {                                  // the ring keeps running: first halo of the workgroup's next tile
             const int nb = __builtin_amdgcn_readfirstlane(halo_offsets(tile_next));
             if (tile_next < tiles_total) { b = nb; rx = make_rx(b); }
@@ -289,66 +232,44 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
           }
         }
         // ---- half-step 0: MFMAs on (a0, b0); in their shadow the slab request of step + D and the reads of half-step 1 ----
-        if (!ABL(256)) stage_weights(pc, pt, WCL ? tap % 3 : wnext);
+        stage_weights(pc, pt, wnext);
         if (++pt == 9) { pt = 0; if (++pc == nChunks) pc = 0; }
-        if (!ABL(64)) read_frags(hb, tap, wb, 1, a1, b1);
-        if (!ABL(128)) {
+        read_frags(hb, tap, wb, 1, a1, b1);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
-        } else { acc[0][0][0] += (float)a0[0][0] * (float)b0[0][0]; }
-        if (!ABL(4096)) interleave();
+        interleave();
         // the slab of step+1 (requested D steps before it) has landed: all but the requests of the last D-1 steps (this
         // step's included), which include this chunk's halo burst -- issued BEFORE this step's slab request -- while tap <= D-2
-        if (!ABL(16)) {
         if (tap <= D - 2) wait_vm<(D - 1) * WJ + HT>();
         else wait_vm<(D - 1) * WJ>();
-        }
-        const int wbn = wb + 1 == WSL ? 0 : wb + 1;
-        if (WCL && !ABL(256)) commit_weights((tap + 1) % 3, wbn);    // slab of step+1: read from the other slot after the barrier
+        const int wbn = wb + 1 == WS ? 0 : wb + 1;
         // (the builtin, not inline asm: the compiler's own lgkmcnt bookkeeping must see that nothing is pending here)
         __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): (a1, b1) have arrived, all of this wave's LDS accesses are done
-        if (!ABL(32)) __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();
         wb = wbn;
         wnext = wnext + 1 == WS ? 0 : wnext + 1;
         // ---- half-step 1: MFMAs on (a1, b1); in their shadow the reads of the NEXT step's half-step 0 ----
         const int wrap = tap == 8;
-        if (!ABL(64)) read_frags(hb ^ wrap, wrap ? 0 : tap + 1, wb, 0, a0, b0);
-        if (!ABL(128)) {
+        read_frags(hb ^ wrap, wrap ? 0 : tap + 1, wb, 0, a0, b0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
-        } else { acc[0][0][0] += (float)a1[0][0] * (float)b1[0][0]; }
-        if (!ABL(4096)) interleave();
+        interleave();
       };
       // (tap loops not unrolled: with nine copies the compiler keeps every tap's fragment addresses live -- 345 spilled
       // VGPRs; the address arithmetic of a step, ~60 VALU instructions, hides under its 32 MFMAs)
-#ifdef CRD_C3P_ROLLED
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
       for (int tap = 0; tap < 9; ++tap) step(tap);
     }
-#ifdef CRD_CONV3_PROF
-    const unsigned long long pt1 = __builtin_readcyclecounter();
-#endif
     // ---- epilogue of this wave's 4 x 32 pixels x BN columns, straight from the accumulators ----
     // The MFMA operands are swapped (A = weight rows, B = pixels), so a lane holds ONE pixel (column l&31) and, per 32 x 32
     // tile, the output channels (r&3) + 8 (r>>2) + 4 (l>>5): four runs of 4 consecutive channels.  v_permlane32_swap
     // between the two half-waves (which hold the same pixel) turns two such runs into 8 consecutive channels = one
     // 16-byte store per lane (the CDNA guide's T21).  No LDS staging (the first version's staging strip + barrier-free
     // per-wave copy cost 0.6 ms of a 0.9 ms launch whose main loop takes 0.28 ms), no wait on anything in flight.
-    if (ABL(512)) {       // (every accumulator stays live: an ablation that lets the compiler drop MFMAs measures nothing)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) asm volatile("" :: "v"(acc[i][j][r]));
-    } else
     {
       // lane-constant epilogue values must not be hoisted out of the tile loop (they would be spilled across the main loop
       // and every reload waits vmcnt(0), behind the DMA queue): an opaque copy of the lane id makes them per-tile values
@@ -391,50 +312,42 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ABL(1024)) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(u[j][0].x), "v"(u[j][0].w), "v"(u[j][1].x), "v"(u[j][1].w));
-        } else if (pok) {
+        if (pok) {
           // read-modify-write (gradient accumulation): ALL of the row's loads first, one wait, then the stores -- a load
           // inside the per-store branch made the compiler wait vmcnt(0) before every single store
           if (a.accumulate) {
-            uint4 o[TN][2];
+            // (one 16-channel half of every 32-column tile at a time: all TN x 2 old values live at once cost two spilled
+            // VGPRs in the 128-column variant, and their reload at the top of every tile waits vmcnt(0) behind the ring)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+            for (int pr = 0; pr < 2; ++pr) {
+              uint4 o[TN];
 #pragma unroll
-              for (int pr = 0; pr < 2; ++pr) {
-                o[j][pr] = make_uint4(0, 0, 0, 0);
-                if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) o[j][pr] = *reinterpret_cast<const uint4*>(row + j * 32 + pr * 16);
+              for (int j = 0; j < TN; ++j) {
+                o[j] = make_uint4(0, 0, 0, 0);
+                if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) o[j] = *reinterpret_cast<const uint4*>(row + j * 32 + pr * 16);
               }
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-              for (int pr = 0; pr < 2; ++pr) {
+              for (int j = 0; j < TN; ++j) {
                 uint4& v = u[j][pr];
-                const uint4 q = o[j][pr];
+                const uint4 q = o[j];
                 v.x = pack_bf2(bf_lo(v.x) + bf_lo(q.x), bf_hi(v.x) + bf_hi(q.x));
                 v.y = pack_bf2(bf_lo(v.y) + bf_lo(q.y), bf_hi(v.y) + bf_hi(q.y));
                 v.z = pack_bf2(bf_lo(v.z) + bf_lo(q.z), bf_hi(v.z) + bf_hi(q.z));
                 v.w = pack_bf2(bf_lo(v.w) + bf_lo(q.w), bf_hi(v.w) + bf_hi(q.w));
               }
+            }
           }
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
               if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) {
-#ifdef CRD_C3P_NT_STORE
-                // (experiment: non-temporal output stores, so that the tile's 128 KB do not push the other half of the input
-                // lines out of L2 before the next chunk asks for it)
-                __builtin_nontemporal_store(u32x4w{u[j][pr].x, u[j][pr].y, u[j][pr].z, u[j][pr].w}, reinterpret_cast<u32x4w*>(row + j * 32 + pr * 16));
-#else
                 *reinterpret_cast<uint4*>(row + j * 32 + pr * 16) = u[j][pr];
-#endif
               }
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (a.stats && !ABL(2048)) {
+      if (a.stats) {
         // GroupNorm sums of this wave's part of the tile as one row of plain stores: [image][tile][wave][G16][2], summed by
         // k_stats_finalize.  (Atomics straight into stats: the persistent workgroups reach their epilogues together, and
         // 1024 waves x 16 atomics on the same few cache lines stalled every wave's next vmcnt wait -- 0.4 ms of a 1.1 ms launch.)
@@ -461,12 +374,6 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void k_conv3x3p(ConvK a, int tiles
       __builtin_amdgcn_sched_barrier(0);
       read_frags(gchunk & 1, 0, wb, 0, a0, b0);
     }
-#ifdef CRD_CONV3_PROF
-    if (blockIdx.x == 0 && blockIdx.y == 0 && t == 0) {
-      const unsigned long long pt2 = __builtin_readcyclecounter();
-      g_profp[0] += pt1 - pt0; g_profp[1] += pt2 - pt1; g_profp[2] += 1;
-    }
-#endif
   }
   wait_vm<0>();
 }
@@ -505,13 +412,6 @@ int waves_per_wg() {
 inline long long partial_rows(const ConvK& k) { return (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * waves_per_wg(); }
 
 }  // namespace
-
-#ifdef CRD_CONV3_PROF
-extern "C" int crd_dbg_conv3p_prof(unsigned long long* out, int reset) {
-  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_profp), z, sizeof(z)); }
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_profp), sizeof(g_profp));
-}
-#endif
 
 // Can the persistent kernel take (part of) this launch?  Plain bf16 store / accumulate with optional GroupNorm sums, on
 // grids with enough 16 x 32 tiles to occupy the chip.

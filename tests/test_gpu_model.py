@@ -21,8 +21,13 @@ from camradepth_amd.params import param_specs
 from tests.util import golden_state_dict, load_npz
 
 pytestmark = pytest.mark.gpu
-# measured on MI355X over repeated runs (see the test's printout in profiles/r02_gpu_tests.log); bound = 2x the largest
-RMSE_GAP_GOLDEN_256 = 1.5e-2       # measured 4e-4 .. 6.9e-3 (0.65 % of the reference RMSE 1.065 these weights give)
+# |RMSE(HIP bf16) - RMSE(reference fp32)| with the golden weights at 256x416, normalised depth units.  Every run gives the same
+# bits now (crd_sum_t accumulators): measured 4.096e-3 on MI355X, three runs identical (profiles/r03_gpu_tests.log; round 2:
+# 1.3e-3 .. 9.2e-3 from run to run).  The CPU oracle's own bf16-vs-fp32 gap on the same fixture is 5.09e-3
+# (tests/golden/oracle_bf16_gap.json, tools/oracle_bf16_gap.py): with these deliberately ill-conditioned weights the north-star
+# 1e-3 is below the bf16 floor of the reference's own arithmetic, so the 1e-3 gate is asserted at the reference's
+# initialisation (test_rmse_within_1e3_of_fp32_oracle_at_reference_init) and this bound is 2x the measured value.
+RMSE_GAP_GOLDEN_256 = 8.2e-3
 VARIANTS = ["base", "supervised_seg", "unsupervised_seg", "sup_unsup_seg"]
 
 
@@ -367,6 +372,7 @@ def test_rmse_gap_with_golden_weights_256x416():
             rmse = float(torch.sqrt(hl.MaskedMSELoss()(out["depth"]["final_depth"], batch["gt_full"].cuda())))
         gaps.append(abs(rmse - float(g["loss"][5])))
     print(f"RMSE gap to the reference golden at 256x416 (golden weights): {gaps}, reference RMSE {float(g['loss'][5]):.6f}")
+    assert gaps[0] == gaps[1] == gaps[2], gaps              # bit-reproducible forward
     assert max(gaps) < RMSE_GAP_GOLDEN_256, gaps
 
 

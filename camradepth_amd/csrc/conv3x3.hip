@@ -333,7 +333,12 @@ extern "C" int crd_tune_conv3x3_small_grid(int workgroups) {
 int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_cap) {
   // persistent one-wave-per-SIMD kernel (conv3x3p.hip) for the 128-column tiles (96 / 64 columns: one narrower tile).  Its
   // GroupNorm sums need the caller's partial-sum buffer; without one (or a too small one) the launch stays here.
-  if (crd_conv3x3p_applicable(k, B) && (!k.stats || (k.stats_partial && crd_conv3x3p_partial_floats(k, B) <= partial_cap))) {
+  // (a launch WITH GroupNorm sums whose column count leaves a ragged tail of <= 64 columns -- e.g. Cout 160 / 192 / 288; no
+  // layer of the model -- would need its sums split over two kernels: it stays with the two-workgroup kernel below)
+  const int rest128 = k.Cout > 96 ? k.Cout % 128 : 0;
+  const bool ragged_stats = k.stats && rest128 > 0 && rest128 <= 64;
+  if (crd_conv3x3p_applicable(k, B) && !ragged_stats &&
+      (!k.stats || (k.stats_partial && crd_conv3x3p_partial_floats(k, B) <= partial_cap))) {
     // a ragged tail of <= 64 columns (data gradients towards 136 / 144 / 296 / 304 channels) goes to the narrow tiles here
     const int N = k.Cout;
     int rc;
@@ -343,7 +348,6 @@ int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_ca
       const int full = N / 128 * 128, rest = N - full;
       if (rest == 0 || rest > 64) rc = crd_conv3x3p(k, B, st, 0, N, 4);
       else {
-        CRD_UNSUPPORTED(!k.stats, "crd_conv_igemm: GroupNorm sums with a ragged column tail are not split over two kernels");
         rc = crd_conv3x3p(k, B, st, 0, full, 4);
         if (rc != CRD_OK) return rc;
         ConvK kt = k;

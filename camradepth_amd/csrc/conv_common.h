@@ -19,7 +19,7 @@ struct ConvK {
   int lds_bytes;   // dynamic LDS of the launch (the fp32 staging tile needs BM x (BN+4) floats)
   // Optional: reduce phase of the backward of the GroupNorm (+GELU) whose dy this launch produces (vector path only).
   // red_x = that GroupNorm's raw bf16 input [pixels][red_x_ld], batch stride red_x_bstride; r as in crd_gn_bwd_reduce.
-  const bf16_t* red_x; int red_x_ld; long long red_x_bstride;
+  const void* red_x; int red_x_f32; int red_x_ld; long long red_x_bstride;   // bf16, or fp32 when red_x_f32 (the residual stream)
   const crd_sum_t* red_stats; const float* red_gamma; const float* red_beta; int red_gmul, red_act;
   crd_sum_t* red_r;
   crd_sum_t* chan;   // optional per-channel (sum, sumsq) of the stored output [B][Cout][2] (scalar epilogue path only)
@@ -132,9 +132,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
         }
         *reinterpret_cast<uint4*>(dst) = u;
         if (redo) {
-          const uint4 xv = *reinterpret_cast<const uint4*>(a.red_x + (long long)b * a.red_x_bstride + (long long)p * a.red_x_ld + col);
+          float xq[8];
+          load8(a.red_x, (long long)b * a.red_x_bstride + (long long)p * a.red_x_ld + col, a.red_x_f32, xq);
           const float dq[8] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y), bf_lo(u.z), bf_hi(u.z), bf_lo(u.w), bf_hi(u.w)};
-          const float xq[8] = {bf_lo(xv.x), bf_hi(xv.x), bf_lo(xv.y), bf_hi(xv.y), bf_lo(xv.z), bf_hi(xv.z), bf_lo(xv.w), bf_hi(xv.w)};
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             const float xh = (xq[j] - rmean) * rrstd;

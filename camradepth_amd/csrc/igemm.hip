@@ -279,7 +279,7 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   k.vecf_ok = d->y_f32 && d->y_coff % 4 == 0 && d->y_ld % 4 == 0 && d->Cout % 4 == 0 && (reinterpret_cast<uintptr_t>(d->y) & 15) == 0 &&
               (!d->res || (d->res_ld % 4 == 0 && (reinterpret_cast<uintptr_t>(d->res) & 15) == 0));
   k.lds_bytes = 0;
-  k.red_x = reinterpret_cast<const bf16_t*>(d->red_x); k.red_x_ld = d->red_x_ld;
+  k.red_x = d->red_x; k.red_x_f32 = d->red_x_f32; k.red_x_ld = d->red_x_ld;
   k.red_x_bstride = (long long)YH * YW * d->red_x_ld;
   k.red_stats = d->red_stats; k.red_gamma = d->red_gamma; k.red_beta = d->red_beta; k.red_gmul = d->red_gmul;
   k.red_act = d->red_act; k.red_r = d->red_r;

@@ -30,7 +30,7 @@ class ConvDesc(C.Structure):
         ("accumulate", C.c_int32), ("stats", C.c_void_p),
         ("stats_partial", C.c_void_p), ("stats_partial_capacity", C.c_int64),
         ("red_x", C.c_void_p), ("red_x_ld", C.c_int32), ("red_gmul", C.c_int32), ("red_act", C.c_int32),
-        ("red_reserved", C.c_int32), ("red_stats", C.c_void_p), ("red_gamma", C.c_void_p), ("red_beta", C.c_void_p),
+        ("red_x_f32", C.c_int32), ("red_stats", C.c_void_p), ("red_gamma", C.c_void_p), ("red_beta", C.c_void_p),
         ("red_r", C.c_void_p), ("chan_sums", C.c_void_p),
     ]
 

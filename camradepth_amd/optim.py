@@ -123,6 +123,14 @@ class diffGradNorm(Optimizer):
             for p, a_ in zip(ps, act_host):
                 if a_:
                     self.state[p]["step"] += 1
+            # The kernel's bias corrections use ONE step count per group.  The reference keeps one per parameter
+            # (diffGradNorm.py:66,76-77): they differ only for a parameter that is frozen for some steps and unfrozen later
+            # (or a checkpoint with non-uniform steps).  Refuse that silently-different case instead of approximating it.
+            steps = {self.state[p]["step"] for p, a_ in zip(ps, act_host) if a_}
+            if len(steps) > 1:
+                raise L.CrdError("camradepth_amd.diffGradNorm: parameters of one group have different step counts "
+                                 f"({sorted(steps)}): unfreezing a parameter mid-run (or loading such a checkpoint) needs one "
+                                 "param_group per step count")
         return loss
 
     def load_state_dict(self, state_dict):

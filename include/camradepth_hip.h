@@ -87,12 +87,12 @@ typedef struct {
   int64_t stats_partial_capacity; /* floats available in stats_partial; needs B*ceil(OH*OW/64)*(Cout/16)*2 */
   /* Optional (red_x != NULL; bf16 output, no residual, Cout > 160, not the 3x3 halo shapes): this launch produces the dy
    * of a GroupNorm (+GELU) backward -- e.g. the data gradient of Mlp.fc2 feeding Mlp.norm2 -- and also computes that
-   * backward's reduce phase: red_x is the GroupNorm's raw bf16 input laid out like y (pixel-major, red_x_ld channels per
+   * backward's reduce phase: red_x is the GroupNorm's raw input (bf16, or fp32 with red_x_f32) laid out like y (pixel-major, red_x_ld channels per
    * pixel, same pixel grid), red_stats its g16 sums, red_gmul its slabs per group, red_act 1 for GELU; red_r is the
    * buffer crd_gn_bwd_reduce would fill (crd_sum_t [B*Cout*2 + B*(Cout/(16*red_gmul))*2], zeroed by the caller).  Only
    * crd_gn_bwd_apply remains to be called. */
   const void* red_x;
-  int32_t red_x_ld, red_gmul, red_act, red_reserved;
+  int32_t red_x_ld, red_gmul, red_act, red_x_f32;   /* red_x_f32 = 1: red_x holds fp32 (the encoder's residual stream) */
   const crd_sum_t* red_stats;
   const float* red_gamma;
   const float* red_beta;

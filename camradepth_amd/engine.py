@@ -121,6 +121,16 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
     return "k_igemm<2,2,2,2>"
 
 
+FUSE_BLOCK_RED = os.environ.get("CRD_NO_FUSE_BLOCK_RED") is None    # developer switch (A/B): Block.norm1 / norm2 reduces in GEMM epilogues
+
+
+def fused_reduce_tile_ok(cout, ohw, B):
+    """crd_conv_igemm's rule for red_x (csrc/igemm.hip): the fused GroupNorm-backward reduce lives in the vector epilogue of the
+    32 / 64 / 128-column tiles (small grids always use 64-column tiles), not the 96- and 160-column ones."""
+    small = cout > 32 and -(-ohw // 128) * -(-cout // 128) * B < 192
+    return FUSE_BLOCK_RED and cout % 16 == 0 and (small or cout <= 64 or 96 < cout <= 128 or cout > 160)
+
+
 def persistent_conv3(spec, B):
     """Does crd_conv_igemm send this 3x3 launch to the persistent one-wave-per-SIMD kernel (csrc/conv3x3p.hip)?  Plain bf16
     store / accumulate (+ GroupNorm sums) on grids of >= 192 tiles of 16 x 32 pixels."""
@@ -464,7 +474,7 @@ class Plan:
             if sp.get("red") is not None:        # fused reduce phase of the GroupNorm backward this output feeds
                 rx, rstats, rgamma, rbeta, rgmul, ract, rr = sp["red"]
                 assert rx.coff == 0, "the fused reduce reads the GroupNorm input from channel 0"
-                d.red_x, d.red_x_ld, d.red_gmul, d.red_act = P(rx), rx.ld, rgmul, ract
+                d.red_x, d.red_x_ld, d.red_gmul, d.red_act, d.red_x_f32 = P(rx), rx.ld, rgmul, ract, rx.f32
                 d.red_stats, d.red_gamma, d.red_beta, d.red_r = P(rstats), P(rgamma), P(rbeta), P(rr)
             # stats_partial stays NULL: workgroup-level sums go in with one fp32 atomic each.  The library's deterministic
             # partial-store + finalize path measured the same step time (34.6 vs 34.9 ms) and costs 261 more dispatches.
@@ -995,8 +1005,12 @@ class Plan:
                                         H1.t, sth1, self.p(ml + ".norm1.weight"), r1])
         self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2, r=r1)             # in place: d(H1)
         self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=ml + ".fc1.bias")
-        self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1))
-        self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1)              # DX = d(X1)
+        # fc1's data gradient also runs the reduce phase of Block.norm2's backward on its own output (a launch less per block;
+        # the GroupNorm's input is the fp32 residual stream: red_x_f32)
+        rb2 = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if (FUSE_STATS and fused_reduce_tile_ok(Cs, N, B)) else None
+        redb2 = None if rb2 is None else (X1, st2, self.p(name + ".norm2.weight"), self.p(name + ".norm2.bias"), 1, 0, rb2)
+        self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, red=redb2))
+        self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1, r=rb2)       # DX = d(X1)
         # attention branch
         T, dSv = self.zb(B, Cs), self.new((B, N), F32)
         dbp_rows = self.zb(B, Cs)
@@ -1020,7 +1034,16 @@ class Plan:
             self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None] + vec)
         self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
         self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=a + ".q.bias")
-        self.conv(g, self.conv_desc(DQ, ("dgrad", cq), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, bias=Es.t, bias_bstride=Cs))
+        # d(norm1(X)) = q's data gradient (+ the rank-one vector path's Es) + the key path's.  With the fused reduce the key path
+        # writes DXN first (its patches cover every pixel once) and q's data gradient goes LAST: it accumulates and, being the
+        # final writer in the plain layout, also runs the reduce phase of Block.norm1's backward (fp32 input X): a launch less.
+        rb1 = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if (FUSE_STATS and fused_reduce_tile_ok(Cs, N, B)) else None
+        q_dgrad = self.conv_desc(DQ, ("dgrad", cq), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, bias=Es.t, bias_bstride=Cs)
+        if rb1 is None:
+            self.conv(g, q_dgrad)
+        else:
+            q_dgrad.update(accumulate=1, red=(X, st1, self.p(name + ".norm1.weight"), self.p(name + ".norm1.bias"), 1, 0, rb1))
+        key_acc = 1 if rb1 is None else 0
         DKb = self.act(Cs, Hs // sr, Ws // sr)
         if dK is None:
             self._emit(g, "crd_sum_partials_bf16", [self.attn_parts, nparts, B * M * Cs, DKb.t, B * M * Cs])
@@ -1036,11 +1059,13 @@ class Plan:
             self.gn_bwd(g, KR, stk, 1, a + ".norm", 0, None, DKR, DKR, r=rk)
             self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=a + ".sr.bias")
             self.conv(g, self.conv_desc(DKR, ("scatter", csr), sr * sr * Cs, 1, 1, 0, Hs // sr, Ws // sr, DXN, out_mode=1,
-                                        patch_k=sr, patch_c=Cs, accumulate=1))
+                                        patch_k=sr, patch_c=Cs, accumulate=key_acc))
         else:
             self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=a + ".k.bias")
-            self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=1))
-        self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1,                # DX = d(X)
+            self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=key_acc))
+        if rb1 is not None:
+            self.conv(g, q_dgrad)
+        self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1, r=rb1,         # DX = d(X)
                     dx2=dh_prev[0] if dh_prev else None, scale2=dh_prev[1] if dh_prev else None)
         self._push(g)
         return X2, nxt, dh_out

@@ -74,6 +74,7 @@ def run_conv(xpm, x_ld, x_coff, B, IH, IW, Cin, wp, Cout, KH, KW, stride, pad, O
     if red is not None:
         rx, rstats, rgamma, rbeta, rgmul, ract, rr = red
         d.red_x, d.red_x_ld, d.red_gmul, d.red_act = rx.data_ptr(), rx.shape[-1], rgmul, ract
+        d.red_x_f32 = 1 if rx.dtype == torch.float32 else 0
         d.red_stats, d.red_gamma, d.red_beta, d.red_r = rstats.data_ptr(), rgamma.data_ptr(), rbeta.data_ptr(), rr.data_ptr()
     lib.check(L.crd_conv_igemm(C.byref(d), lib.stream()), "crd_conv_igemm")
     torch.cuda.synchronize()
@@ -244,8 +245,11 @@ def test_conv_dgrad_gather_mode(case):
     assert_close(dx.float().cpu().permute(0, 3, 1, 2), x.grad, f"dgrad {case}")
 
 
-@pytest.mark.parametrize("Ci,Co,H,W,gmul,act", [(640, 160, 16, 26, 4, 1), (512, 64, 24, 40, 8, 1), (256, 64, 9, 7, 1, 0), (1024, 256, 2, 3, 4, 1), (1024, 256, 8, 13, 4, 1)])
-def test_conv_dgrad_with_fused_groupnorm_backward_reduce(Ci, Co, H, W, gmul, act):
+@pytest.mark.parametrize("Ci,Co,H,W,gmul,act,xf32", [(640, 160, 16, 26, 4, 1, 0), (512, 64, 24, 40, 8, 1, 0), (256, 64, 9, 7, 1, 0, 0),
+                                                      (1024, 256, 2, 3, 4, 1, 0), (1024, 256, 8, 13, 4, 1, 0),
+                                                      # Mlp.fc1's data gradient feeding Block.norm2 (fp32 residual stream, no activation)
+                                                      (160, 640, 16, 26, 1, 0, 1), (128, 1024, 32, 52, 1, 0, 1), (64, 512, 64, 104, 1, 0, 1)])
+def test_conv_dgrad_with_fused_groupnorm_backward_reduce(Ci, Co, H, W, gmul, act, xf32):
     """Data gradient of a 1x1 conv (Mlp.fc2) that also runs the reduce phase of the GroupNorm(+GELU) backward on its own
     output: same dx, and r equal to crd_gn_bwd_reduce on (x_gn, dx).  Both tile configurations (64- and 128-wide)."""
     lib = _lib()
@@ -257,14 +261,16 @@ def test_conv_dgrad_with_fused_groupnorm_backward_reduce(Ci, Co, H, W, gmul, act
     wd = w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 1, Co).to(torch.bfloat16).cuda()
     dypm = to_pm(dy)
     xg = to_pm(bf(torch.randn(B, Ci, H, W, generator=g) * 1.3 + 0.2))       # the GroupNorm's raw input, [B, H*W, Ci]
+    if xf32:
+        xg = (xg.float() + 0.001 * torch.randn(xg.shape, generator=g).cuda()).contiguous()
     gam, bet = (1 + 0.1 * torch.randn(Ci, generator=g)).cuda(), (0.1 * torch.randn(Ci, generator=g)).cuda()
     stats = zsum(B, Ci // 16, 2)
-    lib.check(L.crd_gn_stats(xg.data_ptr(), 0, Ci, 0, B, H * W, Ci, stats.data_ptr(), None, lib.stream()), "gn_stats")
+    lib.check(L.crd_gn_stats(xg.data_ptr(), xf32, Ci, 0, B, H * W, Ci, stats.data_ptr(), None, lib.stream()), "gn_stats")
     G = Ci // (16 * gmul)
     dx0 = torch.zeros(B, H, W, Ci, dtype=torch.bfloat16, device="cuda")
     run_conv(dypm, Co, 0, B, H, W, Co, wd, Ci, 1, 1, 1, 0, H, W, dx0, Ci, 0, gather_mode=1)
     r_ref = zsum(B * Ci * 2 + B * G * 2)
-    lib.check(L.crd_gn_bwd_reduce(xg.data_ptr(), 0, Ci, 0, dx0.data_ptr(), 0, Ci, 0, B, H * W, Ci, stats.data_ptr(), gmul,
+    lib.check(L.crd_gn_bwd_reduce(xg.data_ptr(), xf32, Ci, 0, dx0.data_ptr(), 0, Ci, 0, B, H * W, Ci, stats.data_ptr(), gmul,
                                   gam.data_ptr(), bet.data_ptr(), act, None, r_ref.data_ptr(), None, 0, lib.stream()), "gn_bwd_reduce")
     dx1 = torch.zeros_like(dx0)
     r = torch.zeros_like(r_ref)

@@ -1,5 +1,6 @@
 // Encoder-side kernels for gfx950: depthwise 3x3 (+wgrad) and the max-pool attention of the
 // Simplified Transformer (fused QK^T + scale + row-max on MFMA, rank-1 output, backward).
+#include <stdlib.h>
 #include "common.h"
 
 namespace {
@@ -718,6 +719,15 @@ __global__ __launch_bounds__(TPB) void k_gsum_to_bf16(const crd_sum_t* src, bf16
 
 }  // namespace
 
+// tile width: 32; 16 for images at most 16 pixels wide (W = 13).  (Round 2 chose 16 whenever it wasted fewer columns -- W = 104:
+// 112 instead of 128 -- but the 32-wide tiles are faster there: 19.56 -> 19.48 ms per step.)  CRD_DW_TW (developer switch) forces one.
+static int dw_tile_width(int W) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("CRD_DW_TW"); forced = e ? atoi(e) : 0; }
+  if (forced == 16 || forced == 32) return forced;
+  return W <= 16 ? 16 : 32;
+}
+
 extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int32_t C, const float* w9, const float* bias,
                              int32_t flip, void* y, crd_sum_t* stats, const crd_sum_t* in_stats, int32_t in_gmul,
                              const float* in_gamma, const float* in_beta, const void* red_x, const crd_sum_t* red_stats,
@@ -732,7 +742,7 @@ extern "C" int crd_dwconv3x3(const void* x, int32_t B, int32_t H, int32_t W, int
   bf16_t* yp = reinterpret_cast<bf16_t*>(y);
   hipStream_t st = as_stream(stream);
   // tile width: 32, or 16 when that wastes fewer columns (W = 13: 16 instead of 32)
-  const int tw = (cdiv(W, 16) * 16 < cdiv(W, 32) * 32) ? 16 : 32;
+  const int tw = dw_tile_width(W);
   const int tiles_x = cdiv(W, tw), tiles_y = cdiv(H, DTH);
   dim3 grid(tiles_x * tiles_y, cdiv(C, DCW), B);
 #define CRD_DW(FL, STT, TWV) hipLaunchKernelGGL((k_dwconv<FL, STT, TWV>), grid, dim3(TPB), 0, st, xp, H, W, C, w9, bias, yp, stats, tiles_x, inn, red)
@@ -755,7 +765,7 @@ extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int
   CRD_CHECK_ARG(!in_stats || (in_gamma && in_beta && in_gmul >= 1 && (C / 16) % in_gmul == 0), "crd_dwconv3x3_wgrad: bad input-norm arguments");
   const InNorm inn{in_stats, in_gamma, in_beta, in_gmul};
   CRD_CHECK_ARG(C % 16 == 0 && C <= 4096, "crd_dwconv3x3_wgrad: C must be a multiple of 16, <= 4096");
-  const int tw = (cdiv(W, 16) * 16 < cdiv(W, 32) * 32) ? 16 : 32;
+  const int tw = dw_tile_width(W);
   const int tiles_x = cdiv(W, tw), tiles_y = cdiv(H, DTH), wins = cdiv(C, DCW);
   // vertical runs of tiles per workgroup: as long as possible (one fold + one set of atomics per run) while ~512
   // workgroups (two per CU: 76 KB of LDS each) remain

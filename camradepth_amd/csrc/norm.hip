@@ -412,10 +412,10 @@ inline void grid_for(long long P, int C, int B, dim3& grid, int& chunk, bool red
   int PL = TPB / CG; if (PL < 1) PL = 1;
   long long per_block = (long long)PL * 8;         // >= 8 pixels per pixel-lane (two batches of U loads)
   long long nblk = (P + per_block - 1) / per_block;
-  static int minpix = -1, small = 128;
+  static int minpix = -1, small = 256;
   if (minpix < 0) {
     const char* e = getenv("CRD_GN_MINPIX"); minpix = e ? atoi(e) : 2;
-    e = getenv("CRD_GN_SMALL"); small = e ? atoi(e) : 128;
+    e = getenv("CRD_GN_SMALL"); small = e ? atoi(e) : 256;
   }
   if (nblk * B < small && minpix < 8) {              // small grids: fewer pixels per lane rather than idle CUs
     per_block = (long long)PL * minpix;

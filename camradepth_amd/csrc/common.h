@@ -199,16 +199,24 @@ __device__ __forceinline__ float stat_get(const crd_sum_t* p) { return (float)(*
 __device__ __forceinline__ float grad_get(const crd_sum_t* p) { return (float)(*p) * (1.f / GRAD_ONE); }
 
 // mean / rstd of GroupNorm group from g16 slab sums: group = gmul consecutive slabs starting at slab0
-__device__ __forceinline__ void gn_mean_rstd(const crd_sum_t* stats_b, int slab0, int gmul, float inv_count, float& mean,
-                                             float& rstd) {
+// mean and 1/sqrt(var + eps) of `count` elements from their fixed-point sums.  E[x^2] - mean^2 in fp64: in fp32 the difference
+// loses mean^2 / var of its 24 bits (groups whose mean is 30x their deviation kept 14), fp64 keeps what the integer sums hold.
+// count (pixels x channels of the group) is exact in a float up to 2^28 elements (it is a multiple of 16).
+__device__ __forceinline__ void gn_moments(long long s, long long ss, float count, float& mean, float& rstd) {
+  const double inv = 1.0 / ((double)count * (double)STAT_ONE);
+  const double m = (double)s * inv;
+  const double var = fmax((double)ss * inv - m * m, 0.0);
+  mean = (float)m;
+  rstd = (float)(1.0 / sqrt(var + (double)GN_EPS));
+}
+
+__device__ __forceinline__ void gn_mean_rstd(const crd_sum_t* stats_b, int slab0, int gmul, float count, float& mean, float& rstd) {
   long long s = 0, ss = 0;
   for (int i = 0; i < gmul; ++i) {
     s += stats_b[(slab0 + i) * 2];
     ss += stats_b[(slab0 + i) * 2 + 1];
   }
-  mean = (float)s * (1.f / STAT_ONE) * inv_count;
-  float var = fmaxf((float)ss * (1.f / STAT_ONE) * inv_count - mean * mean, 0.f);
-  rstd = rsqrtf(var + GN_EPS);
+  gn_moments(s, ss, count, mean, rstd);
 }
 
 static inline hipStream_t as_stream(crd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

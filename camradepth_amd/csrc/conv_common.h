@@ -67,7 +67,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
       if (rcol < a.Cout) {
         const int cpg = 16 * a.red_gmul;
         gn_mean_rstd(a.red_stats + (long long)b * (a.Cout >> 4) * 2, (rcol / cpg) * a.red_gmul, a.red_gmul,
-                     1.f / ((float)a.OHW * cpg), rmean, rrstd);
+                     (float)a.OHW * cpg, rmean, rrstd);
 #pragma unroll
         for (int j = 0; j < 8; ++j) { rga[j] = a.red_gamma[rcol + j]; rbe[j] = a.red_beta[rcol + j]; }
       }

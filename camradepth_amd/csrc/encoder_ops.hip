@@ -33,7 +33,7 @@ __device__ __forceinline__ void innorm_coeffs(const InNorm& n, int b, int C, lon
   if (n.stats == nullptr || !ok) return;
   float mean, rstd;
   const int grp = (c0 >> 4) / n.gmul;
-  gn_mean_rstd(n.stats + (long long)b * (C >> 4) * 2, grp * n.gmul, n.gmul, 1.f / ((float)P * 16.f * n.gmul), mean, rstd);
+  gn_mean_rstd(n.stats + (long long)b * (C >> 4) * 2, grp * n.gmul, n.gmul, (float)P * 16.f * n.gmul, mean, rstd);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     a[j] = n.gamma[c0 + j] * rstd;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
   float rs0[8], rs1[8], rmean = 0.f, rrstd = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) rs0[j] = rs1[j] = 0.f;
-  if (red.xr && gok) gn_mean_rstd(red.stats + (long long)b * (C >> 4) * 2, c0 >> 4, 1, 1.f / ((float)H * W * 16.f), rmean, rrstd);
+  if (red.xr && gok) gn_mean_rstd(red.stats + (long long)b * (C >> 4) * 2, c0 >> 4, 1, (float)H * W * 16.f, rmean, rrstd);
 #pragma unroll
   for (int i = 0; i < ROWS; ++i) {
 #pragma unroll
@@ -351,7 +351,7 @@ __device__ __forceinline__ void attn_xbar_proj_body(const XbarProj& x, int b) {
   const int C = x.C, N = x.N, nt = blockDim.x;
   for (int c = threadIdx.x; c < C; c += nt) {
     float mean, rstd;
-    gn_mean_rstd(x.stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
+    gn_mean_rstd(x.stats + (long long)b * (C >> 4) * 2, c >> 4, 1, (float)N * 16.f, mean, rstd);
     const float mc = stat_get(&x.chan[((long long)b * C + c) * 2]) / (float)N;
     const bf16_t q = f2bf(x.gamma[c] * (mc - mean) * rstd + x.beta[c]);
     x.xbar[(long long)b * C + c] = q;
@@ -457,7 +457,7 @@ __global__ void k_attn_xbar(const crd_sum_t* chan, const crd_sum_t* stats, const
   const int b = blockIdx.x;
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     float mean, rstd;
-    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
+    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, c >> 4, 1, (float)N * 16.f, mean, rstd);
     float mc = stat_get(&chan[((long long)b * C + c) * 2]) / (float)N;
     xbar[(long long)b * C + c] = f2bf(gamma[c] * (mc - mean) * rstd + beta[c]);
   }

@@ -32,7 +32,7 @@ struct GnIn {
   const void* x; int x_f32;               // raw input [B][IH*IW][x_ld] (+ channel offset applied), fp32 or bf16
   const crd_sum_t* stats; int gmul;       // [B][Cin/16][2] slab sums of x; a group = gmul slabs
   const float* gamma; const float* beta;  // [Cin]
-  float inv_count;                        // 1 / (pixels per sample * channels per group)
+  float count;                            // pixels per sample * channels per group
   bf16_t* xn; int xn_ld; long long xn_bstride;    // optional store of act(GN(x)) (bf16), nullptr = none
 };
 
@@ -42,7 +42,7 @@ __device__ __forceinline__ void build_table(const ConvK& a, const GnIn& gi, int 
   const crd_sum_t* stb = gi.stats + (long long)b * (a.Cin >> 4) * 2;
   for (int c = threadIdx.x; c < a.Cin; c += 256) {
     float mean, rstd;
-    gn_mean_rstd(stb, ((c >> 4) / gi.gmul) * gi.gmul, gi.gmul, gi.inv_count, mean, rstd);
+    gn_mean_rstd(stb, ((c >> 4) / gi.gmul) * gi.gmul, gi.gmul, gi.count, mean, rstd);
     const float ga = gi.gamma[c] * rstd;
     tab[c] = make_float2(ga, gi.beta[c] - mean * ga);
   }
@@ -289,7 +289,7 @@ extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_st
   gi.x = n->x_f32 ? (const void*)(reinterpret_cast<const float*>(d->x) + d->x_coff) : (const void*)(reinterpret_cast<const bf16_t*>(d->x) + d->x_coff);
   CRD_CHECK_ARG((reinterpret_cast<uintptr_t>(gi.x) & 15) == 0 && (!n->x_f32 || d->x_ld % 4 == 0), "crd_gn_conv: x rows must be 16-byte aligned");
   gi.stats = n->stats; gi.gmul = n->gmul; gi.gamma = n->gamma; gi.beta = n->beta;
-  gi.inv_count = 1.f / ((float)d->IH * (float)d->IW * 16.f * (float)n->gmul);
+  gi.count = (float)d->IH * (float)d->IW * 16.f * (float)n->gmul;
   gi.xn = reinterpret_cast<bf16_t*>(n->xn); gi.xn_ld = n->xn_ld; gi.xn_bstride = (long long)d->IH * d->IW * n->xn_ld;
   hipStream_t st = as_stream(stream);
   if (n->x_f32) return n->act ? dispatch<1, 1>(k, gi, d->B, st) : dispatch<1, 0>(k, gi, d->B, st);

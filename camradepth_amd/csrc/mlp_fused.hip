@@ -86,7 +86,7 @@ __global__ __launch_bounds__(MT) void k_mlp_fwd(MlpK a) {
   if (NCH > 1) load_chunk(1, xr[1]);
   for (int c = t; c < Cs; c += MT) {
     float mean, rstd;
-    gn_mean_rstd(a.st2 + (long long)b * (Cs >> 4) * 2, c >> 4, 1, 1.f / ((float)N * 16.f), mean, rstd);
+    gn_mean_rstd(a.st2 + (long long)b * (Cs >> 4) * 2, c >> 4, 1, (float)N * 16.f, mean, rstd);
     const float ga = a.g2[c] * rstd;
     tab2[c] = make_float2(ga, a.b2[c] - mean * ga);
   }
@@ -194,15 +194,14 @@ __global__ __launch_bounds__(MT) void k_mlp_fwd(MlpK a) {
 
   // ---- phase 2: h1 -> global, norm1(h1) in place.  Thread = (pixel prow + 128 i, granule hg): 128 contiguous bytes per pixel
   const int hg = t & 7, hch = hc0 + hg * 8;
-  const float inv16 = 1.f / ((float)N * 16.f);
   {
     float ga[8], be[8];
     load8t<1>(a.n1g, hch, ga);
     load8t<1>(a.n1b, hch, be);
     // (mean / rstd from the fixed-point values a reader of sth1 sees -- gn_mean_rstd's arithmetic -- so that this kernel and
     // the backward pass normalise with the same numbers)
-    const float mean = (float)to_fx(red[128 + (hg >> 1) * 2], STAT_ONE) * (1.f / STAT_ONE) * inv16;
-    const float rstd = rsqrtf(fmaxf((float)to_fx(red[128 + (hg >> 1) * 2 + 1], STAT_ONE) * (1.f / STAT_ONE) * inv16 - mean * mean, 0.f) + GN_EPS);
+    float mean, rstd;
+    gn_moments(to_fx(red[128 + (hg >> 1) * 2], STAT_ONE), to_fx(red[128 + (hg >> 1) * 2 + 1], STAT_ONE), (float)N * 16.f, mean, rstd);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ga[j] *= rstd; be[j] -= mean * ga[j]; }
 #pragma unroll 1
@@ -288,13 +287,12 @@ __global__ __launch_bounds__(MT) void k_mlp_fwd(MlpK a) {
     float ga[8], be[8];
     load8t<1>(a.n2g, hch, ga);
     load8t<1>(a.n2b, hch, be);
-    const float inv64 = 1.f / ((float)N * 64.f);
     // (the sums are added as the fixed-point values a reader of sth2 would see, so that this kernel and the backward agree)
     long long qs = 0, qss = 0;
 #pragma unroll
     for (int g = 0; g < 4; ++g) { qs += to_fx(red[128 + g * 2], STAT_ONE); qss += to_fx(red[128 + g * 2 + 1], STAT_ONE); }
-    const float mean = (float)qs * (1.f / STAT_ONE) * inv64;
-    const float rstd = rsqrtf(fmaxf((float)qss * (1.f / STAT_ONE) * inv64 - mean * mean, 0.f) + GN_EPS);
+    float mean, rstd;
+    gn_moments(qs, qss, (float)N * 64.f, mean, rstd);
 #pragma unroll
     for (int j = 0; j < 8; ++j) { ga[j] *= rstd; be[j] -= mean * ga[j]; }
 #pragma unroll 1

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
   }
   float mean, rstd;
   const int grp = (c0 >> 4) / gmul;
-  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, 1.f / ((float)P * 16.f * gmul), mean, rstd);
+  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, (float)P * 16.f * gmul, mean, rstd);
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     ga[j] *= rstd;
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
     }
     float mean, rstd;
     const int grp = (c0 >> 4) / gmul;
-    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, 1.f / ((float)P * 16.f * gmul), mean, rstd);
+    gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, (float)P * 16.f * gmul, mean, rstd);
     for (bool first = true; p < p1; p += (long long)U * m.PL, first = false) {
       if (!first) load_batch(p);               // (the first batch was requested at the top)
 #pragma unroll
@@ -363,7 +363,7 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
   const crd_sum_t* rg = r + (long long)B * C * 2 + ((long long)b * (C / cpg) + grp) * 2;
   const float S1 = grad_get(rg) * inv_m, S2 = grad_get(rg + 1) * inv_m;
   float mean, rstd;
-  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, inv_m, mean, rstd);
+  gn_mean_rstd(stats + (long long)b * (C >> 4) * 2, grp * gmul, gmul, (float)P * cpg, mean, rstd);
   const float sc2 = (dx2 && scale2) ? scale2[b] : 1.f;
   for (bool first = true; p < p1; p += (long long)U * m.PL, first = false) {
     if (!first) load_batch(p);                 // (the first batch was requested at the top of the kernel)

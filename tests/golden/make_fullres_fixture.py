@@ -38,12 +38,22 @@ def main():
     with torch.no_grad():
         enc, _ = model.dest_encoder(b["image"])
         out = model(b["image"])
+        # conditioning yardstick: the same fp32 reference on the input rounded to bf16 (noise injected at the input only --
+        # a lower bound of what bf16 storage between layers does to these deliberately ill-conditioned weights)
+        outq = model(b["image"].to(torch.bfloat16).to(torch.float32))
     fd, inter = out["depth"]["final_depth"], out["depth"]["intermediate_depths"]
+    seg = out["seg"]["final_seg"][0, :, ::4, ::4]
+    top2 = seg.topk(2, dim=0).values
+    fdq, segq = outq["depth"]["final_depth"], outq["seg"]["final_seg"][0, :, ::4, ::4]
     st = {"final_depth_s4": fd[0, 0, ::4, ::4].numpy().copy(), "depth_half_s4": inter[3][0, 0, ::4, ::4].numpy().copy(),
           "depth_quarter_s2": inter[2][0, 0, ::2, ::2].numpy().copy(),
           "final_stats": np.array([float(fd.mean()), float(fd.norm())]),
           "seg_argmax_s4": out["seg"]["final_seg"][0].argmax(0)[::4, ::4].numpy().astype(np.uint8),
           "seg_stats": np.array([float(out["seg"]["final_seg"].mean()), float(out["seg"]["final_seg"].norm())]),
+          "seg_margin_s4": (top2[0] - top2[1]).numpy().astype(np.float16),           # top-1 minus top-2 logit
+          "seg_logit_rms": np.array([float(seg.pow(2).mean().sqrt())]),
+          "bf16_input_rel_final": np.array([float((fdq - fd).norm() / fd.norm())]),
+          "bf16_input_seg_mismatch_s4": np.array([float((segq.argmax(0) != seg.argmax(0)).float().mean())]),
           "rmse": np.array([float(torch.sqrt(MaskedMSELoss()(fd, b["gt_full"])))])}
     for i, e in enumerate(enc):
         st[f"enc{i + 1}_stats"] = np.array([float(e.mean()), float(e.norm())])

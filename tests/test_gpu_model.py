@@ -21,13 +21,16 @@ from camradepth_amd.params import param_specs
 from tests.util import golden_state_dict, load_npz
 
 pytestmark = pytest.mark.gpu
-# |RMSE(HIP bf16) - RMSE(reference fp32)| with the golden weights at 256x416, normalised depth units.  Every run gives the same
-# bits now (crd_sum_t accumulators): measured 4.096e-3 on MI355X, three runs identical (profiles/r03_gpu_tests.log; round 2:
-# 1.3e-3 .. 9.2e-3 from run to run).  The CPU oracle's own bf16-vs-fp32 gap on the same fixture is 5.09e-3
-# (tests/golden/oracle_bf16_gap.json, tools/oracle_bf16_gap.py): with these deliberately ill-conditioned weights the north-star
-# 1e-3 is below the bf16 floor of the reference's own arithmetic, so the 1e-3 gate is asserted at the reference's
-# initialisation (test_rmse_within_1e3_of_fp32_oracle_at_reference_init) and this bound is 2x the measured value.
-RMSE_GAP_GOLDEN_256 = 8.2e-3
+# The 256x416 golden forward (deliberately ill-conditioned golden weights) against the reference's fp32 output.  Every run gives
+# the same bits (crd_sum_t accumulators), but the comparison is chaotic in the launch geometry: regrouping float partial sums
+# (depthwise tile width 16/32, GroupNorm small-grid threshold 128/256: tools/spread_fullres.sh) moved |RMSE(HIP) - RMSE(reference)|
+# between 1.9e-3 and 1.4e-2 -- it is the difference of two scalars, each carrying the whole error field.  The stable quantity
+# is the relative L2 distance of the final depth map: the CPU oracle's own bf16-vs-fp32 distance on this fixture is 0.0187 (RMSE gap
+# 5.09e-3; tests/golden/oracle_bf16_gap.json), so the north-star 1e-3 is below the bf16 floor of the reference's own arithmetic
+# with these weights and is asserted at the reference's initialisation instead
+# (test_rmse_within_1e3_of_fp32_oracle_at_reference_init).  Measured: rel-L2 0.0295, gap 8.7e-3.  Bounds: 2.5x the oracle's bf16 distance; RMSE gap 2 % of the RMSE.
+REL_L2_GOLDEN_256 = 0.047
+RMSE_GAP_GOLDEN_256 = 2e-2
 VARIANTS = ["base", "supervised_seg", "unsupervised_seg", "sup_unsup_seg"]
 
 
@@ -358,21 +361,23 @@ def test_train_step_graph_matches_eager_autograd_path():
 
 
 def test_rmse_gap_with_golden_weights_256x416():
-    """|RMSE(HIP, bf16) - RMSE(reference, fp32)| on the 256x416 golden (reference output stored by make_golden.py) with the
-    deliberately ill-conditioned golden weights; north-star bound 1e-3 in normalised depth units."""
+    """Final depth map and RMSE of the 256x416 golden forward (reference output stored by make_golden.py) with the deliberately
+    ill-conditioned golden weights, three identical runs; bounds: see REL_L2_GOLDEN_256."""
     from camradepth_amd import losses as hl
     cfg = ModelConfig.variant("base")
     g = load_npz("forward256x416_base.npz")
     model = build(cfg, golden_state_dict(cfg))
     batch = synth.make_batch(1, 256, 416, seed=1234)
-    gaps = []
+    gaps, rels = [], []
     for _ in range(3):
         with torch.no_grad():
             out = model(batch["image"].cuda())
             rmse = float(torch.sqrt(hl.MaskedMSELoss()(out["depth"]["final_depth"], batch["gt_full"].cuda())))
         gaps.append(abs(rmse - float(g["loss"][5])))
-    print(f"RMSE gap to the reference golden at 256x416 (golden weights): {gaps}, reference RMSE {float(g['loss'][5]):.6f}")
-    assert gaps[0] == gaps[1] == gaps[2], gaps              # bit-reproducible forward
+        rels.append(rel(out["depth"]["final_depth"], torch.from_numpy(g["final_depth"])))
+    print(f"256x416 golden weights vs the reference: final depth rel-L2 {rels}, RMSE gap {gaps}, reference RMSE {float(g['loss'][5]):.6f}")
+    assert gaps[0] == gaps[1] == gaps[2] and rels[0] == rels[1] == rels[2], (gaps, rels)              # bit-reproducible forward
+    assert max(rels) < REL_L2_GOLDEN_256, rels
     assert max(gaps) < RMSE_GAP_GOLDEN_256, gaps
 
 
@@ -393,10 +398,20 @@ def test_full_resolution_928x1600_matches_reference_golden():
     r_half = rel(out["depth"]["intermediate_depths"][3][0, 0, ::4, ::4], torch.from_numpy(g["depth_half_s4"]))
     r_quarter = rel(out["depth"]["intermediate_depths"][2][0, 0, ::2, ::2], torch.from_numpy(g["depth_quarter_s2"]))
     am = out["seg"]["final_seg"][0].argmax(0)[::4, ::4].cpu().numpy().astype(np.uint8)
-    seg_miss = float((am != g["seg_argmax_s4"]).mean())
+    miss = am != g["seg_argmax_s4"]
+    margin = g["seg_margin_s4"].astype(np.float32)              # reference top-1 minus top-2 logit (logit RMS 0.65)
+    clear = margin > 0.5 * float(g["seg_logit_rms"][0])
+    seg_miss, seg_miss_clear = float(miss.mean()), float(miss[clear].mean())
     print(f"928x1600 vs reference: final {r_full:.4f} half {r_half:.4f} quarter {r_quarter:.4f} seg arg-max mismatch {seg_miss:.4f} "
-          f"rmse {rmse:.6f} / {float(g['rmse'][0]):.6f}")
-    assert r_full < 0.2 and r_half < 0.1 and r_quarter < 0.1        # measured 0.089 / 0.041 / 0.028
+          f"(where the reference's margin > half the logit RMS, {clear.mean():.2f} of the pixels: {seg_miss_clear:.4f}) "
+          f"rmse {rmse:.6f} / {float(g['rmse'][0]):.6f}; the fp32 reference on the bf16-rounded input alone moves "
+          f"final by {float(g['bf16_input_rel_final'][0]):.4f} and flips {float(g['bf16_input_seg_mismatch_s4'][0]):.4f} of the arg-maxes")
+    # The golden weights are ill-conditioned on purpose (every branch contributes, nothing saturates): rounding only the INPUT to
+    # bf16 already moves the fp32 reference by 1.5 % / flips 2 % of the arg-maxes, and regrouping float partial sums between
+    # launch geometries (tools/spread_fullres.sh) moves this comparison between 0.039-0.055 (final) and 0.037-0.069 (arg-max);
+    # with GroupNorm variances taken in fp32 (E[x^2] - mean^2 cancelling) it was 0.076-0.128 and 0.106-0.204.
+    # Bounds: ~2x the worst geometry on the chaotic quantities, tight on what a kernel bug would move (clear-margin pixels, RMSE, mean).
+    assert r_full < 0.12 and r_half < 0.06 and r_quarter < 0.05
     assert abs(rmse - float(g["rmse"][0])) < 3e-2 * float(g["rmse"][0])
     assert abs(float(fd.double().mean()) - g["final_stats"][0]) < 0.05 * abs(g["final_stats"][0]) + 1e-3
-    assert seg_miss < 0.2              # measured 0.12 (arg-max over 21 near-tied logits of the ill-conditioned golden weights)
+    assert seg_miss < 0.15 and seg_miss_clear < 0.01

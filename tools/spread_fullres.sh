@@ -1,0 +1,5 @@
+# spread of the 928x1600 golden comparison over launch geometries that only regroup float partial sums
+for tw in 16 32; do for gs in 128 256; do
+  echo "CRD_DW_TW=$tw CRD_GN_SMALL=$gs"
+  CRD_DW_TW=$tw CRD_GN_SMALL=$gs timeout 300 python -m pytest tests/test_gpu_model.py -q -s -k "928x1600 or rmse_gap" 2>&1 | grep -E "vs reference|vs the reference|passed|failed"
+done; done

@@ -1,0 +1,17 @@
+# build container: gpurun_out/final3 (tools/gpu_round3_final.sh) -> profiles/r03_*
+cd "$(dirname "$0")/.."; O=gpurun_out/final3; P=profiles
+cp $O/gpu_tests.log $P/r03_gpu_tests.log
+cp $O/bench_c2.json $P/r03_bench_c2.json
+cp $O/kernel_stats.md $P/r03_bench_kernel_stats.md
+cp $O/one_step.txt $P/r03_one_step_kernels.txt
+cp $O/forward_only_kernels.txt $P/r03_forward_only_kernels.txt
+cp $O/pmc_traffic.json $P/r03_pmc_traffic.json; cp $O/pmc_traffic.json $P/pmc_traffic.json
+cp $O/bench_c3.json $P/r03_bench_c3_supervised_seg.json
+cp $O/bench_c4.json $P/r03_bench_c4_928x1600_seg_frozen.json
+cp $O/bench_c5_b16_bf16.json $P/r03_bench_c5_b16_bf16_train.json
+cp $O/bench_c5_b16_fp8fwd.json $P/r03_bench_c5_b16_fp8fwd_train.json
+cp $O/bench_inf_b16.json $P/r03_bench_inference_b16_bf16.json
+cp $O/bench_inf_fp8_b16.json $P/r03_bench_inference_b16_fp8.json
+cp $O/bench_inf_b1.json $P/r03_bench_inference_b1_416x800.json
+cp $O/bench_inf_b8.json $P/r03_bench_inference_b8.json
+cp $O/bench_c2_forced_dist_1rank.json $P/r03_bench_c2_forced_dist_1rank.json

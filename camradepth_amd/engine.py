@@ -13,6 +13,7 @@ libcamradepth_hip.so.  Forward structure follows the reference: CamRaDepth.forwa
 Decoder/ShortResBlock/ConvLayer/Depth_Activation (src/utils/utils.py:127-135,223-228,249-257,285-289).
 The backward pass is hand-derived.
 """
+import bisect
 import ctypes as C
 import os
 
@@ -1089,7 +1090,7 @@ class Plan:
             t = self.w_arena[off:off + n]
             off += rup(n)
             return t
-        entries, max_elems = [], 1
+        entries, pack_elems = [], []
         unpack, max_unpack = [], 1
         for cw in self.convs:
             cw.w_fwd = take(cw.cout * cw.taps * cw.cin_pad)
@@ -1107,7 +1108,7 @@ class Plan:
             e.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
             e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad, cw.cout_pad, 0
             entries.append(e)
-            max_elems = max(max_elems, cw.cout * cw.taps * cw.cin_pad, cw.cin_pad * cw.taps * cw.cout_pad)
+            pack_elems.append(max(cw.cout * cw.taps * cw.cin_pad, cw.cin_pad * cw.taps * cw.cout_pad))
             # weight-gradient destination: a crd_sum_t scratch block (order-independent integer atomics) + unpack.
             # The streaming 3x3 kernel splits the pixels S ways; each split stores its block into its own copy (no
             # atomics, nothing to zero) and the segment's unpack kernel sums the copies.
@@ -1133,9 +1134,19 @@ class Plan:
             e.src, e.dst_fwd = self.p(name + ".weight").data_ptr(), w9.data_ptr()
             e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = 1, hid, 9, hid, 8, 1
             entries.append(e)
-            max_elems = max(max_elems, 9 * hid)
+            pack_elems.append(9 * hid)
+        # Sorted by the parameter's position in the model's flat buffer, so that the entries of a gradient bucket (a contiguous
+        # range of that buffer, trainer.GradSync) are a contiguous range of the table: pack(lo, hi) re-packs one bucket right
+        # behind its optimizer slice instead of everything at the head of the next step's forward (169 us on the critical path).
+        base = self.model.flat.data_ptr()
+        order = sorted(range(len(entries)), key=lambda i: entries[i].src)
+        entries = [entries[i] for i in order]
+        self.pack_offs = [(e.src - base) // 4 for e in entries]
+        self.pack_elems = [pack_elems[i] for i in order]
         self.pack_table = _struct_table(entries, dev)
-        self.n_pack, self.max_pack = len(entries), max_elems
+        self.pack_stride = C.sizeof(L.PackEntry)
+        self.n_pack = len(entries)
+        self.packed_version = None          # model._param_version the packed weights correspond to (None: never packed)
         # zero arenas
         self.zf_arena = self._materialise(self._zf_views)
         self.zb_arena = self._materialise(self._zb_views)
@@ -1292,14 +1303,37 @@ class Plan:
             ev.record(self._side_streams[sid - 1])
             main.wait_event(ev)
 
-    def forward(self, masks=None):
-        """x must already be in self.x_in.  masks: optional injected {'drop_path': [...], 'dropout2d': [...]}."""
+    def pack(self, lo=None, hi=None):
+        """fp32 parameters -> the bf16 (and e4m3) operand layouts of the kernels, on the current stream: all of them, or those
+        whose parameter lies in elements [lo, hi) of the model's flat buffer (one optimizer bucket)."""
+        st = L.stream()
+        i0 = 0 if lo is None else bisect.bisect_left(self.pack_offs, lo)
+        i1 = self.n_pack if hi is None else bisect.bisect_left(self.pack_offs, hi)
+        if i1 > i0:
+            L.check(self.lib.crd_weight_pack(self.pack_table.data_ptr() + i0 * self.pack_stride, i1 - i0,
+                                             max(self.pack_elems[i0:i1]), st), "crd_weight_pack")
+        base = self.model.flat.data_ptr()
+        for cw, cin16 in self.fp8_convs:
+            off = (self.p(cw.name + ".weight").data_ptr() - base) // 4
+            if (lo is None or off >= lo) and (hi is None or off < hi):
+                L.check(self.lib.crd_weight_quant_fp8(cw.w_fwd.data_ptr(), cw.cout, 9, cw.cin_pad, cin16, cw.w8.data_ptr(),
+                                                      cw.w8_scales.data_ptr(), st), "crd_weight_quant_fp8")
+        if lo is None and hi is None:
+            self.packed_version = getattr(self.model, "_param_version", 0)
+
+    def ensure_packed(self):
+        """Re-packs everything if the parameters changed since the last full pack (model.mark_params_changed(): optimizer steps,
+        load_state_dict): callers that keep the pack out of their captured forward (TrainStep, InferenceGraph) call this first."""
+        if self.packed_version != getattr(self.model, "_param_version", 0):
+            self.pack()
+
+    def forward(self, masks=None, pack=True):
+        """x must already be in self.x_in.  masks: optional injected {'drop_path': [...], 'dropout2d': [...]}.
+        pack=False: the packed weights are current (ensure_packed() / pack(lo, hi) behind the optimizer)."""
         st = L.stream()
         self.zf_arena.zero_()
-        L.check(self.lib.crd_weight_pack(self.pack_table.data_ptr(), self.n_pack, self.max_pack, st), "crd_weight_pack")
-        for cw, cin16 in self.fp8_convs:
-            L.check(self.lib.crd_weight_quant_fp8(cw.w_fwd.data_ptr(), cw.cout, 9, cw.cin_pad, cin16, cw.w8.data_ptr(),
-                                                  cw.w8_scales.data_ptr(), st), "crd_weight_quant_fp8")
+        if pack:
+            self.pack()
         if self.training and not getattr(self, "training_masks_fixed", False):
             if masks is not None:
                 self.dp_masks.copy_(torch.stack([t.to(self.dev, F32) for t in masks["drop_path"]]))

@@ -31,17 +31,18 @@ class InferenceGraph:
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph, stream=self.stream):
-                self.plan.forward()
+                self.plan.forward(pack=False)       # weights are packed when they change (replay()), not per frame
         torch.cuda.current_stream().wait_stream(self.stream)
         model.train(was_training)
 
     def replay(self):
+        self.plan.ensure_packed()                   # optimizer step / load_state_dict / mark_params_changed() since the last frame
         self.graph.replay()
 
     def run(self, x, clone=True):
         p = self.plan
         p.x_in.copy_(x.to(torch.float32))
-        self.graph.replay()
+        self.replay()
         B, H, W = self.B, self.H, self.W
         final = p.out_depth[5].t.view(B, 1, H, W)
         half = p.out_depth[4].t.view(B, 1, H // 2, W // 2)

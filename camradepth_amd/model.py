@@ -220,7 +220,14 @@ class CamRaDepth(nn.Module):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         if not self._flat_ok():
             self._reflatten()
+        self.mark_params_changed()
         return out
+
+    def mark_params_changed(self):
+        """The parameters were written (optimizer step, load_state_dict, or by hand): TrainStep / InferenceGraph, which keep
+        the fp32 -> bf16 weight packing out of their captured forward, re-pack before their next replay.  model(x) packs
+        on every call and needs no notice."""
+        self.__dict__["_param_version"] = self.__dict__.get("_param_version", 0) + 1
 
     # ------------------------------------------------------------------ forward
     def _plan_for(self, x):

@@ -123,6 +123,9 @@ class diffGradNorm(Optimizer):
             for p, a_ in zip(ps, act_host):
                 if a_:
                     self.state[p]["step"] += 1
+            for ow in {getattr(p, "_crd_owner", None) for p in ps}:        # graph-replayed forwards re-pack their weights
+                if ow is not None and ow() is not None:
+                    ow().mark_params_changed()
             # The kernel's bias corrections use ONE step count per group.  The reference keeps one per parameter
             # (diffGradNorm.py:66,76-77): they differ only for a parameter that is frozen for some steps and unfrozen later
             # (or a checkpoint with non-uniform steps).  Refuse that silently-different case instead of approximating it.

@@ -172,7 +172,7 @@ class TrainStep:
         if self._zero:
             self.model.flat_grad.zero_()
         self.acc.zero_()
-        p.forward()
+        p.forward(pack=False)                  # step() keeps the packed weights current (ensure_packed / _optimizer)
         for i, (j, key) in enumerate(((5, "full"), (4, "half"), (3, "quarter"))):
             pred, tgt = p.out_depth[j].t, self.gt[key]
             L.check(self.lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), pred.numel(), self.acc.data_ptr() + 32 * i, st()),
@@ -203,6 +203,10 @@ class TrainStep:
                                                self.nt, nb, None if mask is None else mask.data_ptr(),
                                                0.0, 0.0, 0.0, 0.0, 0.0, 1, self.hp.data_ptr(), L.stream()),
                 "crd_diffgradnorm_step")
+        # the bucket's new weights in the kernels' bf16 layouts, right behind its update (late stream: under the encoder's
+        # backward) instead of one 169-us launch at the head of the next forward
+        lo, hi = (None, None) if key is None else self.sync.ranges[key]
+        self.plan.pack(lo, hi)
 
     def _segments(self):
         """The iteration as a list of (callable, bucket-to-launch-after | None | 'loss'), for the current
@@ -230,6 +234,7 @@ class TrainStep:
         """Captures one set of graphs per (zero gradients, optimizer) variant the accumulation schedule needs.  Capturing
         executes nothing; one eager warm-up iteration runs first (allocator, lazy module loading) and every buffer it
         changes is restored afterwards."""
+        self.plan.ensure_packed()
         saved = [t.clone() for t in (self.model.flat, self.m, self.v, self.pg, self.egn, self.nsq, self.fac, self.model.flat_grad)]
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -249,6 +254,7 @@ class TrainStep:
         torch.cuda.synchronize()
         for t, sv in zip((self.model.flat, self.m, self.v, self.pg, self.egn, self.nsq, self.fac, self.model.flat_grad), saved):
             t.copy_(sv)
+        self.plan.packed_version = None        # the warm-up iteration packed ITS updated weights
 
     def _capture_variant(self):
         graphs = []
@@ -337,6 +343,7 @@ class TrainStep:
         if self.use_graph and self.graphs is None:
             self._capture()
             self._zero, self._opt = zero, opt
+        self.plan.ensure_packed()              # first step / parameters written from outside since the last one
         if self.use_graph and (zero, opt) not in self.graphs:      # e.g. a flush right after an update (last_of_epoch)
             self.graphs[(zero, opt)] = self._capture_variant()
         runs = self.graphs[(zero, opt)] if self.use_graph else [(None, a) for _, a in self._segments()]
@@ -371,6 +378,9 @@ class TrainStep:
                 self.sync.launch(after)
                 if after == GradSync.ORDER[-1]:
                     self.sync.wait()
+        if opt:                                # every bucket was re-packed behind its optimizer slice
+            self.model.mark_params_changed()
+            self.plan.packed_version = self.model._param_version
         # bookkeeping of the reference loop
         self.iter_count += 1
         self.epoch_iter += 1

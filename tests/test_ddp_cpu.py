@@ -84,6 +84,8 @@ def _worker_step(rank, world, port, q):
         ts.iter_count = ts.epoch_iter = ts.sched_steps = ts.step_count = 0
         ts._window_open, ts._window_pos, ts._zero, ts._opt = False, 0, True, True
         ts.hp, ts.hp_ring, ts.acc = torch.zeros(8), [torch.zeros(8) for _ in range(4)], torch.zeros(16, dtype=torch.int64)
+        import types
+        ts.plan = types.SimpleNamespace(ensure_packed=lambda: None, packed_version=None)     # (the weight packing is a HIP segment too)
         seen, accs = [], []
 
         def fwd():

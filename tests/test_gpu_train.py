@@ -187,6 +187,51 @@ def test_training_iteration_is_bit_reproducible(variant, depths, use_graph):
     assert float(ga[0].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_packed_weights_follow_parameter_changes(use_graph):
+    """TrainStep and InferenceGraph keep the fp32 -> bf16 weight packing out of their captured forward: each optimizer bucket is
+    re-packed behind its update, and anything else that writes parameters (load_state_dict, mark_params_changed()) triggers a
+    full re-pack before the next replay.  Checked through what stale packed weights would change: losses and outputs."""
+    from camradepth_amd.inference import InferenceGraph
+    from camradepth_amd.trainer import TrainStep
+    cfg = dataclasses.replace(ModelConfig.variant("supervised_seg"), depths=(1, 1, 1, 1))
+    sd = synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0)
+    masks = synth.make_masks(cfg, 2, seed=99)
+    batch = {k: v.cuda() for k, v in synth.make_batch(2, 64, 96, seed=70).items()}
+    m = build(cfg, sd)
+    ig = InferenceGraph(m, 2, 64, 96)
+    m.train()
+    out0 = ig.run(batch["image"])["depth"]["final_depth"]
+    ts = TrainStep(m, 2, 64, 96, lr=1e-2, use_graph=use_graph)
+    fix_masks(ts, masks)
+    ts.set_batch(batch)
+    losses = []
+    for _ in range(3):
+        ts.step()
+        losses.append(ts.losses()["loss"])
+    assert losses[0] != losses[1] != losses[2]                     # the forward sees each update
+    # the graph built before training serves the trained weights, bit-equal to the eager eval forward (which packs per call)
+    m.eval()
+    with torch.no_grad():
+        ref = m(batch["image"])["depth"]["final_depth"]
+    out1 = ig.run(batch["image"])["depth"]["final_depth"]
+    assert torch.equal(out1, ref) and not torch.equal(out1, out0)
+    # parameters written from outside between two steps: the next step's forward (its loss) is the first step's again
+    m.train()
+    m.load_state_dict(sd)
+    ts.step()
+    assert ts.losses()["loss"] == losses[0]
+    m.eval()
+    assert torch.equal(ig.run(batch["image"])["depth"]["final_depth"], m(batch["image"])["depth"]["final_depth"].detach())
+    # by hand + notice
+    with torch.no_grad():
+        m.flat.mul_(1.01)
+    m.mark_params_changed()
+    with torch.no_grad():
+        ref = m(batch["image"])["depth"]["final_depth"]
+    assert torch.equal(ig.run(batch["image"])["depth"]["final_depth"], ref)
+
+
 def test_scheduler_lag_of_the_reference_loop():
     """runner.py:269-270: scheduler.step() runs from the (update_interval+1)-th iteration of an epoch on, so the first
     optimizer steps reuse the first schedule entry."""

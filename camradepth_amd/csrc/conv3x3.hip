@@ -308,7 +308,7 @@ int launch3(const ConvK& k0, int B, hipStream_t st, long long partial_cap, int c
     hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 1, WS>), grid, dim3(256), lds, st, k, tiles_x);
   }
   if (finalize && k.stats && k.stats_partial)
-    hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, k.n_tiles, k.G16, k.stats);
+    hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(256), 0, st, k.stats_partial, k.n_tiles, k.G16, k.stats);
   CRD_LAUNCH_CHECK("crd_conv_igemm(3x3 halo)");
   return CRD_OK;
 }

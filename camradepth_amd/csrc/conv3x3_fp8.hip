@@ -464,7 +464,7 @@ extern "C" int crd_conv3x3_fp8(const crd_conv_desc* d, const float* w_scales, fl
   else if (d->Cout <= 96) rc = launch8<3>(k, d->B, st);
   else rc = launch8<4>(k, d->B, st);
   if (rc != CRD_OK || !d->stats) return rc;
-  hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, d->B), dim3(64), 0, st, k.stats_partial, (int)rows, k.G16, d->stats);
+  hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, d->B), dim3(256), 0, st, k.stats_partial, (int)rows, k.G16, d->stats);
   CRD_LAUNCH_CHECK("crd_conv3x3_fp8(statistics)");
   return CRD_OK;
 }

@@ -427,7 +427,7 @@ bool crd_conv3x3p_applicable(const ConvK& k, int B) {
 // GroupNorm sums go through per-(tile, wave) partial rows: floats the caller's stats_partial buffer must hold
 long long crd_conv3x3p_partial_floats(const ConvK& k, int B) { return (long long)B * partial_rows(k) * k.G16 * 2; }
 int crd_conv3x3p_finalize(const ConvK& k, int B, hipStream_t st) {
-  hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(64), 0, st, k.stats_partial, (int)partial_rows(k), k.G16, k.stats);
+  hipLaunchKernelGGL(k_stats_finalize, dim3(k.G16, B), dim3(256), 0, st, k.stats_partial, (int)partial_rows(k), k.G16, k.stats);
   CRD_LAUNCH_CHECK("crd_conv_igemm(3x3 persistent, statistics)");
   return CRD_OK;
 }

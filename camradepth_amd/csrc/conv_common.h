@@ -352,7 +352,7 @@ __device__ __forceinline__ void conv_epilogue_idle(const ConvK& a) {
 }
 
 // stats[b][g][which] += sum over tiles of the per-tile partials written by conv_epilogue
-__global__ void k_stats_finalize(const float* partial, int n_tiles, int G16, crd_sum_t* stats);
+__global__ __launch_bounds__(256) void k_stats_finalize(const float* partial, int n_tiles, int G16, crd_sum_t* stats);
 
 
 }  // namespace crdk

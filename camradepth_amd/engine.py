@@ -60,6 +60,7 @@ MLP_FUSED = os.environ.get("CRD_MLP_FUSED", "1") != "0"
 # workgroups on 256 CUs) it is bound by the VALU work of the stencil / GELU phases on those 80 CUs -- 35 us + the 11 us
 # reduce against 41 us unfused (tools/prof_mlp.py) -- so stage 3 keeps the four launches.
 MLP_FUSED_MAXPIX = int(os.environ.get("CRD_MLP_FUSED_MAXPIX", "128"))
+FC2_FOLD_MINROWS = int(os.environ.get("CRD_FC2_FOLD_MINROWS", "16384"))   # (B = 16 inference 10.51 -> 10.16 ms; B = 1, 8: unchanged)
 GN_CONV_MAXROWS = int(os.environ.get("CRD_GN_CONV_MAXROWS", str(1 << 30)))   # pixels x batch up to which a Block's GEMMs are fused
 LATE_WGRAD = os.environ.get("CRD_NO_LATE_WGRAD") is None
 W3_LATE_WGS = int(os.environ.get("CRD_W3_LATE_WGS", "160"))
@@ -969,7 +970,10 @@ class Plan:
                 self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
                 self.conv(F_, fc1_spec)
             self._emit(F_, "crd_dwconv3x3", dw_args)
-            if fused and self.gn_conv_on == 1:   # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only)
+            # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only).  Inference plans
+            # (nothing saved) take it from FC2_FOLD_MINROWS pixels x batch on: on small grids fc2 is a long-K GEMM on few
+            # workgroups, which k_igemm's intra-workgroup split-K handles better than the register-path kernel
+            if fused and (self.gn_conv_on == 1 or (not tr and B * Hs * Ws >= FC2_FOLD_MINROWS)):
                 fc2_spec["x"] = H2
                 self.gn_conv(F_, fc2_spec, sth2, ratio, ml + ".norm2", 1, H3 if tr else None)
             else:

@@ -1,5 +1,5 @@
 """Per-kernel totals of ONE graph-replayed eval forward (bench.py --inference) from a rocprofv3 rocpd database: forwards are
-delimited by k_weight_pack (the first kernel of a forward); the third-last complete one is reported.
+delimited by k_nchw_to_pm (the input conversion at the head of a forward); the third-last complete one is reported.
 Usage: python tools/rocprof_forward.py <results.db>"""
 import collections
 import sqlite3
@@ -7,7 +7,7 @@ import sys
 
 db = sqlite3.connect(sys.argv[1])
 ks = db.execute("select start,end,name from kernels order by start").fetchall()
-packs = [s for s, e, n in ks if "k_weight_pack" in n]
+packs = [s for s, e, n in ks if "k_nchw_to_pm" in n]
 a, b = (packs[-4], packs[-3]) if len(packs) >= 4 else (packs[0], packs[1])
 agg = collections.defaultdict(lambda: [0, 0])
 first, last = None, None

@@ -5,7 +5,7 @@ import collections, sqlite3, sys
 
 db = sqlite3.connect(sys.argv[1])
 ks = db.execute("select start,end,name from kernels order by start").fetchall()
-packs = [s for s, e, n in ks if "k_weight_pack" in n]
+packs = [s for s, e, n in ks if "k_nchw_to_pm" in n]
 upd = [s for s, e, n in ks if "k_dgn_update" in n]
 steps = [(a, b) for a, b in zip(packs, packs[1:]) if any(a < u < b for u in upd)]
 a, b = steps[-3] if len(steps) >= 3 else steps[-1]

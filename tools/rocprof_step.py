@@ -1,14 +1,14 @@
-"""Per-kernel totals of ONE graph-replayed training step from a rocprofv3 rocpd database (steps delimited by k_weight_pack).
+"""Per-kernel totals of ONE graph-replayed training step from a rocprofv3 rocpd database (steps delimited by k_nchw_to_pm, the input conversion at the head of a forward).
 Usage: python tools/rocprof_step.py <results.db> [<other.db>]   (two databases: side-by-side + fixed-cost estimate 2*t1-t2)"""
 import collections, sqlite3, sys
 
 
 def step_table(path):
-    """A training step = the interval between two consecutive k_weight_pack launches (the first kernel of a forward) that
+    """A training step = the interval between two consecutive k_nchw_to_pm launches (the head of a forward) that
     contains an optimizer update; the third-last such interval of the trace is reported."""
     db = sqlite3.connect(path)
     ks = db.execute("select start,end,name from kernels order by start").fetchall()
-    packs = [s for s, e, n in ks if "k_weight_pack" in n]
+    packs = [s for s, e, n in ks if "k_nchw_to_pm" in n]
     upd = [s for s, e, n in ks if "k_dgn_update" in n]
     steps = [(a, b) for a, b in zip(packs, packs[1:]) if any(a < u < b for u in upd)]
     a, b = steps[-3] if len(steps) >= 3 else steps[-1]

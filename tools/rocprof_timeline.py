@@ -7,7 +7,7 @@ db = sqlite3.connect(sys.argv[1])
 cols = [r[1] for r in db.execute("pragma table_info(kernels)").fetchall()]
 qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else None)
 ks = db.execute(f"select start,end,name{',' + qcol if qcol else ''} from kernels order by start").fetchall()
-packs = [k[0] for k in ks if "k_weight_pack" in k[2]]
+packs = [k[0] for k in ks if "k_nchw_to_pm" in k[2]]
 upd = [k[0] for k in ks if "k_dgn_update" in k[2]]
 steps = [(a, b) for a, b in zip(packs, packs[1:]) if any(a < u < b for u in upd)]
 a, b = steps[-3] if len(steps) >= 3 else steps[-1]

@@ -345,30 +345,79 @@ __global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf1
 
 // Rank-one value path of the attention forward (documented at k_attn_xbar_proj below); also run by one extra workgroup
 // per sample of k_attn_scores (crd_attn_fwd), hence blockDim-strided.
+// y[r] = sum_c W[r][c] * sx[c] for the rows [r_lo, r_hi) of a bf16 matrix with `ld` elements per row: a wave takes four rows at
+// a time, its lanes run along the columns (coalesced 16-byte loads, 512 columns per pass), the products are folded with the wave
+// butterfly.  (One thread per row walking its 1 KB row 16 bytes at a time was a chain of 64 uncoalesced loads: the [C x C] vector
+// products of the attention's rank-one path.)  The sums are taken in fp64: these per-sample vectors are broadcast over every pixel
+// of the sample (x1 = x + bf16(u * S + bp)), so their rounding error is COHERENT across the image instead of averaging out, and the
+// value should not depend on how the sum is grouped -- with the golden weights, the fp32 sum in this order instead of row-sequential
+// (a 1e-7 relative difference in u) moved the 928 x 1600 comparison with the reference from 0.048 to 0.121.
+template <class PRE, class F>
+__device__ __forceinline__ void matvec_rows(const bf16_t* w, int ld, int r_lo, int r_hi, int ncols, const float* sx, PRE&& pre, F&& out) {
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  auto load_rows = [&](int r0, int c0, float (&wv)[4][8]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = r0 + k < r_hi ? r0 + k : r_hi - 1;                // (clamped: unconditional loads; the extra rows are not stored)
+      load8(w + (long long)r * ld, c0 < ncols ? c0 : 0, 0, wv[k]);
+    }
+  };
+  // the first batch of weight rows does not depend on the vector: it is requested before `pre` builds the vector in LDS
+  // (pre() ends with the workgroup barrier; every thread calls it exactly once)
+  float w0[4][8];
+  const int r_first = r_lo + wave * 4;
+  load_rows(r_first < r_hi ? r_first : r_lo, l * 8, w0);
+  pre();
+  for (int r0 = r_first; r0 < r_hi; r0 += nw * 4) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};             // fp64: see above
+    for (int c0 = l * 8; c0 < ncols; c0 += 512) {
+      float wv[4][8];
+      if (r0 == r_first && c0 == l * 8) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) wv[k][j] = w0[k][j];
+      } else {
+        load_rows(r0, c0, wv);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[k] += (double)wv[k][j] * (double)sx[c0 + j];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc[k] += __shfl_xor(acc[k], o);
+    if (l == 0) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (r0 + k < r_hi) out(r0 + k, (float)acc[k]);
+    }
+  }
+}
+constexpr int VEC_ROWS = 64;       // rows of the [C x C] vector products per extra workgroup
+
 struct XbarProj { const crd_sum_t* chan; const crd_sum_t* stats; const float* gamma; const float* beta; const bf16_t* w; int N, C; bf16_t* xbar; float* u; };
-__device__ __forceinline__ void attn_xbar_proj_body(const XbarProj& x, int b) {
+// part e of cdiv(C, VEC_ROWS): every part rebuilds xbar (C values from the sums) and owns VEC_ROWS rows of u; part 0 stores xbar
+__device__ __forceinline__ void attn_xbar_proj_body(const XbarProj& x, int b, int e) {
   __shared__ float sx[1024];
   const int C = x.C, N = x.N, nt = blockDim.x;
-  for (int c = threadIdx.x; c < C; c += nt) {
-    float mean, rstd;
-    gn_mean_rstd(x.stats + (long long)b * (C >> 4) * 2, c >> 4, 1, (float)N * 16.f, mean, rstd);
-    const float mc = stat_get(&x.chan[((long long)b * C + c) * 2]) / (float)N;
-    const bf16_t q = f2bf(x.gamma[c] * (mc - mean) * rstd + x.beta[c]);
-    x.xbar[(long long)b * C + c] = q;
-    sx[c] = bf2f(q);
-  }
-  __syncthreads();
-  for (int co = threadIdx.x; co < C; co += nt) {
-    const bf16_t* wr = x.w + (long long)co * C;
-    float acc = 0.f;
-    for (int ci = 0; ci < C; ci += 8) {
-      float wv[8];
-      load8(wr, ci, 0, wv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc += wv[j] * sx[ci + j];
-    }
-    x.u[(long long)b * C + co] = acc;
-  }
+  const int r_lo = e * VEC_ROWS, r_hi = r_lo + VEC_ROWS < C ? r_lo + VEC_ROWS : C;
+  float* ub = x.u + (long long)b * C;
+  matvec_rows(x.w, C, r_lo, r_hi, C, sx,
+              [&]() {
+                for (int c = threadIdx.x; c < C; c += nt) {
+                  float mean, rstd;
+                  gn_mean_rstd(x.stats + (long long)b * (C >> 4) * 2, c >> 4, 1, (float)N * 16.f, mean, rstd);
+                  const float mc = stat_get(&x.chan[((long long)b * C + c) * 2]) / (float)N;
+                  const bf16_t q = f2bf(x.gamma[c] * (mc - mean) * rstd + x.beta[c]);
+                  if (e == 0) x.xbar[(long long)b * C + c] = q;
+                  sx[c] = bf2f(q);
+                }
+                __syncthreads();
+              },
+              [&](int r, float v) { ub[r] = v; });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -385,57 +434,85 @@ __global__ __launch_bounds__(1024) void k_attn_scores(const bf16_t* q, const bf1
                                                       float scale, float* S, short* idx, int qg, XbarProj xp) {
   __shared__ float smax[16][32];
   const int b = blockIdx.y;
-  if (xp.chan && blockIdx.x == gridDim.x - 1) { attn_xbar_proj_body(xp, b); return; }     // crd_attn_fwd: the value path
+  // crd_attn_fwd: the value path, in the FIRST workgroups of the sample (a dependent chain of ~6 us: dispatched last, behind the
+  // score tiles, it ended the launch 1.6 us late at stage 1)
+  const int nvec = xp.chan ? (xp.C + VEC_ROWS - 1) / VEC_ROWS : 0;
+  if ((int)blockIdx.x < nvec) { attn_xbar_proj_body(xp, b, blockIdx.x); return; }
+  const int tile_x = blockIdx.x - nvec;
   const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int h = wave % heads, g = wave / heads;
-  const int n0 = (blockIdx.x * qg + g) * 32;
+  const int n0 = (tile_x * qg + g) * 32;
   const int C = heads * d;
   const int n = n0 + (l & 31);
   const bool nok = n < N;
   const bf16_t* qb = q + ((long long)b * N + (nok ? n : 0)) * C;
   const bf16_t* kb = k + (long long)b * M * C;
   const int half = l >> 5;
-  const int nks = (d + 15) / 16;
   // query fragments for this head (B operand: col = lane&31, k = 8*half + j within each 16-chunk)
   bf16x8 qf[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    uint4 u = make_uint4(0, 0, 0, 0);
-    int kk = ks * 16 + half * 8;
-    if (ks < nks && kk < d && nok) u = *reinterpret_cast<const uint4*>(qb + h * d + kk);
+    const int kk = ks * 16 + half * 8;
+    uint4 u = *reinterpret_cast<const uint4*>(qb + h * d + (kk < d ? kk : 0));       // (qb is row 0 for queries past N)
+    if (kk >= d) u = make_uint4(0, 0, 0, 0);
     qf[ks] = *reinterpret_cast<bf16x8*>(&u);
   }
   float best = -INFINITY;
   int besti = 0;
-  // key fragments (A operand: row = lane&31 -> key, k = 8*half + j) are fetched one 32-key tile ahead of the MFMAs that
-  // consume them
+  // key fragments (A operand: row = lane&31 -> key, k = 8*half + j) go through a ring of four 32-key tiles: a tile is requested
+  // four tiles before the MFMAs that consume it.  Every load is UNCONDITIONAL (clamped row, columns past d zeroed by a select) and
+  // the tile loop has no branch in its body: with `if (row < M) load` the compiler's wait insertion gave up and put
+  // s_waitcnt vmcnt(0) in front of every use (29 of them), i.e. one full memory latency per tile whatever was prefetched --
+  // 1.2 us per 32 keys, 16-19 us for the 325 keys of a 416 x 800 frame at every stage.
+  const bool kcol_ok[4] = {half * 8 < d, 16 + half * 8 < d, 32 + half * 8 < d, 48 + half * 8 < d};
   auto load_keys = [&](int m0, uint4 (&dst)[4]) {
-    const int mrow = m0 + (l & 31);
+    int mrow = m0 + (l & 31);
+    mrow = mrow < M ? mrow : M - 1;
+    const bf16_t* rowp = kb + (long long)mrow * C + h * d;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      dst[ks] = make_uint4(0, 0, 0, 0);
-      const int kk = ks * 16 + half * 8;
-      if (ks < nks && kk < d && mrow < M) dst[ks] = *reinterpret_cast<const uint4*>(kb + (long long)mrow * C + h * d + kk);
-    }
+    for (int ks = 0; ks < 4; ++ks) dst[ks] = *reinterpret_cast<const uint4*>(rowp + (kcol_ok[ks] ? ks * 16 + half * 8 : 0));
   };
-  uint4 kc[4], kn[4];
-  load_keys(0, kc);
-  for (int m0 = 0; m0 < M; m0 += 32) {
-    if (m0 + 32 < M) load_keys(m0 + 32, kn);
+  auto score_tile = [&](int m0, const uint4 (&kt)[4]) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      if (ks < nks) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<bf16x8*>(&kc[ks]), qf[ks], acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int m = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      float v = bf_round(bf_round(acc[r]) * scale);
-      if (m < M && v > best) { best = v; besti = m; }
+    for (int ks = 0; ks < 4; ++ks) {
+      uint4 kf = kt[ks];
+      if (!kcol_ok[ks]) kf = make_uint4(0, 0, 0, 0);                  // (v_cndmask, no branch)
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&kf), qf[ks], acc, 0, 0, 0);
     }
+    // The kernel is bound by THIS: the two bf16 roundings, the scale, compare and two selects per score are vector instructions
+    // (4 clocks each per wave), the MFMAs a quarter of that.  Roundings in pairs through v_cvt_pk_bf16_f32 (one instruction per
+    // two values + one shift / mask each to widen again, instead of three integer operations per value); selects only -- as
+    // `if (m < M && v > best)` this compiled to two exec-mask branches per key; the `m < M` select only in a tile that crosses M.
+    const bool edge = m0 + 32 > M;                                    // wave-uniform
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) kc[ks] = kn[ks];
+    for (int r = 0; r < 16; r += 2) {
+      const int ma = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;          // r even: the pair is keys ma, ma + 1
+      const uint32_t p1 = pack_bf2(acc[r], acc[r + 1]);
+      const uint32_t p2 = pack_bf2(bf_lo(p1) * scale, bf_hi(p1) * scale);
+      float va = bf_lo(p2), vb = bf_hi(p2);
+      if (edge) { va = ma < M ? va : -INFINITY; vb = ma + 1 < M ? vb : -INFINITY; }      // rows past M (clamped re-reads) never win
+      const bool ta = va > best;
+      best = ta ? va : best;
+      besti = ta ? ma : besti;
+      const bool tb = vb > best;
+      best = tb ? vb : best;
+      besti = tb ? ma + 1 : besti;
+    }
+  };
+  uint4 ring[4][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_keys(j * 32, ring[j]);
+  for (int m0 = 0; m0 < M; m0 += 128) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      score_tile(m0 + j * 32, ring[j]);
+      __builtin_amdgcn_sched_barrier(0);               // keep the refill HERE: the scheduler otherwise sinks the ring's loads next
+      load_keys(m0 + j * 32 + 128, ring[j]);           // to their uses (one latency per pass again)
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
   // combine the two half-waves (same query column, other 16 rows of every tile)
   float ob = __shfl_xor(best, 32);
@@ -467,33 +544,29 @@ __global__ void k_attn_xbar(const crd_sum_t* chan, const crd_sum_t* stats, const
 // conversion + [B,1,C] data-gradient "conv" + a scale: three to four dependent dispatches of a few hundred threads).
 // Forward: xbar[b][c] = bf16(mean_n GroupNorm(x)[b][n][c]) (as k_attn_xbar), u[b][co] = sum_ci W[co][ci] * xbar[b][ci]
 // with W the proj weight in its packed bf16 forward form [C][C] (bf16 products, fp32 accumulation, as the MFMA path).
-__global__ __launch_bounds__(TPB) void k_attn_xbar_proj(XbarProj x) { attn_xbar_proj_body(x, blockIdx.x); }
+__global__ __launch_bounds__(TPB) void k_attn_xbar_proj(XbarProj x) { attn_xbar_proj_body(x, blockIdx.y, blockIdx.x); }
 
 // Backward: tb = bf16(t); es[b][ci] = inv_n * sum_co W[co][ci] * tb[b][co], with wt the proj weight in its packed bf16
 // data-gradient form [C][Cpad] (row ci, contiguous over co).
 struct VecBwd { const crd_sum_t* t; const bf16_t* wt; int C, Cpad; float inv_n; bf16_t* tb; float* es; };
-__device__ __forceinline__ void attn_vec_bwd_body(const VecBwd& v, int b) {
+__device__ __forceinline__ void attn_vec_bwd_body(const VecBwd& v, int b, int e) {
   __shared__ float st[1024];
   const int C = v.C;
-  for (int c = threadIdx.x; c < C; c += TPB) {
-    const bf16_t q = f2bf(grad_get(&v.t[(long long)b * C + c]));
-    v.tb[(long long)b * C + c] = q;
-    st[c] = bf2f(q);
-  }
-  __syncthreads();
-  for (int ci = threadIdx.x; ci < C; ci += TPB) {
-    const bf16_t* wr = v.wt + (long long)ci * v.Cpad;
-    float acc = 0.f;
-    for (int co = 0; co < C; co += 8) {
-      float wv[8];
-      load8(wr, co, 0, wv);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc += wv[j] * st[co + j];
-    }
-    v.es[(long long)b * C + ci] = acc * v.inv_n;
-  }
+  const int r_lo = e * VEC_ROWS, r_hi = r_lo + VEC_ROWS < C ? r_lo + VEC_ROWS : C;
+  float* eb = v.es + (long long)b * C;
+  const float inv_n = v.inv_n;
+  matvec_rows(v.wt, v.Cpad, r_lo, r_hi, C, st,
+              [&]() {
+                for (int c = threadIdx.x; c < C; c += TPB) {
+                  const bf16_t q = f2bf(grad_get(&v.t[(long long)b * C + c]));
+                  if (e == 0) v.tb[(long long)b * C + c] = q;
+                  st[c] = bf2f(q);
+                }
+                __syncthreads();
+              },
+              [&](int r, float a) { eb[r] = a * inv_n; });
 }
-__global__ __launch_bounds__(TPB) void k_attn_vec_bwd(VecBwd v) { attn_vec_bwd_body(v, blockIdx.x); }
+__global__ __launch_bounds__(TPB) void k_attn_vec_bwd(VecBwd v) { attn_vec_bwd_body(v, blockIdx.y, blockIdx.x); }
 
 // x1 = x + dp[b]*bf16(u[b][c]*S[b][n] + bp[c])
 __global__ __launch_bounds__(TPB) void k_attn_out_residual(const float* x, const float* u, const float* S, const float* bp,
@@ -590,11 +663,13 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
   // (head, key) a BITMASK over the chunk's pixels: bit n set <=> pixel n's arg-max for that head is this key
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int b = blockIdx.y;
-  // one extra workgroup per sample runs the rank-one vector path of the same backward step (crd_attn_bwd: it depends on
+  // cdiv(C, 64) extra workgroups per sample run the rank-one vector path of the same backward step (crd_attn_bwd: it depends on
   // the same producer, crd_attn_out_bwd, and a launch of its own cost more than its work)
-  if (vec.t && blockIdx.x == gridDim.x - 1) { attn_vec_bwd_body(vec, b); return; }
+  const int nvec = vec.t ? (vec.C + VEC_ROWS - 1) / VEC_ROWS : 0;
+  if ((int)blockIdx.x < nvec) { attn_vec_bwd_body(vec, b, blockIdx.x); return; }
+  const int chunk_x = blockIdx.x - nvec;
   const int C = heads * d, CG = C >> 3;
-  long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
+  long long p0 = (long long)chunk_x * chunk, p1 = p0 + chunk;
   if (p1 > N) p1 = N;
   const int npx = (int)(p1 - p0);
   const int HM = heads * M, WPC = (chunk + 31) >> 5;                           // mask words per (head, key)
@@ -662,7 +737,7 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
   // per-key pixel lists with an LDS cursor atomic: a count pass, a scan and a fill pass more, and a summation order that
   // changed from run to run.)
   __syncthreads();
-  float* outp = dk_part ? dk_part + ((long long)blockIdx.x * gridDim.y + b) * M * C : nullptr;
+  float* outp = dk_part ? dk_part + ((long long)chunk_x * gridDim.y + b) * M * C : nullptr;
   for (int pr = threadIdx.x; pr < M * CG; pr += TPB) {
     const int m = pr / CG, cg = pr - m * CG;
     const int h = (cg * 8) / d;
@@ -800,7 +875,7 @@ static int attn_scores_launch(const void* q, const void* k, int32_t B, int32_t N
   int qg = 8 / heads;                      // query groups per workgroup: ~8 waves, at most 16
   if (qg < 1) qg = 1;
   if (qg > 4) qg = 4;
-  dim3 grid(cdiv(N, 32 * qg) + (xp.chan ? 1 : 0), B);
+  dim3 grid(cdiv(N, 32 * qg) + (xp.chan ? cdiv(xp.C, VEC_ROWS) : 0), B);
   hipLaunchKernelGGL(k_attn_scores, grid, dim3(64 * heads * qg), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(q),
                      reinterpret_cast<const bf16_t*>(k), N, M, heads, d, scale, S, idx, qg, xp);
   CRD_LAUNCH_CHECK(who);
@@ -836,7 +911,7 @@ extern "C" int crd_attn_xbar_proj(const crd_sum_t* chan_sums, const crd_sum_t* s
                                   int32_t B, int32_t N, int32_t C, void* xbar, float* u, crd_stream_t stream) {
   CRD_CHECK_ARG(chan_sums && stats && gamma && beta && w_fwd && xbar && u, "crd_attn_xbar_proj: null pointer");
   CRD_UNSUPPORTED(C % 16 == 0 && C <= 1024, "crd_attn_xbar_proj: C must be a multiple of 16, <= 1024");
-  hipLaunchKernelGGL(k_attn_xbar_proj, dim3(B), dim3(TPB), 0, as_stream(stream),
+  hipLaunchKernelGGL(k_attn_xbar_proj, dim3(cdiv(C, VEC_ROWS), B), dim3(TPB), 0, as_stream(stream),
                      XbarProj{chan_sums, stats, gamma, beta, reinterpret_cast<const bf16_t*>(w_fwd), N, C, reinterpret_cast<bf16_t*>(xbar), u});
   CRD_LAUNCH_CHECK("crd_attn_xbar_proj");
   return CRD_OK;
@@ -846,7 +921,7 @@ extern "C" int crd_attn_vec_bwd(const crd_sum_t* t, const void* w_dgrad, int32_t
                                 crd_stream_t stream) {
   CRD_CHECK_ARG(t && w_dgrad && tb && es, "crd_attn_vec_bwd: null pointer");
   CRD_UNSUPPORTED(C % 8 == 0 && C <= 1024 && Cpad >= C && Cpad % 8 == 0, "crd_attn_vec_bwd: C must be a multiple of 8, <= 1024");
-  hipLaunchKernelGGL(k_attn_vec_bwd, dim3(B), dim3(TPB), 0, as_stream(stream),
+  hipLaunchKernelGGL(k_attn_vec_bwd, dim3(cdiv(C, VEC_ROWS), B), dim3(TPB), 0, as_stream(stream),
                      VecBwd{t, reinterpret_cast<const bf16_t*>(w_dgrad), C, Cpad, inv_n, reinterpret_cast<bf16_t*>(tb), es});
   CRD_LAUNCH_CHECK("crd_attn_vec_bwd");
   return CRD_OK;
@@ -932,7 +1007,7 @@ static int attn_scores_bwd_launch(const void* q, const void* k, const float* dS,
   int chunk = cdiv(N, nblk);
   nblk = cdiv(N, chunk);
   const size_t lds = attn_bwd_lds(chunk, M, heads, C);
-  hipLaunchKernelGGL(k_attn_scores_bwd, dim3(nblk + (vec.t ? 1 : 0), B), dim3(TPB), use_lds ? lds : 0, as_stream(stream),
+  hipLaunchKernelGGL(k_attn_scores_bwd, dim3(nblk + (vec.t ? cdiv(vec.C, VEC_ROWS) : 0), B), dim3(TPB), use_lds ? lds : 0, as_stream(stream),
                      reinterpret_cast<const bf16_t*>(q), reinterpret_cast<const bf16_t*>(k), dS, reinterpret_cast<const short*>(idx),
                      (long long)N, M, heads, d, scale, chunk, reinterpret_cast<bf16_t*>(dq), dk, use_lds,
                      use_lds ? dk_partials : nullptr, vec);

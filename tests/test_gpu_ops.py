@@ -353,7 +353,8 @@ def test_dwconv_with_fused_input_groupnorm(C_, H, W, gmul):
     assert_close(gval(r_fused), gval(r_ref), "fused gn-bwd reduce", rel=2e-4, elem=2e-4)
 
 
-@pytest.mark.parametrize("N,M,heads,d", [(200, 104, 1, 64), (130, 104, 2, 64), (70, 35, 4, 40), (104, 104, 8, 32)])
+@pytest.mark.parametrize("N,M,heads,d", [(200, 104, 1, 64), (130, 104, 2, 64), (70, 35, 4, 40), (104, 104, 8, 32), (300, 1450, 8, 64), (97, 325, 5, 64),
+                                         (64, 129, 1, 24)])
 def test_attention_scores_and_backward(N, M, heads, d):
     lib, lb = L()
     g = torch.Generator().manual_seed(4)
@@ -374,7 +375,7 @@ def test_attention_scores_and_backward(N, M, heads, d):
     # argmax may differ only where two scores tie after bf16 rounding: check the chosen score is the max
     chosen = torch.gather(att, 3, idx.cpu().long().permute(0, 2, 1).unsqueeze(-1)).squeeze(-1)
     assert float((chosen - smax).abs().max()) <= 1e-2 * float(smax.abs().max())
-    if C_ % 16 == 0:      # fused launch: scores + the rank-one value path (crd_attn_xbar_proj) in one extra workgroup per sample
+    if C_ % 16 == 0:      # fused launch: scores + the rank-one value path (crd_attn_xbar_proj) in cdiv(C, 64) extra workgroups per sample
         chan = to_stat(torch.randn(B, C_, 2, generator=g)).cuda()
         st = to_stat(torch.stack([torch.randn(B, C_ // 16, generator=g), 20.0 + torch.rand(B, C_ // 16, generator=g)], -1) * N).cuda()
         gam, bet = (1 + 0.1 * torch.randn(C_, generator=g)).cuda(), (0.1 * torch.randn(C_, generator=g)).cuda()

@@ -9,7 +9,7 @@ qcol = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols
 ks = db.execute(f"select start,end,name{',' + qcol if qcol else ''} from kernels order by start").fetchall()
 packs = [k[0] for k in ks if "k_nchw_to_pm" in k[2]]
 upd = [k[0] for k in ks if "k_dgn_update" in k[2]]
-steps = [(a, b) for a, b in zip(packs, packs[1:]) if any(a < u < b for u in upd)]
+steps = [(a, b) for a, b in zip(packs, packs[1:]) if not upd or any(a < u < b for u in upd)]      # (no optimizer: replayed inference forwards)
 a, b = steps[-3] if len(steps) >= 3 else steps[-1]
 last_end = {}
 out = []

@@ -20,6 +20,7 @@ import os
 import torch
 
 from . import lib as L
+from . import trace
 from .config import MID_CHANNELS, UNSUP_CLASSES, ModelConfig
 from .params import short_res_block_plan
 
@@ -1352,7 +1353,8 @@ class Plan:
                 L.check(self.lib.crd_dropout_masks(self.d2_masks.data_ptr(), self.d2_keep.data_ptr(), n_drop * self.B,
                                                    MID_CHANNELS, (seed + 1) & 0xFFFFFFFFFFFFFFFF, self.rng_counter.data_ptr(), st),
                         "crd_dropout_masks")
-        self.run_ops(self.fwd)
+        with trace.range("forward"):
+            self.run_ops(self.fwd)
 
     def backward(self, tags=None):
         """Loss gradients must already be in out_depth[('grad', j)] (and seg_grad_in).  Adds into the flat gradient.
@@ -1363,7 +1365,8 @@ class Plan:
         for tag, a, b in self.bwd_segments:
             if tags is not None and tag not in tags:
                 continue
-            self.run_ops(self.bwd[a:b])
+            with trace.range("backward:" + tag):
+                self.run_ops(self.bwd[a:b])
             if tag in self.unpack_ranges and not self.split_late:
                 lo, hi, mx = self.unpack_ranges[tag]
                 L.check(self.lib.crd_wgrad_unpack(self.unpack_table.data_ptr() + lo * self.unpack_stride, hi - lo, mx, 1,

@@ -19,6 +19,7 @@ import torch
 import torch.distributed as dist
 
 from . import lib as L
+from . import trace
 from .optim import _CHUNK
 
 LOSS_W = (1.0, 1.0, 1.0, 0.2, 0.2)   # runner.py:213
@@ -356,9 +357,10 @@ class TrainStep:
                     g0.replay()
                     dist.all_reduce(self.acc, group=self.sync.group)      # global loss denominators before the backward
                 for gm, gl, key, gopt in chain:
-                    gm.replay()
+                    with trace.range("main:" + "+".join(key)):
+                        gm.replay()
                     self.late_stream.wait_stream(main)
-                    with torch.cuda.stream(self.late_stream):
+                    with torch.cuda.stream(self.late_stream), trace.range("late:" + "+".join(key)):
                         gl.replay()
                         if self.dist_active and opt:
                             self.sync.launch(key)      # this bucket's all-reduce, behind the graph that finishes its gradients
@@ -368,9 +370,11 @@ class TrainStep:
                 if go is not None:
                     go.replay()
             elif g is not None:
-                g.replay()
+                with trace.range("graph:%d" % i):
+                    g.replay()
             else:
-                fns[i]()
+                with trace.range("segment:%d" % i):
+                    fns[i]()
             if after == "loss":
                 if self.dist_active:
                     dist.all_reduce(self.acc, group=self.sync.group)

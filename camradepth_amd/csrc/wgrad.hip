@@ -275,7 +275,9 @@ extern "C" int crd_wgrad_group_build(const crd_wgrad_desc* descs, int32_t n, voi
       for (int c = 0; c < 4; ++c) { info->item_offset[c] = (int32_t)off; info->n_items[c] = (int32_t)count[c]; cursor[c] = off; off += count[c]; }
       info->n_problems = n;
       info->bytes = head + off * (long long)sizeof(int4);
-      if (host_table == nullptr || capacity < info->bytes) return CRD_OK;      // size query
+      if (host_table == nullptr) return CRD_OK;                                // size query
+      CRD_CHECK_ARG(capacity >= info->bytes, "crd_wgrad_group_build: the table needs %lld bytes, capacity is %lld", (long long)info->bytes,
+                    (long long)capacity);                                      // (was taken for a size query: rc 0, nothing written)
     }
     for (int i = 0; i < n; ++i) {
       WgK k;

@@ -346,8 +346,20 @@ int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_ca
     else if (N <= 96) rc = crd_conv3x3p(k, B, st, 0, N, 3);
     else {
       const int full = N / 128 * 128, rest = N - full;
+      // how the ragged tail of a data gradient is cut (CRD_C3P_SPLIT, developer switch: 0 = 128-wide tiles + the two-workgroup
+      // kernel for the tail; bits 1 / 2 below: 365.7 -> 354.8 us and 594 -> 584 us on the 256 x 416 level, 3.74 ms -> 3.71 ms per step)
+      static int split_mode = -1;
+      if (split_mode < 0) { const char* e = getenv("CRD_C3P_SPLIT"); split_mode = e ? atoi(e) : 3; }
       if (rest == 0 || rest > 64) rc = crd_conv3x3p(k, B, st, 0, N, 4);
-      else {
+      else if ((split_mode & 1) && full == 128) {    // 136 / 144 columns: 96 + 40 / 48 on the persistent kernel's 96- and 64-wide tiles
+        rc = crd_conv3x3p(k, B, st, 0, 96, 3);
+        if (rc != CRD_OK) return rc;
+        return crd_conv3x3p(k, B, st, 96, N, 2);
+      } else if ((split_mode & 2) && rest > 32) {    // 296 / 304 columns: the 40 / 48-column tail on the persistent kernel's 64-wide tile
+        rc = crd_conv3x3p(k, B, st, 0, full, 4);
+        if (rc != CRD_OK) return rc;
+        return crd_conv3x3p(k, B, st, full, N, 2);
+      } else {
         rc = crd_conv3x3p(k, B, st, 0, full, 4);
         if (rc != CRD_OK) return rc;
         ConvK kt = k;

@@ -45,3 +45,24 @@ for (B, N, M, heads, d, tag) in [(1, 20800, 325, 1, 64, "416x800 stage 1"), (1, 
     t_v = timed(lambda: lb.crd_attn_xbar_proj(P(chan), P(st), P(gam), P(bet), P(wf), B, N, C, P(xb), P(u), L.stream()))
     t_f = timed(lambda: lb.crd_attn_fwd(P(q), P(k), B, N, M, heads, d, scale, P(S), P(idx), P(chan), P(st), P(gam), P(bet), P(wf), P(xb), P(u), L.stream()))
     print(f"{tag:24s} B={B} N={N} M={M} heads={heads}: scores {t_s:6.2f} us   xbar+proj {t_v:6.2f} us   fused {t_f:6.2f} us")
+
+# ---- backward pieces at the benchmark size (B = 8, 256 x 416)
+from tests.util import zsum
+print("backward (B = 8, 256 x 416): crd_attn_out_bwd, crd_attn_scores_bwd (with partial copies), crd_sum_partials_bf16")
+for (N, M, heads, d, tag) in [(6656, 104, 1, 64, "stage 1"), (1664, 104, 2, 64, "stage 2"), (416, 104, 5, 64, "stage 3"), (104, 104, 8, 64, "stage 4")]:
+    B, C = 8, heads * d
+    g = torch.Generator().manual_seed(0)
+    q = torch.randn(B, N, C, generator=g).to(torch.bfloat16).cuda(); k = torch.randn(B, M, C, generator=g).to(torch.bfloat16).cuda()
+    idx = torch.randint(0, M, (B, N, heads), generator=g).to(torch.int16).cuda()
+    dS = torch.randn(B, N, generator=g).cuda(); S = torch.randn(B, N, generator=g).cuda()
+    dx1 = torch.randn(B, N, C, generator=g).cuda(); u = torch.randn(B, C, generator=g).cuda()
+    t, dbp = zsum(B, C), zsum(B, C)
+    dq = torch.zeros(B, N, C, dtype=torch.bfloat16, device="cuda"); dk = zsum(B, M, C)
+    Pn = lb.crd_attn_scores_bwd_partials(B, N, M, heads, d)
+    parts = torch.zeros(max(Pn, 1), B, M, C, device="cuda")
+    dkb = torch.zeros(B, M, C, dtype=torch.bfloat16, device="cuda")
+    scale = d ** -0.5
+    t_o = timed(lambda: lb.crd_attn_out_bwd(P(dx1), P(u), P(S), None, B, N, C, P(t), P(dbp), P(dS), L.stream()))
+    t_s = timed(lambda: lb.crd_attn_scores_bwd(P(q), P(k), P(dS), P(idx), B, N, M, heads, d, scale, P(dq), P(dk), P(parts) if Pn > 0 else None, L.stream()))
+    t_p = timed(lambda: lb.crd_sum_partials_bf16(P(parts), max(Pn, 1), B * M * C, P(dkb), B * M * C, L.stream()))
+    print(f"{tag}: N={N} heads={heads} partial copies {Pn}: out_bwd {t_o:6.2f} us   scores_bwd {t_s:6.2f} us   sum_partials {t_p:6.2f} us")

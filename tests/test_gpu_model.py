@@ -51,14 +51,26 @@ def rel(a, b):
 @pytest.mark.parametrize("variant", VARIANTS)
 @pytest.mark.parametrize("mode", ["eval", "train"])
 def test_shallow_model_forward_backward_vs_oracle(variant, mode):
+    _shallow_vs_oracle(variant, mode, 2, 64, 96)
+
+
+@pytest.mark.parametrize("B,H,W", [(1, 96, 160), (3, 160, 96), (2, 96, 224)])
+def test_shallow_model_ragged_sizes_vs_oracle(B, H, W):
+    """Frame sizes whose pixel grids are odd multiples of the kernels' tiles at every stage (3 x 5, 5 x 3, 3 x 7 pixels at stage 4;
+    15 / 21 attention keys), odd batch sizes, every branch of the model (sup_unsup_seg), train mode: forward, loss and every
+    parameter gradient against the oracle."""
+    _shallow_vs_oracle("sup_unsup_seg", "train", B, H, W)
+
+
+def _shallow_vs_oracle(variant, mode, B, H, W):
     from camradepth_amd import losses as hl
     from oracle import losses as ol
     from oracle import model as om
     cfg = dataclasses.replace(ModelConfig.variant(variant), depths=(1, 1, 1, 1))
     sd = synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0)
     model = build(cfg, sd, train=(mode == "train"))
-    batch = synth.make_batch(2, 64, 96, seed=77)
-    masks = synth.make_masks(cfg, 2, seed=4321) if mode == "train" else None
+    batch = synth.make_batch(B, H, W, seed=77)
+    masks = synth.make_masks(cfg, B, seed=4321) if mode == "train" else None
     out = model(batch["image"].cuda(), masks=masks)
     loss, _ = hl.total_loss(out, {k: v.cuda() for k, v in batch.items()}, cfg.supervised_seg)
     loss.backward()

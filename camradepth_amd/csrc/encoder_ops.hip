@@ -594,8 +594,16 @@ __global__ __launch_bounds__(TPB) void k_attn_out_residual(const float* x, const
 // Four pixel groups are loaded per iteration (one load in flight per thread left the kernel latency-bound); the sums are
 // folded over the wave's pixel lanes with shuffles and over the waves through LDS, then added with one atomic per value
 // and workgroup into PER-SAMPLE rows (chain depth = workgroups of the sample; crd_wgrad_unpack sums the rows of dbp).
-__global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp,
-                                                      long long N, int C, int chunk, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS) {
+// PRE: the apply phase of Block.norm2's backward runs first, in the same threads -- dx1 += (gamma * dxn - S1 - xhat * S2) * rstd with
+// xhat from the fp32 residual stream x, (S1, S2) the group sums crd_gn_bwd_reduce / the fc1 data-gradient epilogue left in r --
+// crd_gn_bwd_apply's arithmetic for an fp32 accumulating output without activation or mask, written back to dx1 (the residual
+// gradient the rest of the block's backward continues with).  The parameter gradients of that GroupNorm come from r as there.
+struct GnPre {
+  const float* x; const bf16_t* dxn; const crd_sum_t* stats; const float* gamma; const crd_sum_t* r; float* dgamma; float* dbeta; int B;
+};
+template <bool PRE>
+__global__ __launch_bounds__(TPB) void k_attn_out_bwd(float* dx1, const float* u, const float* S, const float* dp,
+                                                      long long N, int C, int chunk, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, GnPre pre) {
   extern __shared__ float sm[];  // [2][C]
   const int b = blockIdx.y;
   const int CG = C >> 3;
@@ -611,9 +619,30 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
   for (int j = 0; j < 8; ++j) { uu[j] = cok ? u[(long long)b * C + cg * 8 + j] : 0.f; ta[j] = ba[j] = 0.f; }
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > N) p1 = N;
+  float ga[8], mean = 0.f, rstd = 0.f, S1 = 0.f, S2 = 0.f;
+  if (PRE) {
+    if (b == 0 && pre.dgamma) {       // parameter gradients: the workgroups of sample 0 share the channels (as k_gn_bwd_apply)
+      for (int c = blockIdx.x * TPB + threadIdx.x; c < C; c += gridDim.x * TPB) {
+        long long g0 = 0, g1 = 0;
+        for (int bb = 0; bb < pre.B; ++bb) { g0 += pre.r[((long long)bb * C + c) * 2]; g1 += pre.r[((long long)bb * C + c) * 2 + 1]; }
+        pre.dbeta[c] += (float)g0 * (1.f / GRAD_ONE);
+        pre.dgamma[c] += (float)g1 * (1.f / GRAD_ONE);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ga[j] = cok ? pre.gamma[cg * 8 + j] : 0.f;
+    if (cok) {
+      const int grp = cg >> 1;                                    // 16-channel groups (gmul = 1)
+      const float inv_m = 1.f / ((float)N * 16.f);
+      const crd_sum_t* rg = pre.r + (long long)pre.B * C * 2 + ((long long)b * (C >> 4) + grp) * 2;
+      S1 = grad_get(rg) * inv_m; S2 = grad_get(rg + 1) * inv_m;
+      gn_mean_rstd(pre.stats + (long long)b * (C >> 4) * 2, grp, 1, (float)N * 16.f, mean, rstd);
+    }
+  }
   constexpr int UN = 4;
   for (long long nb = p0 + wave * PPW; nb < p1; nb += (long long)UN * 4 * PPW) {
     float v[UN][8], s[UN];
+    float xv[PRE ? UN : 1][8], dv[PRE ? UN : 1][8];
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
       const long long n = nb + (long long)k * 4 * PPW + sub;
@@ -621,11 +650,25 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(const float* dx1, const fl
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[k][j] = 0.f;
       s[k] = 0.f;
-      if (ok) { load8(dx1, ((long long)b * N + n) * C + cg * 8, 1, v[k]); s[k] = S[(long long)b * N + n]; }
+      if (ok) {
+        const long long off = ((long long)b * N + n) * C + cg * 8;
+        load8(dx1, off, 1, v[k]); s[k] = S[(long long)b * N + n];
+        if (PRE) { load8(pre.x, off, 1, xv[PRE ? k : 0]); load8(pre.dxn, off, 0, dv[PRE ? k : 0]); }
+      }
     }
 #pragma unroll
     for (int k = 0; k < UN; ++k) {
       const long long n = nb + (long long)k * 4 * PPW + sub;
+      if (PRE && cok && n < p1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (xv[PRE ? k : 0][j] - mean) * rstd;
+          float o = (ga[j] * dv[PRE ? k : 0][j] - S1 - xh * S2) * rstd;
+          o += v[k][j];
+          v[k][j] = o;
+        }
+        store8_f32(dx1, ((long long)b * N + n) * C + cg * 8, v[k]);
+      }
       float dot = 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j) { v[k][j] *= dps; dot += v[k][j] * uu[j]; ta[j] += v[k][j] * s[k]; ba[j] += v[k][j]; }
@@ -939,10 +982,10 @@ extern "C" int crd_attn_out_residual(const float* x, const float* u, const float
   return CRD_OK;
 }
 
-extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
-                                int32_t C, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, crd_stream_t stream) {
-  CRD_CHECK_ARG(dx1 && u && S && t && dbp_rows && dS, "crd_attn_out_bwd: null pointer");
-  CRD_UNSUPPORTED(C % 8 == 0 && C <= 512, "crd_attn_out_bwd: C must be a multiple of 8 and <= 512");
+static int attn_out_bwd_launch(float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N, int32_t C, crd_sum_t* t,
+                               crd_sum_t* dbp_rows, float* dS, const GnPre* pre, const char* who, crd_stream_t stream) {
+  CRD_CHECK_ARG(dx1 && u && S && t && dbp_rows && dS, "%s: null pointer", who);
+  CRD_UNSUPPORTED(C % 8 == 0 && C <= 512, "%s: C must be a multiple of 8 and <= 512", who);
   static int small = -1;
   if (small < 0) { const char* e = getenv("CRD_ATTN_OUT_BWD_CHUNK"); small = e ? atoi(e) : 32; }
   int nblk = cdiv(N, (long long)B * cdiv(N, 256) < 128 ? small : 256);     // fewer pixels per workgroup on small grids
@@ -950,10 +993,26 @@ extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S
   if (nblk > cap) nblk = cap;
   int chunk = cdiv(N, nblk);
   nblk = cdiv(N, chunk);
-  hipLaunchKernelGGL(k_attn_out_bwd, dim3(nblk, B), dim3(TPB), 2 * C * sizeof(float), as_stream(stream), dx1, u, S, dp,
-                     (long long)N, C, chunk, t, dbp_rows, dS);
-  CRD_LAUNCH_CHECK("crd_attn_out_bwd");
+  if (pre) hipLaunchKernelGGL(k_attn_out_bwd<true>, dim3(nblk, B), dim3(TPB), 2 * C * sizeof(float), as_stream(stream), dx1, u, S, dp,
+                              (long long)N, C, chunk, t, dbp_rows, dS, *pre);
+  else hipLaunchKernelGGL(k_attn_out_bwd<false>, dim3(nblk, B), dim3(TPB), 2 * C * sizeof(float), as_stream(stream), dx1, u, S, dp,
+                          (long long)N, C, chunk, t, dbp_rows, dS, GnPre{});
+  CRD_LAUNCH_CHECK(who);
   return CRD_OK;
+}
+
+extern "C" int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
+                                int32_t C, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, crd_stream_t stream) {
+  return attn_out_bwd_launch(const_cast<float*>(dx1), u, S, dp, B, N, C, t, dbp_rows, dS, nullptr, "crd_attn_out_bwd", stream);
+}
+
+extern "C" int crd_attn_out_bwd_gn(float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N, int32_t C,
+                                   crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, const float* x, const void* dxn, const crd_sum_t* stats,
+                                   const float* gamma, const crd_sum_t* r, float* dgamma, float* dbeta, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && dxn && stats && gamma && r, "crd_attn_out_bwd_gn: null pointer");
+  CRD_CHECK_ARG(C % 16 == 0 && (dgamma == nullptr) == (dbeta == nullptr), "crd_attn_out_bwd_gn: C %% 16, dgamma / dbeta both or neither");
+  const GnPre pre{x, reinterpret_cast<const bf16_t*>(dxn), stats, gamma, r, dgamma, dbeta, B};
+  return attn_out_bwd_launch(dx1, u, S, dp, B, N, C, t, dbp_rows, dS, &pre, "crd_attn_out_bwd_gn", stream);
 }
 
 // LDS of the chunked path: q rows + g + one pixel bitmask per (head, key) of a `chunk`-pixel chunk

@@ -124,6 +124,7 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
     return "k_igemm<2,2,2,2>"
 
 
+FUSE_NORM2_APPLY = os.environ.get("CRD_NO_FUSE_NORM2_APPLY") is None    # developer switch (A/B): Block.norm2's backward apply inside crd_attn_out_bwd
 FUSE_BLOCK_RED = os.environ.get("CRD_NO_FUSE_BLOCK_RED") is None    # developer switch (A/B): Block.norm1 / norm2 reduces in GEMM epilogues
 
 
@@ -1016,12 +1017,18 @@ class Plan:
         rb2 = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if (FUSE_STATS and fused_reduce_tile_ok(Cs, N, B)) else None
         redb2 = None if rb2 is None else (X1, st2, self.p(name + ".norm2.weight"), self.p(name + ".norm2.bias"), 1, 0, rb2)
         self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, red=redb2))
-        self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1, r=rb2)       # DX = d(X1)
         # attention branch
         T, dSv = self.zb(B, Cs), self.new((B, N), F32)
         dbp_rows = self.zb(B, Cs)
         self.row_grads.append((a + ".proj.bias", Cs, dbp_rows, B, self._tag, 0, Cs))
-        self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
+        if rb2 is not None and FUSE_NORM2_APPLY and Cs <= 512:
+            # the apply phase of Block.norm2's backward (DX += ...: DX = d(X1)) runs inside the launch that reads DX next
+            self._emit(g, "crd_attn_out_bwd_gn", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv, X1.t, DXN.t, st2,
+                                                   self.p(name + ".norm2.weight"), rb2, self.g(name + ".norm2.weight"),
+                                                   self.g(name + ".norm2.bias")])
+        else:
+            self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1, r=rb2)       # DX = d(X1)
+            self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
         Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
         # rank-one vector path (Tb = bf16(T), Es = d(xbar)/N: the bias of the q data gradient) rides in the launch of the

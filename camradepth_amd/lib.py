@@ -113,7 +113,7 @@ _SIGS = {
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiipipp",
     "crd_dwconv3x3": "piiiippipppippppppp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",
     "crd_attn_scores": "ppiiiiifppp", "crd_attn_fwd": "ppiiiiifpppppppppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_xbar_proj": "pppppiiippp", "crd_attn_vec_bwd": "ppiiifppp", "crd_attn_out_residual": "pppppiiipp", "crd_attn_out_residual_stats": "pppppiiippp",
-    "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_bwd": "ppppiiiiifpppppifppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp", "crd_gsum_to_bf16": "pplp",
+    "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_out_bwd_gn": "ppppiiippppppppppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_bwd": "ppppiiiiifpppppifppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp", "crd_gsum_to_bf16": "pplp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_fp8": "piiiiiipiifpiip", "crd_gn_apply_fp8": "piiiiiipippippiifpiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
     "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiiip", "crd_scale_f32": "pplfp",
     "crd_slice_copy": "piipiiliip", "crd_f32_to_bf16_rows": "pipiiliplpiip", "crd_dropout_masks": "ppiiLpp", "crd_sigmoid_bwd": "pplp", "crd_head_conv2_fwd": "pppiiippiip", "crd_head_conv2_bwd": "ppiippiiippip", "crd_head_conv2_bwd_data": "ppiippiiipp", "crd_head_conv2_wgrad": "ppiipiiipip",

@@ -330,6 +330,14 @@ int crd_attn_out_residual_stats(const float* x, const float* u, const float* S, 
  * chain of contended atomics at the workgroups of one sample; crd_wgrad_unpack (replicas = B) folds them. */
 int crd_attn_out_bwd(const float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N,
                      int32_t C, crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, crd_stream_t stream);
+/* The same with the apply phase of the preceding GroupNorm's backward fused in (Block.norm2, simplified_attention.py:144: gmul = 1,
+ * no activation, fp32 input x = the residual stream, dxn = bf16 d(norm2(x)) from fc1's data gradient, r = the sums
+ * crd_gn_bwd_reduce / the fused data-gradient epilogue left): first dx1 += crd_gn_bwd_apply(x, dxn) (written back: dx1 is the
+ * residual gradient the block's backward continues with), then crd_attn_out_bwd on the result; dgamma / dbeta (both or neither)
+ * += the GroupNorm's parameter gradients.  One launch and one pass over dx1 less per block. */
+int crd_attn_out_bwd_gn(float* dx1, const float* u, const float* S, const float* dp, int32_t B, int32_t N, int32_t C,
+                        crd_sum_t* t, crd_sum_t* dbp_rows, float* dS, const float* x, const void* dxn, const crd_sum_t* stats,
+                        const float* gamma, const crd_sum_t* r, float* dgamma, float* dbeta, crd_stream_t stream);
 /* dq[b][n][c] = scale*dS[b][n]*k[b][idx][c] (bf16) ; dk[b][m][c] += scale*dS*q (caller zeroes).
  * Every workgroup accumulates its share of dk in LDS (when [M][C] fp32 fits: always at the reference's sizes).  With
  * dk_partials != NULL (float [P][B][M][C], P = crd_attn_scores_bwd_partials(B,N,M,heads,d) > 0; contents don't-care)

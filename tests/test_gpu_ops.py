@@ -464,6 +464,28 @@ def test_attention_output_path():
     xd = x.cuda()
     stats, chan = zsum(B, C_ // 16, 2), zsum(B, C_, 2)
     ok(lb.crd_gn_stats(P(xd), 1, C_, 0, B, N, C_, P(stats), P(chan), lib.stream()), "gn_stats")
+    # crd_attn_out_bwd_gn = crd_gn_bwd_apply (Block.norm2: fp32 input, accumulating fp32 output) + crd_attn_out_bwd in one launch:
+    # the same dx1, t, dbp, dS and the GroupNorm's parameter gradients
+    dxn = torch.randn(B, N, C_, generator=g).to(torch.bfloat16).cuda()
+    gc_, bc_ = gamma.cuda(), beta.cuda()
+    r = zsum(B * C_ * 2 + B * (C_ // 16) * 2)
+    ok(lb.crd_gn_bwd_reduce(P(xd), 1, C_, 0, P(dxn), 0, C_, 0, B, N, C_, P(stats), 1, P(gc_), P(bc_), 0, None, P(r), None, 0, lib.stream()), "reduce")
+    dxa, dga, dba = dx1.clone().cuda(), torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    ok(lb.crd_gn_bwd_apply(P(xd), 1, C_, 0, P(dxn), 0, C_, 0, B, N, C_, P(stats), 1, P(gc_), P(bc_), 0, None, P(r), P(dga), P(dba),
+                           P(dxa), 1, C_, 0, 1, None, 0, None, lib.stream()), "apply")
+    ta, dbpa, dSa = zsum(B, C_), zsum(B, C_), torch.zeros(B, N, device="cuda")
+    ok(lb.crd_attn_out_bwd(P(dxa), P(uc), P(Sc), P(dpc), B, N, C_, P(ta), P(dbpa), P(dSa), lib.stream()), "attn_out_bwd")
+    dxb, dgb, dbb = dx1.clone().cuda(), torch.zeros(C_, device="cuda"), torch.zeros(C_, device="cuda")
+    tb, dbpb, dSb = zsum(B, C_), zsum(B, C_), torch.zeros(B, N, device="cuda")
+    ok(lb.crd_attn_out_bwd_gn(P(dxb), P(uc), P(Sc), P(dpc), B, N, C_, P(tb), P(dbpb), P(dSb), P(xd), P(dxn), P(stats), P(gc_), P(r),
+                              P(dgb), P(dbb), lib.stream()), "attn_out_bwd_gn")
+    # (to fp32 rounding: the two kernels contract a*b+c differently; the parameter gradients are the same integer sums)
+    assert_close(dxb.cpu(), dxa.cpu(), "fused dx1", rel=1e-6, elem=2e-6)
+    assert_close(gval(tb), gval(ta), "fused t", rel=1e-5, elem=1e-5)
+    assert_close(gval(dbpb), gval(dbpa), "fused dbp", rel=1e-5, elem=1e-5)
+    assert_close(dSb.cpu(), dSa.cpu(), "fused dS", rel=1e-5, elem=1e-5)
+    assert torch.equal(dgb, dga) and torch.equal(dbb, dba) and float(dga.abs().sum()) > 0
+    assert not torch.equal(dxa.cpu(), dx1)
     xbar = torch.zeros(B, C_, dtype=torch.bfloat16, device="cuda")
     gac, bec = gamma.cuda(), beta.cuda()
     ok(lb.crd_attn_xbar(P(chan), P(stats), P(gac), P(bec), B, N, C_, P(xbar), lib.stream()), "xbar")

@@ -187,6 +187,46 @@ def test_training_iteration_is_bit_reproducible(variant, depths, use_graph):
     assert float(ga[0].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("B,H,W", [(3, 96, 160), (1, 160, 96)])
+def test_graph_step_at_ragged_sizes_matches_eager_step(B, H, W):
+    """TrainStep at frame sizes whose grids are odd multiples of the kernels' tiles (3 x 5 / 5 x 3 pixels at stage 4) and odd
+    batch sizes: three graph-replayed iterations (two streams, capped weight-gradient splits, per-bucket optimizer slices and
+    re-packing) against the same three iterations run eagerly in program order -- losses equal to the bit (the forward is the same
+    launches), parameters after three updates within the summation-tree difference of the weight gradients."""
+    from camradepth_amd.trainer import TrainStep
+    cfg = dataclasses.replace(ModelConfig.variant("sup_unsup_seg"), depths=(1, 1, 1, 1))
+    sd = synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0)
+    masks = synth.make_masks(cfg, B, seed=5)
+    batches = [{k: v.cuda() for k, v in synth.make_batch(B, H, W, seed=40 + i).items()} for i in range(3)]
+    runs = []
+    for use_graph in (True, False):
+        m = build(cfg, sd)
+        ts = TrainStep(m, B, H, W, lr=1e-3, use_graph=use_graph)
+        fix_masks(ts, masks)
+        losses = []
+        for b in batches:
+            ts.set_batch(b)
+            assert ts.step() is True
+            losses.append(ts.losses())
+        torch.cuda.synchronize()
+        runs.append((losses, m.flat.clone(), m.flat_grad.clone()))
+    (lg, pg, gg), (le, pe, ge) = runs
+    assert lg[0] == le[0], (lg[0], le[0])                          # same weights, same forward launches: the same bits
+    for a, b in zip(lg[1:], le[1:]):
+        assert abs(a["loss"] - b["loss"]) < 2e-3 * abs(b["loss"]), (a, b)
+    assert rel(gg, ge) < 3e-2
+    assert rel(pg - sd_flat(m, sd), pe - sd_flat(m, sd)) < 5e-2      # the three updates themselves
+
+
+def sd_flat(model, sd):
+    """The state dict laid out like model.flat (padding zero)."""
+    out = torch.zeros_like(model.flat)
+    for name, off in zip(model._names, model._offsets):
+        v = sd[name].reshape(-1).to(out.device, torch.float32)
+        out[off:off + v.numel()] = v
+    return out
+
+
 @pytest.mark.parametrize("use_graph", [True, False])
 def test_packed_weights_follow_parameter_changes(use_graph):
     """TrainStep and InferenceGraph keep the fp32 -> bf16 weight packing out of their captured forward: each optimizer bucket is

@@ -198,16 +198,19 @@ __global__ __launch_bounds__(TPB) void k_gn_apply(const void* x, int x_f32, int 
 }
 
 // r[b][c] = (sum_p g, sum_p g*xhat), g = dy*mask*act'(u)
+// gridDim.z = channel slices of Cs channels each (a multiple of the group width): a workgroup then covers Cs channels of
+// gridDim.z times the pixels instead of all C channels -- the same number of workgroups, 2 Cs instead of 2 C atomics each
+// (Mlp.norm2 of stages 1-2: 1-1.7 M 64-bit atomics per launch were ~10 of its 32-36 us).
 template <int XF, int DF, int ACT>
 __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32, int x_ld, const void* dy, int dy_f32,
-                                                       int dy_ld, long long P, int C, int chunk, const crd_sum_t* stats,
+                                                       int dy_ld, long long P, int C, int Cs, int chunk, const crd_sum_t* stats,
                                                        int gmul, const float* gamma, const float* beta, int act,
                                                        const float* mask, crd_sum_t* r, float* partial) {
-  extern __shared__ float sm[];  // [PL][C][2]
-  const int b = blockIdx.y;
-  Map m(C);
+  extern __shared__ float sm[];  // [PL][Cs][2]
+  const int b = blockIdx.y, cs = blockIdx.z * Cs;
+  Map m(Cs);
   if (m.active) {
-    const int c0 = m.cg * 8;
+    const int c0 = cs + m.cg * 8;
     long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
     if (p1 > P) p1 = P;
     long long p = p0 + m.pl;
@@ -249,30 +252,30 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_reduce(const void* x, int x_f32,
           }
         }
     }
-    float4* row = reinterpret_cast<float4*>(sm + (long long)m.pl * 2 * C + c0 * 2);
+    float4* row = reinterpret_cast<float4*>(sm + (long long)m.pl * 2 * Cs + m.cg * 16);
 #pragma unroll
     for (int j = 0; j < 4; ++j) row[j] = make_float4(s0[2 * j], s1[2 * j], s0[2 * j + 1], s1[2 * j + 1]);
   }
   __syncthreads();
-  fold_rows(sm, 2 * C, m.PL);
+  fold_rows(sm, 2 * Cs, m.PL);
   if (partial) {   // plain stores of this workgroup's sums; k_gn_bwd_finalize folds them (no contended atomics)
-    float* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 2 * C;
-    for (int i = threadIdx.x; i < 2 * C; i += TPB) dst[i] = sm[i];
+    float* dst = partial + ((long long)b * gridDim.x + blockIdx.x) * 2 * C + cs * 2;
+    for (int i = threadIdx.x; i < 2 * Cs; i += TPB) dst[i] = sm[i];
     return;
   }
   // per-channel sums out; in the same pass weight them with gamma in place (all threads, coalesced gamma loads) for the
   // group sums below -- a serial walk of one thread over the 64..128 channels of a group, with a dependent gamma load
   // per channel, was 5 us of this kernel's 13 us floor
-  for (int i = threadIdx.x; i < 2 * C; i += TPB) {
+  for (int i = threadIdx.x; i < 2 * Cs; i += TPB) {
     const float v = sm[i];
-    grad_add(&r[(long long)b * C * 2 + i], v);
-    sm[i] = v * gamma[i >> 1];
+    grad_add(&r[((long long)b * C + cs) * 2 + i], v);
+    sm[i] = v * gamma[cs + (i >> 1)];
   }
   __syncthreads();
   // per-group sums S1 = sum_c gamma_c r0, S2 = sum_c gamma_c r1 (stored after the [B][C][2] block of r)
-  const int cpg = 16 * gmul, G = C / cpg;
-  crd_sum_t* rg = r + (long long)gridDim.y * C * 2 + (long long)b * G * 2;
-  for (int gi = threadIdx.x; gi < 2 * G; gi += TPB) {
+  const int cpg = 16 * gmul, G = C / cpg, Gs = Cs / cpg;
+  crd_sum_t* rg = r + (long long)gridDim.y * C * 2 + ((long long)b * G + cs / cpg) * 2;
+  for (int gi = threadIdx.x; gi < 2 * Gs; gi += TPB) {
     const int grp = gi >> 1, which = gi & 1;
     float acc = 0.f;
     for (int c = grp * cpg; c < (grp + 1) * cpg; ++c) acc += sm[c * 2 + which];
@@ -422,7 +425,7 @@ inline void grid_for(long long P, int C, int B, dim3& grid, int& chunk, bool red
     nblk = (P + per_block - 1) / per_block;
   }
   static int cap_r = -1, cap_e = -1;
-  if (cap_r < 0) { const char* e = getenv("CRD_GN_CAP_R"); cap_r = e ? atoi(e) : 1024; e = getenv("CRD_GN_CAP_E"); cap_e = e ? atoi(e) : 4096; }
+  if (cap_r < 0) { const char* e = getenv("CRD_GN_CAP_R"); cap_r = e ? atoi(e) : 768; e = getenv("CRD_GN_CAP_E"); cap_e = e ? atoi(e) : 4096; }
   long long cap = (reduce ? cap_r : cap_e) / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
@@ -541,12 +544,23 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
   int rc = check_common("crd_gn_bwd_reduce", x_ld, x_coff, C, x_f32);
   if (rc) return rc;
   dim3 grid; int chunk;
-  grid_for(P, C, B, grid, chunk, true);
+  // channel slices (atomics path, C >= 256): the largest S in 8 / 4 / 2 whose slices are >= 64 channels and whole groups
+  int S = 1;
+  static int slicing = -1;
+  if (slicing < 0) { const char* e = getenv("CRD_GN_RED_SLICES"); slicing = e ? atoi(e) : 1; }      // developer switch (A/B)
+  if (slicing && !scratch && C >= 256) {
+    const int cpg = 16 * gmul;
+    for (int s_ = 8; s_ > 1; s_ >>= 1)
+      if (C % s_ == 0 && (C / s_) % cpg == 0 && (C / s_) % 8 == 0 && C / s_ >= 64) { S = s_; break; }
+  }
+  const int Cs = C / S;
+  grid_for(P, Cs, B * S, grid, chunk, true);            // the same number of workgroups: S times the pixels per workgroup
+  grid = dim3(grid.x, (unsigned)B, (unsigned)S);
   float* part = (scratch && (long long)B * grid.x * 2 * C <= scratch_capacity && grid.x > 1) ? scratch : nullptr;
 #define CRD_GN_RED(XF, DF, ACT)                                                                                              \
-  hipLaunchKernelGGL((k_gn_bwd_reduce<XF, DF, ACT>), grid, dim3(TPB), lds_rows(C), as_stream(stream),                      \
+  hipLaunchKernelGGL((k_gn_bwd_reduce<XF, DF, ACT>), grid, dim3(TPB), lds_rows(Cs), as_stream(stream),                     \
                      off_ptr(x, x_f32, x_coff), x_f32, x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C, \
-                     chunk, stats, gmul, gamma, beta, act, mask, r, part)
+                     Cs, chunk, stats, gmul, gamma, beta, act, mask, r, part)
   switch ((x_f32 ? 4 : 0) | (dy_f32 ? 2 : 0) | (act ? 1 : 0)) {
     case 0: CRD_GN_RED(0, 0, 0); break;  case 1: CRD_GN_RED(0, 0, 1); break;
     case 2: CRD_GN_RED(0, 1, 0); break;  case 3: CRD_GN_RED(0, 1, 1); break;

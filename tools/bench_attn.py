@@ -35,7 +35,7 @@ for N, M, heads, d in STAGES:
         L.crd_attn_scores(P_(q), P_(k), B, N, M, heads, d, d ** -0.5, P_(S), P_(idx), lib.stream())
     nparts = L.crd_attn_scores_bwd_partials(B, N, M, heads, d)
     parts = torch.zeros(max(nparts, 1) * B * M * C, device="cuda")
-    dk = torch.zeros(B, M, C, device="cuda")
+    dk = torch.zeros(B, M, C, dtype=torch.int64, device="cuda")   # crd_sum_t
 
     def fwd():
         for r in range(REPS):

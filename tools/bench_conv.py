@@ -12,7 +12,7 @@ L = lib.load()
 x = (torch.randn(B, H * W, Cin, device="cuda") * 0.5).to(torch.bfloat16)
 w = (torch.randn(Cout, 9, Cin, device="cuda") / (9 * Cin) ** 0.5).to(torch.bfloat16)
 y = torch.zeros(B, H * W, Cout, dtype=torch.bfloat16, device="cuda")
-stats = torch.zeros(B, Cout // 16, 2, device="cuda")
+stats = torch.zeros(B, Cout // 16, 2, dtype=torch.int64, device="cuda")
 d = lib.ConvDesc()
 d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x.data_ptr(), Cin, 0, B, H, W, Cin
 d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = w.data_ptr(), Cout, 3, 3, 1, 1, H, W

@@ -15,7 +15,7 @@ x8 = torch.randint(0, 256, (B, H * W, Cin), dtype=torch.uint8, device="cuda") & 
 w8 = torch.randint(0, 256, (Cout, 9, Cin), dtype=torch.uint8, device="cuda") & 0xBF | 0x20
 ws = torch.ones(Cout, device="cuda") * 1e-3
 y = torch.zeros(B, H * W, Cout, dtype=torch.bfloat16, device="cuda")
-stats = torch.zeros(B, Cout // 16, 2, device="cuda")
+stats = torch.zeros(B, Cout // 16, 2, dtype=torch.int64, device="cuda")
 partial = torch.zeros(B * (-(-W // 32)) * (-(-H // 16)) * 4 * (Cout // 16) * 2, device="cuda")
 d = lib.ConvDesc()
 d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x8.data_ptr(), Cin, 0, B, H, W, Cin

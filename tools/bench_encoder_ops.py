@@ -22,14 +22,14 @@ def timeit(name, fn, bytes_):
 st = lib.stream
 Hn, Hd = t(B, N, hid), t(B, N, hid)
 Xn = t(B, N, Cs)
-stats = torch.zeros(B, hid // 16, 2, device="cuda"); chan = torch.zeros(B, hid, 2, device="cuda")
+stats = torch.zeros(B, hid // 16, 2, dtype=torch.int64, device="cuda"); chan = torch.zeros(B, hid, 2, dtype=torch.int64, device="cuda")   # crd_sum_t
 gam, bet = torch.ones(hid, device="cuda"), torch.zeros(hid, device="cuda")
 out = torch.zeros(B, N, hid, dtype=bf, device="cuda")
 L.crd_gn_stats(Hn.data_ptr(), 0, hid, 0, B, N, hid, stats.data_ptr(), None, st())
 hb = B * N * hid * 2
 timeit("gn_stats hidden", lambda: L.crd_gn_stats(Hn.data_ptr(), 0, hid, 0, B, N, hid, stats.data_ptr(), None, st()), hb)
 timeit("gn_apply hidden (+gelu)", lambda: L.crd_gn_apply(Hn.data_ptr(), 0, hid, 0, B, N, hid, stats.data_ptr(), hid // Cs, gam.data_ptr(), bet.data_ptr(), 1, None, out.data_ptr(), 0, hid, 0, st()), 2 * hb)
-r = torch.zeros(B * hid * 2 + B * (Cs // 16) * 2 * 8, device="cuda")
+r = torch.zeros(B * hid * 2 + B * (Cs // 16) * 2 * 8, dtype=torch.int64, device="cuda")
 scr = torch.zeros(1024 * 2 * 1024, device="cuda")
 timeit("gn_bwd_reduce hidden", lambda: L.crd_gn_bwd_reduce(Hn.data_ptr(), 0, hid, 0, Hd.data_ptr(), 0, hid, 0, B, N, hid, stats.data_ptr(), hid // Cs, gam.data_ptr(), bet.data_ptr(), 1, None, r.data_ptr(), scr.data_ptr(), scr.numel(), st()), 2 * hb)
 dg, db = torch.zeros(hid, device="cuda"), torch.zeros(hid, device="cuda")
@@ -37,7 +37,7 @@ timeit("gn_bwd_apply hidden (in place)", lambda: L.crd_gn_bwd_apply(Hn.data_ptr(
 w9, b9 = torch.randn(9, hid, device="cuda"), torch.randn(hid, device="cuda")
 timeit("dwconv fwd (+bias,+stats)", lambda: L.crd_dwconv3x3(Hn.data_ptr(), B, H, W, hid, w9.data_ptr(), b9.data_ptr(), 0, out.data_ptr(), stats.data_ptr(), st()), 2 * hb)
 timeit("dwconv dgrad (flip)", lambda: L.crd_dwconv3x3(Hn.data_ptr(), B, H, W, hid, w9.data_ptr(), None, 1, out.data_ptr(), None, st()), 2 * hb)
-dw9 = torch.zeros(9, hid, device="cuda")
+dw9 = torch.zeros(16, 10, hid, dtype=torch.int64, device="cuda")
 timeit("dwconv wgrad", lambda: L.crd_dwconv3x3_wgrad(Hn.data_ptr(), Hd.data_ptr(), B, H, W, hid, dw9.data_ptr(), db.data_ptr(), st()), 2 * hb)
 # GEMMs
 def conv(x, xC, w, cout, y, yC, k=1, s=1, OH=H, OW=W, bias=None, stats_=None, gather=0, partial=None, f32=0, res=None):
@@ -69,9 +69,9 @@ def wg(x, xC, dy, dyC):
     d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = dy.data_ptr(), dyC, 0, H, W, dyC
     d.KH, d.KW, d.stride, d.pad = 1, 1, 1, 0
     return d
-dwa, dba = torch.zeros(hid, Cs, device="cuda"), torch.zeros(hid, device="cuda")
+dwa, dba = torch.zeros(hid, Cs, dtype=torch.int64, device="cuda"), torch.zeros(hid, dtype=torch.int64, device="cuda")
 dA = wg(Xn, Cs, Hd, hid); dA.dw, dA.dbias = dwa.data_ptr(), dba.data_ptr()
 timeit("fc1 wgrad (+dbias)", lambda: L.crd_conv_wgrad(C.byref(dA), st()), hb + B * N * Cs * 2)
-dwb = torch.zeros(Cs, hid, device="cuda"); dbb = torch.zeros(Cs, device="cuda")
+dwb = torch.zeros(Cs, hid, dtype=torch.int64, device="cuda"); dbb = torch.zeros(Cs, dtype=torch.int64, device="cuda")
 dB = wg(Hn, hid, dxn, Cs); dB.dw, dB.dbias = dwb.data_ptr(), dbb.data_ptr()
 timeit("fc2 wgrad (+dbias)", lambda: L.crd_conv_wgrad(C.byref(dB), st()), hb + B * N * Cs * 2)

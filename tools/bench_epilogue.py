@@ -17,7 +17,7 @@ for name in ("bf16 out", "fp32 out + residual", "+ g16 stats", "+ channel sums")
         y = torch.zeros(B, H * W, Cout, dtype=torch.float32 if f32 else torch.bfloat16, device="cuda")
         res = torch.randn(B, H * W, Cout, device="cuda")
         scale = torch.ones(B, device="cuda")
-        st, ch = torch.zeros(B, Cout // 16, 2, device="cuda"), torch.zeros(B, Cout, 2, device="cuda")
+        st, ch = torch.zeros(B, Cout // 16, 2, dtype=torch.int64, device="cuda"), torch.zeros(B, Cout, 2, dtype=torch.int64, device="cuda")   # crd_sum_t
         d = lib.ConvDesc()
         d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x.data_ptr(), Cin, 0, B, H, W, Cin
         d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = w.data_ptr(), Cout, 1, 1, 1, 0, H, W

@@ -28,7 +28,7 @@ for si, (Cin, Cout, H, W, gmul, act, xf, res, sx) in enumerate(SHAPES):
         r = torch.randn(B, P, Cout, device="cuda") if res else None
         stats = torch.zeros(B, Cin // 16, 2, device="cuda")
         L.crd_gn_stats(x.data_ptr(), xf, Cin, 0, B, P, Cin, stats.data_ptr(), None, lib.stream())
-        ost = torch.zeros(B, Cout // 16, 2, device="cuda")
+        ost = torch.zeros(B, Cout // 16, 2, dtype=torch.int64, device="cuda")
         gam, bet, bias = torch.ones(Cin, device="cuda"), torch.zeros(Cin, device="cuda"), torch.zeros(Cout, device="cuda")
         d = lib.ConvDesc()
         d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = Cin, 0, B, H, W, Cin

@@ -26,7 +26,7 @@ for Cin, Cout, H, W, k, s, mode in SHAPES:
         d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = w.data_ptr(), Cout, k, k, s, 0, OH, OW
         d.gather_mode = mode
         d.y, d.y_ld, d.y_coff, d.y_f32 = y.data_ptr(), Cout, 0, 0
-        st_ = torch.zeros(B, Cout // 16, 2, device="cuda")
+        st_ = torch.zeros(B, Cout // 16, 2, dtype=torch.int64, device="cuda")
         if STATS and Cout % 16 == 0:
             d.stats = st_.data_ptr()
         sets.append((x, w, y, st_)); descs.append(d)

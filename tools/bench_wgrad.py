@@ -9,7 +9,7 @@ Cin, Cout = int(os.environ.get("CIN", 304)), int(os.environ.get("COUT", 128))
 L = lib.load()
 x = (torch.randn(B, H * W, Cin, device="cuda") * 0.5).to(torch.bfloat16)
 dy = (torch.randn(B, H * W, Cout, device="cuda") * 0.5).to(torch.bfloat16)
-dw = torch.zeros(Cout, 9, Cin, device="cuda")
+dw = torch.zeros(Cout, 9, Cin, dtype=torch.int64, device="cuda")   # crd_sum_t
 d = lib.WgradDesc()
 d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x.data_ptr(), Cin, 0, B, H, W, Cin
 d.dy, d.dy_ld, d.dy_coff, d.OH, d.OW, d.Cout = dy.data_ptr(), Cout, 0, H, W, Cout

@@ -138,6 +138,9 @@ class TrainStep:
         self.nsq = torch.zeros(self.nblk, device=self.dev)        # per-workgroup parts of ||g||^2 (summed in a fixed order)
         trainable = torch.tensor([1 if model._param(n_).requires_grad else 0 for n_ in model._names], dtype=torch.uint8)
         self.frozen_names = [n_ for n_ in model._names if not model._param(n_).requires_grad]
+        self._params = [model._param(n_) for n_ in model._names]
+        self._frozen_sig = tuple(p.requires_grad for p in self._params)      # fixed at construction: the plan records no weight
+                                                                             # gradients for frozen tensors (checked in step())
         self.trainable_mask = trainable.to(self.dev) if self.frozen_names else None
         # per gradient bucket: its tensors' slice of the block tables and an `active` mask (the optimizer of a bucket can run
         # as soon as that bucket's gradients are final -- on the late stream, behind their un-packing)
@@ -327,6 +330,9 @@ class TrainStep:
         """One iteration on the batch currently in the static input buffers (set_batch): forward, losses, backward into
         the accumulating gradient buffer and -- on every update_interval-th iteration or the last of an epoch
         (runner.py:222) -- gradient all-reduce + optimizer step.  Returns True when the optimizer ran."""
+        if tuple(p.requires_grad for p in self._params) != self._frozen_sig:
+            raise L.CrdError("camradepth_amd.TrainStep: requires_grad of a parameter changed after the step was built (its plan "
+                             "and optimizer mask are fixed at construction): build a new TrainStep")
         k = self.update_interval
         zero = not self._window_open             # first iteration of an accumulation window: zero the gradients
         pos = self._window_pos if self._window_open else 0

@@ -86,6 +86,7 @@ def _worker_step(rank, world, port, q):
         ts.hp, ts.hp_ring, ts.acc = torch.zeros(8), [torch.zeros(8) for _ in range(4)], torch.zeros(16, dtype=torch.int64)
         import types
         ts.plan = types.SimpleNamespace(ensure_packed=lambda: None, packed_version=None)     # (the weight packing is a HIP segment too)
+        ts._params, ts._frozen_sig = [], ()
         seen, accs = [], []
 
         def fwd():

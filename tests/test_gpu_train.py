@@ -347,6 +347,21 @@ def test_frozen_seg_branch_is_bit_unchanged_and_its_wgrads_are_absent():
         assert rel(m1.flat[o:o + numel] - p1[o:o + numel], m0.flat[o:o + numel] - res[False][2][o:o + numel]) < 0.4, n      # sign-like first steps: run-to-run noise measured 0.17
 
 
+def test_train_step_refuses_requires_grad_changes_after_construction():
+    """The plan of a TrainStep (which weight gradients are launched, the optimizer's mask) is fixed when it is built: freezing or
+    unfreezing a parameter afterwards raises instead of silently training / skipping it."""
+    from camradepth_amd import lib as L
+    from camradepth_amd.trainer import TrainStep
+    cfg = dataclasses.replace(ModelConfig.variant("base"), depths=(1, 1, 1, 1))
+    m = build(cfg, synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0))
+    ts = TrainStep(m, 1, 64, 96, lr=1e-3)
+    ts.set_batch({k: v.cuda() for k, v in synth.make_batch(1, 64, 96, seed=3).items()})
+    ts.step()
+    next(iter(m.parameters())).requires_grad_(False)
+    with pytest.raises(L.CrdError, match="requires_grad"):
+        ts.step()
+
+
 def test_eager_path_respects_frozen_parameters():
     from camradepth_amd import losses as hl
     from camradepth_amd.optim import diffGradNorm

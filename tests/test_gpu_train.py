@@ -408,6 +408,34 @@ def test_per_rank_dropout_streams_differ_and_rank0_is_unchanged():
     assert set(np.unique(drawn[1][0].cpu().numpy()).round(4)) <= {0.0, 1.25}
 
 
+def test_graph_step_matches_eager_step_at_batch16():
+    """Config C5's per-GPU batch (16 x 7 x 256 x 416): the two-stream graph step against the same step run eagerly in program order
+    (different grid caps and weight-gradient split counts than at batch 8): same loss bits, gradients within the summation-tree
+    difference of the weight gradients."""
+    from camradepth_amd.trainer import TrainStep
+    cfg = ModelConfig.variant("base")
+    B = 16
+    batch = {k: v.cuda() for k, v in synth.make_batch(B, 256, 416, seed=99).items()}
+    masks = synth.make_masks(cfg, B, seed=7)
+    m0 = build(cfg)
+    sd = {k: v.detach().cpu().clone() for k, v in m0.state_dict().items()}
+    del m0
+    res = []
+    for use_graph in (True, False):
+        m = build(cfg, sd)
+        ts = TrainStep(m, B, 256, 416, lr=6e-5, use_graph=use_graph)
+        fix_masks(ts, masks)
+        ts.set_batch(batch)
+        ts.step()
+        torch.cuda.synchronize()
+        res.append((ts.losses(), m.flat_grad.clone()))
+        del ts, m
+        torch.cuda.empty_cache()
+    (lg, gg), (le, ge) = res
+    assert lg == le, (lg, le)
+    assert rel(gg, ge) < 2e-2 and float(ge.abs().sum()) > 0
+
+
 def test_train_step_at_benchmark_size_graph_vs_eager_and_oracle():
     """Config C2's workload as a training step: base model, full depth, 8 x 7 x 256 x 416, two-stream HIP graphs, against
     the eager nn.Module + loss + optimizer path with the same masks; loss and first-step update against the CPU oracle

@@ -425,15 +425,15 @@ __global__ __launch_bounds__(TPB) void k_head2_wgrad(const float* gd, const bf16
   if (threadIdx.x == 0) grad_add(&dst[288], sm[288]);
 }
 
-// LDS-tiled form of k_bicubic_bwd: a workgroup owns an 8 x 16 tile of input pixels and a 32-channel window; the
-// (2*8+8) x (2*16+8) region of dy that feeds it is loaded once (coalesced, all loads in flight) and every thread
-// (column, granule, row pair) reads its 10 x 10 candidates from LDS.  The gather kernel above fetched each dy element
-// ~16 times through L1/L2 and 7 times from HBM (rocprofv3 FETCH_SIZE: 421 MB per launch for 233 MB of dy).
-constexpr int BTH = 8, BTW = 16, BCG = 4;                 // tile rows / columns, granules per window
+// LDS-tiled form of k_bicubic_bwd: a workgroup owns an 8 x 16 tile of input pixels and a 16-channel window (32 channels: 60 KB
+// of LDS, two workgroups per CU, 206 instead of 168 us on the 256 x 416 level); the (2*8+8) x (2*16+8) region of dy that feeds it
+// is loaded once (coalesced, all loads in flight).  The gather kernel above fetched each dy element ~16 times through L1/L2 and
+// 7 times from HBM (rocprofv3 FETCH_SIZE: 421 MB per launch for 233 MB of dy).
+constexpr int BTH = 8, BTW = 16, BCG = 2;                 // tile rows / columns, granules per window
 constexpr int BRH = 2 * BTH + 8, BRW = 2 * BTW + 8;       // dy region
 __global__ __launch_bounds__(TPB) void k_bicubic_bwd_tile(const bf16_t* dy, int dy_ld, int H, int W, int C, bf16_t* dx, int dx_ld,
                                                           int accumulate, int tiles_x) {
-  __shared__ __attribute__((aligned(16))) uint4 sdy[BRH * BRW * BCG];
+  __shared__ __attribute__((aligned(16))) uint4 sdy[BRH * BRW * BCG];        // 30 KB: five workgroups per CU
   const int b = blockIdx.z;
   const int g0 = blockIdx.y * BCG;                          // first granule of the window
   const int CG = C >> 3;
@@ -442,18 +442,27 @@ __global__ __launch_bounds__(TPB) void k_bicubic_bwd_tile(const bf16_t* dy, int 
   const int OH = 2 * H, OW = 2 * W;
   const bf16_t* db = dy + (long long)b * OH * OW * dy_ld;
   const int t = threadIdx.x;
+  const int g = t & (BCG - 1), xc = (t >> 1) & (BTW - 1), rgp = t >> 5;      // 2 granules x 16 columns x 8 rows
+  const int ix = x0 + xc, iy = y0 + rgp;
+  const bool colok = g0 + g < CG && ix < W;
+  // the tap weights first, pinned in registers (left to the scheduler, the branchy weight code ended up interleaved with the passes)
+  float wx[10], wy[10];
+  bwd_weights(ix < W ? ix : W - 1, W, wx);
+  bwd_weights(iy < H ? iy : H - 1, H, wy);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) asm volatile("" : "+v"(wx[i]), "+v"(wy[i]));
   {
     constexpr int NP = (BRH * BRW * BCG + TPB - 1) / TPB;
     uint4 r[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const int i = t + k * TPB;
-      const int px = i / BCG, g = i - px * BCG;
+      const int px = i / BCG, gg = i - px * BCG;
       const int ry = px / BRW, rx = px - ry * BRW;
       const int oy = 2 * y0 - 4 + ry, ox = 2 * x0 - 4 + rx;
       r[k] = make_uint4(0, 0, 0, 0);
-      if (i < BRH * BRW * BCG && g0 + g < CG && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW)
-        r[k] = *reinterpret_cast<const uint4*>(db + ((long long)oy * OW + ox) * dy_ld + (g0 + g) * 8);
+      if (i < BRH * BRW * BCG && g0 + gg < CG && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW)
+        r[k] = *reinterpret_cast<const uint4*>(db + ((long long)oy * OW + ox) * dy_ld + (g0 + gg) * 8);
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -462,40 +471,57 @@ __global__ __launch_bounds__(TPB) void k_bicubic_bwd_tile(const bf16_t* dy, int 
     }
   }
   __syncthreads();
-  const int g = t & (BCG - 1), xc = (t >> 2) & (BTW - 1), rgp = t >> 6;      // 4 granules x 16 columns x 4 row pairs
-  const int ix = x0 + xc;
-  if (g0 + g >= CG || ix >= W) return;
-  float wx[10];
-  bwd_weights(ix, W, wx);
+  // The transposed stencil is separable -- dx = By^T (dy Bx) -- and is evaluated that way: a horizontal pass over the region's 24
+  // rows (10 taps each, results kept in registers), then, with the fp32 row sums written back over the dy tile in LDS, a vertical
+  // pass (10 taps).  The dense 10 x 10 form did 100 LDS reads + ~1700 vector operations per (pixel, granule): 276 us on the
+  // 256 x 416 level against ~85 us of memory time.  (Compiled with -fno-slp-vectorize, build.py: the SLP vectoriser pairs the
+  // per-channel FMAs and keeps every unpacked operand alive for it -- 452 registers instead of ~100.)
+  constexpr int RPT = BRH / 8;                                               // region rows per thread in the horizontal pass: 3
+  float hs[RPT][8];
 #pragma unroll
-  for (int rr = 0; rr < 2; ++rr) {
-    const int yl = rgp * 2 + rr, iy = y0 + yl;
-    if (iy >= H) break;
-    float wy[10];
-    bwd_weights(iy, H, wy);
-    float out[8];
+  for (int k = 0; k < RPT; ++k) {
+    const int ry = k * 8 + rgp;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[j] = 0.f;
+    for (int j = 0; j < 8; ++j) hs[k][j] = 0.f;
 #pragma unroll
-    for (int a = 0; a < 10; ++a) {
-      if (wy[a] == 0.f) continue;
-#pragma unroll
-      for (int c = 0; c < 10; ++c) {
-        const uint4 u = sdy[((2 * yl + a) * BRW + 2 * xc + c) * BCG + g];
-        const float w = wy[a] * wx[c];
-        out[0] += w * bf_lo(u.x); out[1] += w * bf_hi(u.x); out[2] += w * bf_lo(u.y); out[3] += w * bf_hi(u.y);
-        out[4] += w * bf_lo(u.z); out[5] += w * bf_hi(u.z); out[6] += w * bf_lo(u.w); out[7] += w * bf_hi(u.w);
-      }
+    for (int c = 0; c < 10; ++c) {
+      const uint4 u = sdy[(ry * BRW + 2 * xc + c) * BCG + g];
+      const float w = wx[c];
+      hs[k][0] += w * bf_lo(u.x); hs[k][1] += w * bf_hi(u.x); hs[k][2] += w * bf_lo(u.y); hs[k][3] += w * bf_hi(u.y);
+      hs[k][4] += w * bf_lo(u.z); hs[k][5] += w * bf_hi(u.z); hs[k][6] += w * bf_lo(u.w); hs[k][7] += w * bf_hi(u.w);
     }
-    const long long off = ((long long)b * H * W + (long long)iy * W + ix) * dx_ld + (g0 + g) * 8;
-    if (accumulate) {
-      float o[8];
-      load8(dx, off, 0, o);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) out[j] += o[j];
-    }
-    store8_bf16(dx, off, out);
   }
+  __syncthreads();                                                           // every read of the dy tile is done
+  float4* srow = reinterpret_cast<float4*>(sdy);                             // [2 halves][BRH][BTW][BCG] float4: 24 KB of the tile's 30
+  constexpr int HALF = BRH * BTW * BCG;
+#pragma unroll
+  for (int k = 0; k < RPT; ++k) {
+    const int ry = k * 8 + rgp;
+    float4* p = srow + (ry * BTW + xc) * BCG + g;
+    p[0] = make_float4(hs[k][0], hs[k][1], hs[k][2], hs[k][3]);
+    p[HALF] = make_float4(hs[k][4], hs[k][5], hs[k][6], hs[k][7]);
+  }
+  __syncthreads();
+  if (!colok || iy >= H) return;
+  float out[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) out[j] = 0.f;
+#pragma unroll
+  for (int a = 0; a < 10; ++a) {
+    const float4* p = srow + ((2 * rgp + a) * BTW + xc) * BCG + g;
+    const float4 lo = p[0], hi = p[HALF];
+    const float w = wy[a];
+    out[0] += w * lo.x; out[1] += w * lo.y; out[2] += w * lo.z; out[3] += w * lo.w;
+    out[4] += w * hi.x; out[5] += w * hi.y; out[6] += w * hi.z; out[7] += w * hi.w;
+  }
+  const long long off = ((long long)b * H * W + (long long)iy * W + ix) * dx_ld + (g0 + g) * 8;
+  if (accumulate) {
+    float o[8];
+    load8(dx, off, 0, o);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[j] += o[j];
+  }
+  store8_bf16(dx, off, out);
 }
 
 // workgroups per sample of the head stencil kernels: 4 lanes per pixel, ~8+ pixels per thread on large grids

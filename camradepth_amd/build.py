@@ -11,8 +11,10 @@ LIB = os.path.join(HERE, "libcamradepth_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-inline-asm"]
 # Per-file flags.  -fno-slp-vectorize: the SLP vectoriser pairs the per-channel fp32 loops of the elementwise / stencil kernels into
 # v_pk_fma_f32 and keeps every unpacked operand alive to do so (k_bicubic_bwd_tile: 452 instead of 106 registers, k_bicubic 194 -> 124,
-# k_gn_bwd_reduce 148 -> 124, k_dwconv_wgrad 354 -> 265); the MFMA kernels are left as they were (conv3x3.hip gets scratch without it).
-NO_SLP = set((os.environ.get("CRD_NOSLP_FILES") or "decoder_ops").split(","))
+# k_dwconv_wgrad 354 -> 255: two workgroups per CU instead of one); norm.hip measured 0.17 ms per step SLOWER without it, the MFMA
+# kernels are left as they were (conv3x3.hip gets scratch without it).
+NO_SLP = set((os.environ.get("CRD_NOSLP_FILES") or "decoder_ops,encoder_ops").split(","))
+EXTRA = (os.environ.get("CRD_EXTRA_FLAGS") or "").split()      # developer switch: e.g. -DCRD_DWW_WGS=1 for an A/B build
 
 
 def _hipcc():
@@ -38,7 +40,7 @@ def build(force=False, verbose=False):
     def cc(job):
         s, o = job
         extra = ["-fno-slp-vectorize"] if os.path.basename(s)[:-4] in NO_SLP else []
-        cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
+        cmd = [hipcc] + FLAGS + extra + EXTRA + ["-c", s, "-o", o]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -221,8 +221,14 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
 // a wave, LDS over the waves) and adds them into ONE of `replicas` copies of the accumulator: an fp32 global atomic
 // costs ~2.6 ns per 128-byte line, serialised device-wide, so all workgroups on one copy would be the whole kernel time.
 // The caller sums the copies (crd_wgrad_unpack).
+// Two workgroups per CU (76 KB of LDS each): needs <= 256 registers.  The SLP vectoriser's build used 354 (one workgroup per CU, 196
+// moves to and from accumulation registers); without it (build.py: -fno-slp-vectorize for this file) 255 + 28 bytes of scratch:
+// 66 -> 39 us on stage 1, 38 -> 26 on stage 2.  (Bounded WITH the vectoriser: 456 bytes of scratch, 100 us.)
+#ifndef CRD_DWW_WGS
+#define CRD_DWW_WGS 2
+#endif
 template <int TW>
-__global__ __launch_bounds__(TPB) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, crd_sum_t* dw10,
+__global__ __launch_bounds__(TPB, CRD_DWW_WGS) void k_dwconv_wgrad(const bf16_t* x, const bf16_t* dy, int H, int W, int C, crd_sum_t* dw10,
                                                       int replicas, int tiles_x, int tiles_y, int tiles_per_wg, InNorm inn) {
   constexpr int HWD = TW + 2;
   constexpr int HPX = (DTH + 2) * HWD;

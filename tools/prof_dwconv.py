@@ -38,5 +38,7 @@ for (H, W, C, tag) in [(64, 104, 512, "stage 1"), (32, 52, 1024, "stage 2"), (16
     t_f0 = timed(lambda: lb.crd_dwconv3x3(P(x), B, H, W, C, P(w9), P(bias), 0, P(y), None, None, 1, None, None, None, None, None, None, st()))
     t_b = timed(lambda: lb.crd_dwconv3x3(P(dy), B, H, W, C, P(w9), None, 1, P(y), None, None, 1, None, None, P(x), P(st_in), P(gam), P(r), st()))
     t_b0 = timed(lambda: lb.crd_dwconv3x3(P(dy), B, H, W, C, P(w9), None, 1, P(y), None, None, 1, None, None, None, None, None, None, st()))
+    dw10 = zsum(16, 10, C)
+    t_w = timed(lambda: lb.crd_dwconv3x3_wgrad(P(x), P(dy), B, H, W, C, P(dw10), 16, P(st_in), 1, P(gam), P(bet), st()))
     mb = B * H * W * C * 2 / 1e6
-    print(f"{tag}: {B}x{H}x{W}x{C} ({mb:5.1f} MB): fwd(+norm,+sums) {t_f:6.2f}  fwd plain {t_f0:6.2f}  dgrad + fused reduce {t_b:6.2f}  dgrad plain {t_b0:6.2f} us")
+    print(f"{tag}: {B}x{H}x{W}x{C} ({mb:5.1f} MB): fwd(+norm,+sums) {t_f:6.2f}  fwd plain {t_f0:6.2f}  dgrad + fused reduce {t_b:6.2f}  dgrad plain {t_b0:6.2f}  wgrad(+norm) {t_w:6.2f} us")

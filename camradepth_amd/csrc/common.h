@@ -211,12 +211,51 @@ __device__ __forceinline__ void gn_moments(long long s, long long ss, float coun
 }
 
 __device__ __forceinline__ void gn_mean_rstd(const crd_sum_t* stats_b, int slab0, int gmul, float count, float& mean, float& rstd) {
+  typedef __attribute__((ext_vector_type(2))) long long ll2;
   long long s = 0, ss = 0;
-  for (int i = 0; i < gmul; ++i) {
-    s += stats_b[(slab0 + i) * 2];
-    ss += stats_b[(slab0 + i) * 2 + 1];
+  if (gmul == 1) {
+    const ll2 v = *reinterpret_cast<const ll2*>(stats_b + slab0 * 2);
+    s = v[0]; ss = v[1];
+  } else {
+    // the slabs of the group, four 16-byte loads in flight per pass (clamped index + select): as `for (i < gmul) s += stats[...]`
+    // every load was waited for before the next was issued -- up to eight dependent memory latencies at the head of every kernel
+    // that normalises with 128-channel groups (Mlp.norm2 of stages 1-2; four at stages 3-4)
+    for (int i0 = 0; i0 < gmul; i0 += 4) {          // (four per pass: eight cost 18-27 more registers in the streaming kernels)
+      ll2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const ll2*>(stats_b + (slab0 + (i0 + k < gmul ? i0 + k : 0)) * 2);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = i0 + k < gmul;
+        s += ok ? v[k][0] : 0ll;
+        ss += ok ? v[k][1] : 0ll;
+      }
+    }
   }
   gn_moments(s, ss, count, mean, rstd);
+}
+
+// sum over the B samples of the per-sample (sum g, sum g*xhat) pairs of channel c in r[B][C][2]: eight independent 16-byte loads in
+// flight per pass (clamped index + select, no branch) -- as `for (bb) g += r[bb]` the compiler waited for every load before issuing
+// the next (s_waitcnt vmcnt(0) in the loop): B dependent memory latencies at the head of the sample-0 workgroups of every
+// GroupNorm-backward apply launch.
+__device__ __forceinline__ void sum_samples(const crd_sum_t* r, int B, int C, int c, long long& g0, long long& g1) {
+  typedef __attribute__((ext_vector_type(2))) long long ll2;
+  g0 = 0; g1 = 0;
+  for (int b0 = 0; b0 < B; b0 += 8) {
+    ll2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bb = b0 + k < B ? b0 + k : B - 1;
+      v[k] = *reinterpret_cast<const ll2*>(r + ((long long)bb * C + c) * 2);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const bool ok = b0 + k < B;
+      g0 += ok ? v[k][0] : 0ll;
+      g1 += ok ? v[k][1] : 0ll;
+    }
+  }
 }
 
 static inline hipStream_t as_stream(crd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }

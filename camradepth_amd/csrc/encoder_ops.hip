@@ -629,10 +629,11 @@ __global__ __launch_bounds__(TPB) void k_attn_out_bwd(float* dx1, const float* u
   if (PRE) {
     if (b == 0 && pre.dgamma) {       // parameter gradients: the workgroups of sample 0 share the channels (as k_gn_bwd_apply)
       for (int c = blockIdx.x * TPB + threadIdx.x; c < C; c += gridDim.x * TPB) {
-        long long g0 = 0, g1 = 0;
-        for (int bb = 0; bb < pre.B; ++bb) { g0 += pre.r[((long long)bb * C + c) * 2]; g1 += pre.r[((long long)bb * C + c) * 2 + 1]; }
-        pre.dbeta[c] += (float)g0 * (1.f / GRAD_ONE);
-        pre.dgamma[c] += (float)g1 * (1.f / GRAD_ONE);
+        const float ob = pre.dbeta[c], og = pre.dgamma[c];
+        long long g0, g1;
+        sum_samples(pre.r, pre.B, C, c, g0, g1);
+        pre.dbeta[c] = ob + (float)g0 * (1.f / GRAD_ONE);
+        pre.dgamma[c] = og + (float)g1 * (1.f / GRAD_ONE);
       }
     }
 #pragma unroll

@@ -345,10 +345,11 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
   if (b == 0 && dgamma) {     // parameter gradients: the workgroups of sample 0 share the channels (one workgroup doing all
                               // of them put B x C dependent loads in front of its own pixels: +5 us on the small grids)
     for (int c = blockIdx.x * TPB + threadIdx.x; c < C; c += gridDim.x * TPB) {
-      long long g0 = 0, g1 = 0;
-      for (int bb = 0; bb < B; ++bb) { g0 += r[((long long)bb * C + c) * 2]; g1 += r[((long long)bb * C + c) * 2 + 1]; }
-      dbeta[c] += (float)g0 * (1.f / GRAD_ONE);
-      dgamma[c] += (float)g1 * (1.f / GRAD_ONE);
+      const float ob = dbeta[c], og = dgamma[c];            // (requested with the sums, not behind them)
+      long long g0, g1;
+      sum_samples(r, B, C, c, g0, g1);
+      dbeta[c] = ob + (float)g0 * (1.f / GRAD_ONE);
+      dgamma[c] = og + (float)g1 * (1.f / GRAD_ONE);
     }
   }
   if (!m.active) return;

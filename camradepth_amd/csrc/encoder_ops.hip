@@ -820,13 +820,21 @@ __global__ __launch_bounds__(TPB) void k_attn_scores_bwd(const bf16_t* q, const 
 // dst[i] = bf16(sum_r part[r*stride + i]), 8 elements per thread
 __global__ __launch_bounds__(TPB) void k_sum_partials_bf16(const float* part, int replicas, long long stride, bf16_t* dst, long long n8) {
   for (long long i = (long long)blockIdx.x * TPB + threadIdx.x; i < n8; i += (long long)gridDim.x * TPB) {
+    // the copies four at a time, all loads of a pass in flight (clamped index, select past the end; still added in index
+    // order): one copy per iteration was one dependent memory latency per copy -- 52 of them at stage 1
     float v[8];
-    load8(part, i * 8, 1, v);
-    for (int r = 1; r < replicas; ++r) {
-      float w[8];
-      load8(part, (long long)r * stride + i * 8, 1, w);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] += w[j];
+    for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    for (int r0 = 0; r0 < replicas; r0 += 4) {
+      float w[4][8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) load8(part, (long long)(r0 + k < replicas ? r0 + k : replicas - 1) * stride + i * 8, 1, w[k]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const bool ok = r0 + k < replicas;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += ok ? w[k][j] : 0.f;
+      }
     }
     store8_bf16(dst, i * 8, v);
   }

@@ -365,13 +365,19 @@ __global__ __launch_bounds__(TPB) void k_mlp_reduce(const float* part, int slabs
     for (long long p = p0 + pl; p < p1; p += PL) {
       const long long off = ((long long)b * P + p) * C + cg * 8;
       float v[8], x[8];
-      load8t<1>(part, off, v);
       load8t<1>(x1, off, x);
-      for (int sl = 1; sl < slabs; ++sl) {
-        float w[8];
-        load8t<1>(part, (long long)sl * slab_stride + off, w);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += w[j];
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      for (int s0 = 0; s0 < slabs; s0 += 4) {           // four slabs per pass in flight (clamped index, select past the end)
+        float w[4][8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) load8t<1>(part, (long long)(s0 + k < slabs ? s0 + k : slabs - 1) * slab_stride + off, w[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const bool ok = s0 + k < slabs;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += ok ? w[k][j] : 0.f;
+        }
       }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

@@ -460,9 +460,11 @@ __global__ __launch_bounds__(TPB) void k_bicubic_bwd_tile(const bf16_t* dy, int 
       const int px = i / BCG, gg = i - px * BCG;
       const int ry = px / BRW, rx = px - ry * BRW;
       const int oy = 2 * y0 - 4 + ry, ox = 2 * x0 - 4 + rx;
-      r[k] = make_uint4(0, 0, 0, 0);
-      if (i < BRH * BRW * BCG && g0 + gg < CG && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW)
-        r[k] = *reinterpret_cast<const uint4*>(db + ((long long)oy * OW + ox) * dy_ld + (g0 + gg) * 8);
+      // (unconditional loads from a clamped address + select: no early wait behind the first piece)
+      const bool ok = i < BRH * BRW * BCG && g0 + gg < CG && (unsigned)oy < (unsigned)OH && (unsigned)ox < (unsigned)OW;
+      const int cy = oy < 0 ? 0 : (oy < OH ? oy : OH - 1), cx = ox < 0 ? 0 : (ox < OW ? ox : OW - 1), cgr = g0 + gg < CG ? g0 + gg : g0;
+      const uint4 u = *reinterpret_cast<const uint4*>(db + ((long long)cy * OW + cx) * dy_ld + cgr * 8);
+      r[k] = ok ? u : make_uint4(0, 0, 0, 0);
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {

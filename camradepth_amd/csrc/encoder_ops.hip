@@ -92,9 +92,12 @@ __global__ __launch_bounds__(TPB) void k_dwconv(const bf16_t* x, int H, int W, i
       const int hp = i >> 3, g = i & 7;
       const int hy = hp / HWD, hx = hp - hy * HWD;
       const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-      r[k] = make_uint4(0, 0, 0, 0);
       inimg[k] = i < HPX * 8 && g < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-      if (inimg[k]) r[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + g * 8);
+      // unconditional loads from a clamped address, zeroed by a select: under `if (inimg) load` the compiler put a
+      // s_waitcnt vmcnt(0) right behind the FIRST piece's load (one memory latency before the other ten were requested)
+      const int cy = iy < 0 ? 0 : (iy < H ? iy : H - 1), cx = ix < 0 ? 0 : (ix < W ? ix : W - 1), cgr = g < nG ? g : 0;
+      const uint4 u = *reinterpret_cast<const uint4*>(xb + ((long long)cy * W + cx) * C + c_win + cgr * 8);
+      r[k] = inimg[k] ? u : make_uint4(0, 0, 0, 0);
     }
     // weights, bias and the input-norm coefficients are requested while the halo is in flight (after the LDS stores they
     // were a second dependent round trip on the small grids)
@@ -270,9 +273,11 @@ __global__ __launch_bounds__(TPB, CRD_DWW_WGS) void k_dwconv_wgrad(const bf16_t*
         const int hp = i >> 3, gg = i & 7;
         const int hy = hp / HWD, hx = hp - hy * HWD;
         const int iy = ty0 - 1 + hy, ix = tx0 - 1 + hx;
-        rx[k] = make_uint4(0, 0, 0, 0);
         inimg[k] = i < HPX * 8 && gg < nG && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-        if (inimg[k]) rx[k] = *reinterpret_cast<const uint4*>(xb + ((long long)iy * W + ix) * C + c_win + gg * 8);
+        // (unconditional loads from a clamped address + select, as in k_dwconv)
+        const int cy = iy < 0 ? 0 : (iy < H ? iy : H - 1), cx = ix < 0 ? 0 : (ix < W ? ix : W - 1), cgr = gg < nG ? gg : 0;
+        const uint4 u = *reinterpret_cast<const uint4*>(xb + ((long long)cy * W + cx) * C + c_win + cgr * 8);
+        rx[k] = inimg[k] ? u : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int k = 0; k < ND; ++k) {
@@ -280,8 +285,9 @@ __global__ __launch_bounds__(TPB, CRD_DWW_WGS) void k_dwconv_wgrad(const bf16_t*
         const int pp = i >> 3, gg = i & 7;
         const int py = pp / TW, px = pp - py * TW;
         const int iy = ty0 + py, ix = tx0 + px;
-        rd[k] = make_uint4(0, 0, 0, 0);
-        if (gg < nG && iy < H && ix < W) rd[k] = *reinterpret_cast<const uint4*>(db + ((long long)iy * W + ix) * C + c_win + gg * 8);
+        const int cy = iy < H ? iy : H - 1, cx = ix < W ? ix : W - 1, cgr = gg < nG ? gg : 0;
+        const uint4 u = *reinterpret_cast<const uint4*>(db + ((long long)cy * W + cx) * C + c_win + cgr * 8);
+        rd[k] = (gg < nG && iy < H && ix < W) ? u : make_uint4(0, 0, 0, 0);
       }
       if (it == 0) innorm_coeffs(inn, b, C, (long long)H * W, c_win + (t & 7) * 8, (t & 7) < nG, na, ns);   // under the first tile's loads
       if (it > 0) __syncthreads();                 // everyone is done with the previous tile's LDS image

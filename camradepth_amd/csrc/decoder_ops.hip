@@ -292,20 +292,23 @@ __global__ __launch_bounds__(TPB) void k_head2_fwd(const bf16_t* a, const float*
   const int npix = H * W, stride = (gridDim.x * TPB) >> 2;
   for (int pix = (blockIdx.x * TPB + threadIdx.x) >> 2; pix < npix; pix += stride) {     // uniform per 4-lane pixel group
     const int py = pix / W, px = pix - py * W;
+    // the nine taps from clamped addresses, all in flight, zeroed by a select outside the image (under `if (inside) load` every
+    // tap's load was waited for before the next was issued: nine dependent memory latencies per pixel)
+    uint4 tv[9];
+    bool in[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int iy = py + t / 3 - 1, ix = px + t % 3 - 1;
+      in[t] = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+      const int cy = iy < 0 ? 0 : (iy < H ? iy : H - 1), cx = ix < 0 ? 0 : (ix < W ? ix : W - 1);
+      tv[t] = *reinterpret_cast<const uint4*>(ab + ((long long)cy * W + cx) * 32);
+    }
     float acc = 0.f;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int iy = py + ky - 1;
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ix = px + kx - 1;
-        if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
-          float v[8];
-          load8(ab, ((long long)iy * W + ix) * 32, 0, v);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc += v[j] * wv[ky * 3 + kx][j];
-        }
-      }
+    for (int t = 0; t < 9; ++t) {
+      const uint4 u = in[t] ? tv[t] : make_uint4(0, 0, 0, 0);
+      acc += bf_lo(u.x) * wv[t][0]; acc += bf_hi(u.x) * wv[t][1]; acc += bf_lo(u.y) * wv[t][2]; acc += bf_hi(u.y) * wv[t][3];
+      acc += bf_lo(u.z) * wv[t][4]; acc += bf_hi(u.z) * wv[t][5]; acc += bf_lo(u.w) * wv[t][6]; acc += bf_hi(u.w) * wv[t][7];
     }
     acc += __shfl_xor(acc, 1);
     acc += __shfl_xor(acc, 2);
@@ -334,21 +337,30 @@ __global__ __launch_bounds__(TPB) void k_head2_bwd_data(const float* gd, const b
     float acc[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    // (the nine taps from clamped addresses, all in flight, zeroed by a select outside the image: as in k_head2_fwd)
+    float dyv[9];
+    long long oc[9];
+    bool in[9];
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-      const int oy = py + 1 - ky;
+    for (int t = 0; t < 9; ++t) {
+      const int oy = py + 1 - t / 3, ox = px + 1 - t % 3;
+      in[t] = (unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W;
+      const int cy = oy < 0 ? 0 : (oy < H ? oy : H - 1), cx = ox < 0 ? 0 : (ox < W ? ox : W - 1);
+      oc[t] = (long long)cy * W + cx;
+      dyv[t] = gb[oc[t]];
+    }
+    if (addb) {                                             // (kernel argument: uniform)
+      bf16_t av9[9];
 #pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ox = px + 1 - kx;
-        if ((unsigned)oy < (unsigned)H && (unsigned)ox < (unsigned)W) {
-          const long long o = (long long)oy * W + ox;
-          float dyv = gb[o];
-          if (addb) dyv += bf2f(addb[o * add_ld]);
-          dyv = bf_round(dyv);
+      for (int t = 0; t < 9; ++t) av9[t] = addb[oc[t] * add_ld];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] += dyv * wv[ky * 3 + kx][j];
-        }
-      }
+      for (int t = 0; t < 9; ++t) dyv[t] += bf2f(av9[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float dv = in[t] ? bf_round(dyv[t]) : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += dv * wv[t][j];
     }
     float av[8];
     const long long off = ((long long)b * npix + pix) * 32 + q * 8;

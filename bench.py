@@ -147,6 +147,24 @@ def pmc_traffic(kernel):
     return round(tot / n) if n else None
 
 
+def trace_frac(kernel, flops):
+    """The same family's fraction of the MFMA peak in the COMMITTED rocprofv3 trace of one replayed step (profiles/
+    r03_one_step_kernels.txt, made by tools/profile_round.sh from this command; valid while profiles/pmc_traffic.json carries the
+    sha of the current kernel sources, i.e. both were refreshed together): sum of the family's rows there.  The live `frac` is
+    measured with the family replayed back to back; the trace's per-kernel durations include the dispatch boundary (~3 us per
+    launch) and the traced step runs ~10 % slower, so it reads 0.01-0.02 lower.  None when the files are absent or stale."""
+    import re
+    path, pmc = os.path.join(REPO, "profiles", "r03_one_step_kernels.txt"), os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not (os.path.exists(path) and os.path.exists(pmc)) or json.load(open(pmc)).get("csrc_sha") != csrc_sha():
+        return None
+    prefix, ms = kernel.rstrip("*"), 0.0
+    for line in open(path):
+        m = re.match(r"\s*([\d.]+) ms\s+\d+x\s+[\d.]+ us\s+(\S+)", line)
+        if m and m.group(2).startswith(prefix):
+            ms += float(m.group(1))
+    return round(flops / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if ms > 0 else None
+
+
 def forward_only(model, batch, B, H, W, variant, reps=20):
     """Eval-mode forward (forward-only roofline fraction), replayed from one HIP graph."""
     from camradepth_amd.inference import InferenceGraph
@@ -410,7 +428,8 @@ def main():
                            "launches_per_step": n, "avg_launch_us": round(1e3 * ms_tot / n, 2),
                            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                            "method": "HIP events around 10 replays of one HIP graph holding all launches of the family of one step",
-                           "isolated_eager_tflops": round(fl_e / (ms_e * 1e-3) / 1e12, 1)}
+                           "isolated_eager_tflops": round(fl_e / (ms_e * 1e-3) / 1e12, 1),
+                           "frac_in_committed_step_trace": trace_frac(dom, fl) if (a.batch, a.height, a.width, a.variant) == (8, 256, 416, "base") else None}
         out["kernels"] = {k: {"launches": v[0], "ms_per_step": round(v[1], 3), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     if rank == 0 and world == 1 and not a.no_roofline:

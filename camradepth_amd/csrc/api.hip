@@ -15,3 +15,19 @@ void crd_set_error(const char* fmt, ...) {
 extern "C" const char* crd_last_error(void) { return g_err; }
 extern "C" int crd_version(void) { return 1; }
 extern "C" const char* crd_arch(void) { return "gfx950"; }
+
+// ---- sticky non-finite indicator of the fixed-point sums (common.h: to_fx) ----
+static int (*g_nf_readers[64])(int);
+static int g_nf_count = 0;
+void crd_register_nonfinite_reader(int (*reader)(int)) {
+  if (g_nf_count < 64) g_nf_readers[g_nf_count++] = reader;
+}
+extern "C" int crd_nonfinite_status(int32_t reset) {
+  int any = 0;
+  for (int i = 0; i < g_nf_count; ++i) {
+    const int v = g_nf_readers[i](reset);
+    if (v < 0) { crd_set_error("crd_nonfinite_status: cannot read the device flag"); return CRD_E_LAUNCH; }
+    any |= v;
+  }
+  return any ? 1 : 0;
+}

@@ -181,11 +181,21 @@ typedef __attribute__((address_space(1))) unsigned long long gsum_raw_t;
 // |v * one| < 2^50 the fp64 adder does the rounding: x + 1.5 * 2^52 has an ulp of exactly 1, so its mantissa bits are the
 // integer (the low dword of the magic constant's bit pattern is zero: taking it off again is one 32-bit subtract).  Both
 // paths round the exact product v * one to nearest even, so they agree bit for bit and the choice is invisible.
+// NON-FINITE / OUT-OF-RANGE partials.  An integer accumulator cannot hold NaN or infinity: a NaN partial would convert to 0 and an
+// infinite one would saturate and wrap -- a diverged run would show a finite, too-small loss where the reference shows NaN
+// (ADVICE r3).  Such a partial (NaN, +-inf, or |v * one| >= 2^62) adds NOTHING and raises this translation unit's sticky flag
+// instead; crd_nonfinite_status() (api.hip) reads and clears the flags of all translation units, and the Python side turns the
+// affected values into NaN (TrainStep.losses(), the loss modules).  The flag is raised on the rare path only (one plain store).
+static __device__ int crd_tu_nonfinite;
 __device__ __forceinline__ long long to_fx(float v, float one) {
   const float s = v * one;                              // exact (power-of-two scale) unless it overflows to inf
   if (fabsf(s) < 1125899906842624.f) {                  // 2^50
     const double d = (double)s + 6755399441055744.0;    // 1.5 * 2^52
     return __double_as_longlong(d) - 0x4338000000000000ll;
+  }
+  if (!(fabsf(s) < 4611686018427387904.f)) {            // 2^62; also NaN (every comparison with NaN is false)
+    crd_tu_nonfinite = 1;
+    return 0;
   }
   return __float2ll_rn(s);
 }
@@ -257,6 +267,16 @@ __device__ __forceinline__ void sum_samples(const crd_sum_t* r, int B, int C, in
     }
   }
 }
+
+// every translation unit registers a reader of its sticky flag with api.hip (crd_nonfinite_status)
+void crd_register_nonfinite_reader(int (*reader)(int reset));
+static int crd_tu_read_nonfinite(int reset) {
+  int v = 0;
+  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(crd_tu_nonfinite), sizeof(int)) != hipSuccess) return -1;
+  if (reset && v) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(crd_tu_nonfinite), &z, sizeof(int)); }
+  return v;
+}
+namespace { struct CrdNonfiniteRegistrar { CrdNonfiniteRegistrar() { crd_register_nonfinite_reader(&crd_tu_read_nonfinite); } }; static CrdNonfiniteRegistrar crd_nonfinite_registrar; }
 
 static inline hipStream_t as_stream(crd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -274,7 +274,7 @@ __global__ __launch_bounds__(TPB) void k_weight_pack(const crd_pack_entry* tab) 
         if (co < e.Cout && ci < e.Cin_pad) {
           const float v = tile[col * per_co + cl * e.taps + tap];
           const long long o = ((long long)co * e.taps + tap) * e.Cin_pad + ci;
-          if (e.dst_f32) reinterpret_cast<float*>(e.dst_fwd)[o] = v;
+          if (e.dst_f32) reinterpret_cast<float*>(e.dst_fwd)[o] = e.dst_f32 == 2 ? bf_round(v) : v;
           else reinterpret_cast<bf16_t*>(e.dst_fwd)[o] = f2bf(v);
         }
       }

@@ -9,7 +9,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcamradepth_hip.so")
+# CRD_LIB: load another build of the library (developer builds with profiling stamps -- tools/prof_*.sh link them to their own
+# file instead of overwriting the product library)
+LIB_PATH = os.environ.get("CRD_LIB") or os.path.join(_HERE, "libcamradepth_hip.so")
 
 
 class CrdError(RuntimeError):
@@ -71,6 +73,23 @@ class MlpDesc(C.Structure):
                [(n, C.c_int32) for n in ("B", "H", "W", "C", "hidden")]
 
 
+class EncBlockDesc(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("wq", "wsr", "wk", "wp", "w1", "w2", "w9b", "vec", "dp")] + \
+               [("pf_ptr", C.c_void_p * 8), ("pf_bytes", C.c_int32 * 8)] + \
+               [(n, C.c_void_p) for n in ("st1", "ch1", "xn", "q", "kr", "stk", "krn", "k", "ssum", "idx", "xbar", "u", "x1", "st2", "xn2",
+                                          "h1", "sth1", "h2", "sth2", "h3", "x2")]
+
+
+class FragEntry(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
+
+
+class EncStageDesc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("blocks", C.c_void_p)] + \
+               [(n, C.c_int32) for n in ("nblocks", "B", "H", "W", "C", "hidden", "heads", "sr")] + \
+               [("xb_out", C.c_void_p), ("sync_ws", C.c_void_p), ("status", C.c_void_p)]
+
+
 class UnpackEntry(C.Structure):
     _fields_ = [
         ("src", C.c_void_p), ("dst", C.c_void_p), ("cmap", C.c_void_p),
@@ -124,6 +143,8 @@ _SIGS = {
     "crd_ce_focal_bwd": "ppiilppfpp",
     "crd_diffgradnorm_step": "pppppppppppiipfffffipp",
     "crd_mlp_fused_supported": "iiii", "crd_mlp_fwd": "pp", "crd_mlp_reduce": "pipppiiipppp",
+    "crd_nonfinite_status": "i",
+    "crd_enc_stage_supported": "iiiiiii", "crd_enc_stage_ws_bytes": "iiiiiii", "crd_enc_stage_fwd": "pp", "crd_pack_frag32": "pilp",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "L": C.c_uint64, "f": C.c_float}
 EXPORTS = list(_SIGS)
@@ -142,6 +163,15 @@ def stat_value(t):
 def grad_value(t):
     """float64 value of gradient sums (CRD_GRAD_FRAC_BITS)."""
     return t.double() * 2.0 ** -GRAD_FRAC_BITS
+
+
+def nonfinite(reset=True):
+    """True if a non-finite (or out-of-range) partial was dropped from a crd_sum_t accumulator since the flag was last cleared
+    (include/camradepth_hip.h: crd_nonfinite_status).  Synchronises with the device."""
+    rc = load().crd_nonfinite_status(1 if reset else 0)
+    if rc < 0:
+        check(rc, "crd_nonfinite_status")
+    return rc == 1
 
 
 def check(rc, what=""):

@@ -111,6 +111,15 @@ class diffGradNorm(Optimizer):
                 gptr = fg.data_ptr()
                 st["active"].copy_(torch.tensor(act_host, dtype=torch.uint8))
                 st["act_host"] = None
+            # The kernel's bias corrections use ONE step count per group.  The reference keeps one per parameter
+            # (diffGradNorm.py:66,76-77): they differ only for a parameter that is frozen for some steps and unfrozen later
+            # (or a checkpoint with non-uniform steps).  Refuse that silently-different case instead of approximating it --
+            # BEFORE anything is modified (no kernel launch, no state change on the refused call).
+            steps = {self.state[p]["step"] + 1 for p, a_ in zip(ps, act_host) if a_}
+            if len(steps) > 1:
+                raise L.CrdError("camradepth_amd.diffGradNorm: parameters of one group have different step counts "
+                                 f"({sorted(steps)}): unfreezing a parameter mid-run (or loading such a checkpoint) needs one "
+                                 "param_group per step count")
             st["step"] += 1
             beta1, beta2 = group["betas"]
             pbase = st["flat_p"].data_ptr() if st["flat_p"] is not None else st["base"]
@@ -126,14 +135,6 @@ class diffGradNorm(Optimizer):
             for ow in {getattr(p, "_crd_owner", None) for p in ps}:        # graph-replayed forwards re-pack their weights
                 if ow is not None and ow() is not None:
                     ow().mark_params_changed()
-            # The kernel's bias corrections use ONE step count per group.  The reference keeps one per parameter
-            # (diffGradNorm.py:66,76-77): they differ only for a parameter that is frozen for some steps and unfrozen later
-            # (or a checkpoint with non-uniform steps).  Refuse that silently-different case instead of approximating it.
-            steps = {self.state[p]["step"] for p, a_ in zip(ps, act_host) if a_}
-            if len(steps) > 1:
-                raise L.CrdError("camradepth_amd.diffGradNorm: parameters of one group have different step counts "
-                                 f"({sorted(steps)}): unfreezing a parameter mid-run (or loading such a checkpoint) needs one "
-                                 "param_group per step count")
         return loss
 
     def load_state_dict(self, state_dict):

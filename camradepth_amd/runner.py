@@ -51,19 +51,27 @@ class Trainer:
         self.max_depth, self.max_distances, self.num_classes = max_depth, tuple(max_distances), num_classes
         self.group, self.use_graph = group, use_graph
         self.criterion = {"depth": HL.MaskedSmoothL1Loss(), "seg": HL.MaskedFocalLoss()}      # runner.py:149
-        self.step = None                     # TrainStep, built on the first training batch (it fixes B, H, W)
+        self.step = None                     # the TrainStep of the batch shape seen last
+        self._steps, self._train_state = {}, None     # (B, H, W) -> TrainStep, all sharing one TrainState
         self._infer = {}                     # (B, H, W) -> InferenceGraph
         self.training_steps = self.val_steps = 0
 
     # ------------------------------------------------------------------ training (runner.py:166-270)
     def _train_step_for(self, b):
+        """The TrainStep for this batch's shape.  The reference DataLoader keeps the smaller last batch of an epoch
+        (src/data/dataloader.py:40: no drop_last), so a run sees (at least) two shapes: each gets its own plan and graphs, all of
+        them continue ONE TrainState -- optimizer moments, bias-correction step count, OneCycle position, open accumulation
+        window (an optimizer that restarted twice per epoch would be silent and wrong)."""
         B, _, H, W = b["image"].shape
-        if self.step is None or (self.step.B, self.step.H, self.step.W) != (B, H, W):
+        key = (B, H, W)
+        if key not in self._steps:
             steps = len(self.train_dataloader) * self.num_epochs       # OneCycleLR(steps_per_epoch=len(loader), epochs): runner.py:151
             self.model.train()
-            self.step = TrainStep(self.model, B, H, W, lr=self.learning_rate, update_interval=self.update_interval,
-                                  schedule=one_cycle(max(steps, 2), self.learning_rate, div_factor=self.div_factor),
-                                  use_graph=self.use_graph, group=self.group)
+            self._steps[key] = TrainStep(self.model, B, H, W, lr=self.learning_rate, update_interval=self.update_interval,
+                                         schedule=one_cycle(max(steps, 2), self.learning_rate, div_factor=self.div_factor),
+                                         use_graph=self.use_graph, group=self.group, state=self._train_state)
+            self._train_state = self._steps[key].state
+        self.step = self._steps[key]
         return self.step
 
     def train_one_epoch(self, epoch, save=False):

@@ -83,6 +83,49 @@ class GradSync:
         self.wait()
 
 
+class TrainState:
+    """What a training run carries from one iteration to the next, independent of the batch shape: diffGradNorm's state over the
+    flat parameter buffer (exp_avg, exp_avg_sq, previous_grad, exp_grad_norm: diffGradNorm.py:62-71), the per-tensor block tables
+    of the multi-tensor optimizer launch, the hyper-parameter upload ring, the (lr, beta1) schedule with its position, the
+    optimizer step count of the bias corrections and the open accumulation window.  A TrainStep is the shape-specific half
+    (plan, static input buffers, captured graphs); the reference's DataLoader has no drop_last (src/data/dataloader.py:40), so
+    the last batch of an epoch is smaller and a second TrainStep for that shape must continue THIS state, not restart it."""
+
+    def __init__(self, model, lr, betas, eps, weight_decay, update_interval, schedule):
+        dev = model.flat.device
+        n = model.flat.numel()
+        self.m, self.v, self.pg = (torch.zeros(n, device=dev) for _ in range(3))
+        nt = len(model._names)
+        self.egn, self.fac = (torch.zeros(nt, device=dev) for _ in range(2))
+        seg, b2s, b2c = [], [], []
+        for t, (name, o) in enumerate(zip(model._names, model._offsets)):
+            numel = model._param(name).numel()
+            seg.append([o, o + numel])
+            for c in range((numel + _CHUNK - 1) // _CHUNK):
+                b2s.append(t)
+                b2c.append(c)
+        self.seg_host, self.b2s_host = seg, b2s
+        self.seg = torch.tensor(seg, dtype=torch.int64, device=dev)
+        self.b2s = torch.tensor(b2s, dtype=torch.int32, device=dev)
+        self.b2c = torch.tensor(b2c, dtype=torch.int32, device=dev)
+        self.nt, self.nblk = nt, len(b2s)
+        self.nsq = torch.zeros(self.nblk, device=dev)        # per-workgroup parts of ||g||^2 (summed in a fixed order)
+        self.hp = torch.zeros(8, device=dev)
+        self.hp_ring = [torch.zeros(8).pin_memory() for _ in range(64)]
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.update_interval = update_interval
+        self.schedule = schedule
+        self.iter_count = 0          # iterations (micro-batches) seen
+        self.epoch_iter = 0          # ... in the current epoch (scheduler lag, runner.py:269)
+        self.sched_steps = 0         # scheduler.step() calls so far = index into `schedule`
+        self.step_count = 0          # optimizer steps taken
+        self._window_open, self._window_pos = False, 0
+
+
+_STATE_FIELDS = ("m", "v", "pg", "egn", "fac", "seg", "b2s", "b2c", "nt", "nblk", "nsq", "hp", "hp_ring", "lr", "betas", "eps", "wd",
+                 "update_interval", "schedule", "iter_count", "epoch_iter", "sched_steps", "step_count", "_window_open", "_window_pos")
+
+
 class TrainStep:
     """One training ITERATION per step() call (runner.py:179-270).  With update_interval = k the gradients of k
     iterations accumulate in the flat gradient buffer (zeroed on the first, runner.py:175,266), the gradient all-reduce
@@ -93,9 +136,14 @@ class TrainStep:
     (diffGradNorm.py:54-55)."""
 
     def __init__(self, model, B, H, W, lr=6e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, update_interval=1,
-                 use_graph=True, schedule=None, group=None):
+                 use_graph=True, schedule=None, group=None, state=None):
+        """state: the TrainState of another TrainStep of the same model (another batch shape of the same run) to continue;
+        lr / betas / eps / weight_decay / update_interval / schedule are then taken from it."""
         assert model.training, "TrainStep drives the training path: call model.train() first"
         assert update_interval >= 1
+        if state is not None and state.m.numel() != model.flat.numel():
+            raise L.CrdError("TrainStep(state=...): the state belongs to a model with a different parameter count")
+        self.state = state if state is not None else TrainState(model, lr, betas, eps, weight_decay, update_interval, schedule)
         self.model, self.B, self.H, self.W = model, B, H, W
         self.dev = model.flat.device
         self.lib = L.load()
@@ -118,24 +166,7 @@ class TrainStep:
                    "quarter": torch.zeros((B, 1, H // 4, W // 4), device=self.dev),
                    "seg": torch.zeros((B, H, W), dtype=torch.int64, device=self.dev)}
         self.acc = torch.zeros(16, dtype=L.SUM_DTYPE, device=self.dev)     # crd_sum_t: 4 x (sum, count, sum sq, -) for full/half/quarter/ce
-        self.update_interval = update_interval
-        # optimizer state over the flat buffers
-        n = model.flat.numel()
-        self.m, self.v, self.pg = (torch.zeros(n, device=self.dev) for _ in range(3))
-        nt = len(model._names)
-        self.egn, self.fac = (torch.zeros(nt, device=self.dev) for _ in range(2))
-        seg, b2s, b2c = [], [], []
-        for t, (name, o) in enumerate(zip(model._names, model._offsets)):
-            numel = model._param(name).numel()
-            seg.append([o, o + numel])
-            for c in range((numel + _CHUNK - 1) // _CHUNK):
-                b2s.append(t)
-                b2c.append(c)
-        self.seg = torch.tensor(seg, dtype=torch.int64, device=self.dev)
-        self.b2s = torch.tensor(b2s, dtype=torch.int32, device=self.dev)
-        self.b2c = torch.tensor(b2c, dtype=torch.int32, device=self.dev)
-        self.nt, self.nblk = nt, len(b2s)
-        self.nsq = torch.zeros(self.nblk, device=self.dev)        # per-workgroup parts of ||g||^2 (summed in a fixed order)
+        seg, b2s, nt = self.state.seg_host, self.state.b2s_host, self.state.nt
         trainable = torch.tensor([1 if model._param(n_).requires_grad else 0 for n_ in model._names], dtype=torch.uint8)
         self.frozen_names = [n_ for n_ in model._names if not model._param(n_).requires_grad]
         self._params = [model._param(n_) for n_ in model._names]
@@ -152,18 +183,9 @@ class TrainStep:
             mask = torch.zeros(nt, dtype=torch.uint8)
             mask[ts_[0]:ts_[-1] + 1] = 1
             self.opt_parts[key] = (blks[0], len(blks), (mask & trainable).to(self.dev))
-        self.hp = torch.zeros(8, device=self.dev)
-        self.hp_ring = [torch.zeros(8).pin_memory() for _ in range(64)]
-        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
-        self.schedule = schedule
-        self.iter_count = 0          # iterations (micro-batches) seen
-        self.epoch_iter = 0          # ... in the current epoch (scheduler lag, runner.py:269)
-        self.sched_steps = 0         # scheduler.step() calls so far = index into `schedule`
-        self.step_count = 0          # optimizer steps taken
         self.use_graph = use_graph
         self.graphs = None
         self._zero, self._opt = True, True
-        self._window_open, self._window_pos = False, 0
 
     def start_epoch(self):
         """Epoch boundary of the reference loop: the batch index restarts (scheduler lag) and pending accumulated
@@ -402,6 +424,11 @@ class TrainStep:
     def losses(self):
         """Host view of the last iteration's loss terms (synchronises)."""
         a = L.stat_value(self.acc.cpu())
+        if L.nonfinite():
+            # a NaN / infinite / out-of-range partial was dropped from a fixed-point sum since the last check (include/camradepth_hip.h:
+            # crd_nonfinite_status): the sums are not what the reference would have computed -- it reports NaN here, so do we
+            nan = float("nan")
+            return {"loss": nan, "full": nan, "half": nan, "quarter": nan, "seg": nan, "rmse": nan}
         full, half, quarter = (float(a[4 * i] / a[4 * i + 1]) for i in range(3))
         rmse = math.sqrt(float(a[2] / a[1]))
         seg = 0.0
@@ -410,3 +437,11 @@ class TrainStep:
             seg = (1 - math.exp(-ce)) ** 2 * ce
         total = (LOSS_W[0] * full + LOSS_W[1] * half + LOSS_W[2] * quarter + LOSS_W[3] * seg) / sum(LOSS_W) / self.update_interval
         return {"loss": total, "full": full, "half": half, "quarter": quarter, "seg": seg, "rmse": rmse}
+
+
+def _delegate(name):
+    return property(lambda self: getattr(self.state, name), lambda self, v: setattr(self.state, name, v))
+
+
+for _n in _STATE_FIELDS:
+    setattr(TrainStep, _n, _delegate(_n))

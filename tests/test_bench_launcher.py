@@ -16,7 +16,8 @@ def test_rank_env_is_one_rank_per_gpu_on_loopback():
     for r, e in enumerate(envs):
         assert e["RANK"] == e["LOCAL_RANK"] == str(r) and e["WORLD_SIZE"] == "8"
         assert e["MASTER_ADDR"] == "127.0.0.1" and e["MASTER_PORT"] == "29999"
-        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and e["PATH"] == "/usr/bin"
+        assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "1" and e["PATH"] == "/usr/bin"      # a value the caller set is kept
+    assert bench.rank_env(0, 2, 29999, base={"PATH": "/usr/bin"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"   # unset: dmabuf IPC for RCCL
     assert bench.free_port() > 0
 
 
@@ -32,3 +33,16 @@ def test_gpus_n_without_a_launcher_spawns_n_ranks():
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["metric"] == "training images/sec at 64x96 bf16"
     # MAX over ranks: rank 1 sleeps 2 ms per step, so 5 steps of global batch 16 cannot beat 16 * 5 / 0.010 images/s
     assert 0 < out["value"] <= 16 * 5 / 0.010
+
+
+def test_launcher_takes_the_other_ranks_down_when_one_dies():
+    """A rank that exits early must not leave the others (and the launcher) in the rendezvous forever: the launcher polls every
+    child, terminates the rest on the first failure and returns that exit code."""
+    import subprocess
+    import time
+    env = dict(os.environ, CRD_STUB_FAIL_RANK="1", CRD_BENCH_TIMEOUT="120")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "0", "--stub"],
+                       env=env, capture_output=True, text=True, timeout=110)
+    assert r.returncode == 3, (r.returncode, r.stdout, r.stderr[-500:])
+    assert time.time() - t0 < 60

@@ -77,7 +77,9 @@ def _worker_step(rank, world, port, q):
         from camradepth_amd.trainer import GradSync, TrainStep
         m = CamRaDepth(input_channels=7, depths=(1, 1, 1, 1))
         m._ensure_grad_views()
+        import types
         ts = object.__new__(TrainStep)
+        ts.state = types.SimpleNamespace()          # the shape-independent half (trainer.TrainState): counters, schedule, window
         ts.model, ts.sync = m, GradSync(m)
         ts.dist_active, ts.world, ts.update_interval, ts.use_graph, ts.graphs = True, world, 2, False, None
         ts.schedule, ts.lr, ts.betas, ts.eps, ts.wd = None, 1e-3, (0.9, 0.999), 1e-8, 0.0

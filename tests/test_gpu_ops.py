@@ -803,3 +803,29 @@ def test_batch_assembly_matches_dataloader_arithmetic():
         got = out[name].cpu()
         assert got.shape == ref.shape, (name, got.shape, ref.shape)
         assert torch.equal(got, ref) or float((got - ref).abs().max()) < 1e-7, name
+
+
+def test_nonfinite_partials_raise_the_sticky_flag():
+    """A crd_sum_t accumulator cannot hold NaN / infinity: such a partial adds nothing and raises a sticky flag instead
+    (include/camradepth_hip.h: crd_nonfinite_status), which TrainStep.losses() turns back into NaN (the fp32 atomics
+    of round 2 propagated NaN, the integer sums of round 3 silently dropped it)."""
+    from camradepth_amd import lib as L
+    lib = L.load()
+    L.nonfinite()                                        # clear
+    n = 4096
+    pred = torch.rand(n, device="cuda")
+    tgt = torch.rand(n, device="cuda") + 0.1
+    acc = zsum(4)
+    L.check(lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), n, acc.data_ptr(), L.stream()))
+    torch.cuda.synchronize()
+    assert not L.nonfinite()
+    pred[17] = float("nan")
+    acc.zero_()
+    L.check(lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), n, acc.data_ptr(), L.stream()))
+    torch.cuda.synchronize()
+    assert L.nonfinite(reset=False) and L.nonfinite() and not L.nonfinite()       # sticky until cleared
+    pred[17] = float("inf")
+    acc.zero_()
+    L.check(lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), n, acc.data_ptr(), L.stream()))
+    torch.cuda.synchronize()
+    assert L.nonfinite()

@@ -63,3 +63,88 @@ def test_trainer_epoch_entry_points():
     # second epoch through train(): the schedule continues, best validation loss is returned
     best = tr.train()
     assert np.isfinite(best) and tr.training_steps == 3 + 2 * 3
+
+
+def test_ragged_last_batch_continues_the_optimizer_state():
+    """The reference DataLoader has no drop_last (src/data/dataloader.py:40): epochs end with a smaller batch.  The epoch loop
+    must carry the optimizer moments, the bias-correction step count, the OneCycle position and an open accumulation window
+    across the shape change: compared with a hand-written eager loop over the same batches -- the module's own
+    autograd path + camradepth_amd.optim.diffGradNorm with the schedule written out -- parameter by parameter."""
+    from camradepth_amd import losses as hl
+    from camradepth_amd.model import CamRaDepth
+    from camradepth_amd.optim import diffGradNorm
+    from camradepth_amd.runner import Trainer
+    from camradepth_amd.trainer import LOSS_W, one_cycle
+    cfg = dataclasses.replace(ModelConfig.variant("base"), depths=(1, 1, 1, 1))
+    sd = synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0)
+    sizes = [2, 2, 1]                                 # 5 samples, batch size 2: the last batch of every epoch holds one
+    epochs, k, lr = 2, 2, 1e-3
+    batches = [synth.make_batch(B, 64, 96, seed=60 + i, with_seg=False) for i, B in enumerate(sizes)]
+
+    def fresh():
+        m = CamRaDepth(input_channels=7, depths=cfg.depths)
+        m.load_state_dict(sd)
+        m = m.cuda().train()
+        return m
+
+    # -- the runner (graph steps; DropPath / Dropout2d masks fixed to ones so that both loops see the same function)
+    m1 = fresh()
+    tr = Trainer(m1, batches, None, None, learning_rate=lr, num_epochs=epochs, update_interval=k)
+    for e in range(epochs):
+        n = len(batches)
+        for i, b in enumerate(batches):
+            ts = tr._train_step_for(b)
+            ts.plan.training_masks_fixed = True
+            ts.plan.dp_masks.fill_(1.0)
+            ts.plan.d2_masks.fill_(1.0)
+            if i == 0:
+                ts.start_epoch()
+            ts.set_batch(b)
+            ts.step(last_of_epoch=(i + 1 == n))
+    torch.cuda.synchronize()
+    assert len(tr._steps) == 2 and tr._steps[(2, 64, 96)].state is tr._steps[(1, 64, 96)].state
+    st = tr._train_state
+    # per epoch: optimizer after batch 2 and (flush) after batch 3
+    assert st.step_count == 2 * epochs and st.iter_count == 3 * epochs
+
+    # -- the same iterations written out eagerly with ONE optimizer
+    m2 = fresh()
+    opt = diffGradNorm(m2.parameters(), lr=lr)
+    sched = one_cycle(max(len(batches) * epochs, 2), lr, div_factor=2.0)
+    cfgm = m2.cfg
+    sched_steps = 0
+    for e in range(epochs):
+        window = 0
+        for i, b in enumerate(batches):
+            B = b["image"].shape[0]
+            masks = {"drop_path": [torch.ones(B) for _ in cfgm.drop_path_rates], "dropout2d": [torch.ones(B, 128) for _ in range(5)]}
+            if window == 0:
+                opt.zero_grad(set_to_none=False)
+            out = m2(b["image"].cuda(), masks=masks)
+            loss, _ = hl.total_loss(out, {kk: v.cuda() for kk, v in b.items()}, False)
+            (loss / k).backward()
+            window += 1
+            if window == k or i + 1 == len(batches):
+                lr_i, b1 = sched[min(sched_steps, len(sched) - 1)]
+                for gp in opt.param_groups:
+                    gp["lr"], gp["betas"] = lr_i, (b1, gp["betas"][1])
+                opt.step()
+                window = 0
+            if i + 1 > k:                  # the reference's scheduler lag (runner.py:269-270)
+                sched_steps += 1
+    torch.cuda.synchronize()
+    assert sched_steps == st.sched_steps
+    start = _flat_of(m2, sd)
+    moved = float((m2.flat - start).norm())
+    assert moved > 0
+    # graph step vs eager autograd path: the same kernels, enqueued differently; parameters agree to float rounding of the update
+    rel_ = float((m1.flat - m2.flat).norm()) / moved
+    assert rel_ < 2e-2, rel_
+    # a run whose optimizer state restarted at the shape changes is far outside that (moments, bias correction and schedule differ)
+
+
+def _flat_of(model, sd):
+    out = torch.zeros_like(model.flat)
+    for n, o in zip(model._names, model._offsets):
+        out[o:o + sd[n].numel()] = sd[n].flatten().to(out.device)
+    return out

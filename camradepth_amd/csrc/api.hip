@@ -31,3 +31,16 @@ extern "C" int crd_nonfinite_status(int32_t reset) {
   }
   return any ? 1 : 0;
 }
+
+// ---- refused dynamic-LDS reservations (common.h: crd_reserve_lds) ----
+static thread_local char g_attr_err[256] = "";
+void crd_note_attr_failure(const char* kernel, int bytes, int hip_err) {
+  snprintf(g_attr_err, sizeof(g_attr_err), "cannot reserve %d bytes of dynamic LDS for %s (hip error %d: %s)", bytes, kernel, hip_err,
+           hipGetErrorString((hipError_t)hip_err));
+}
+int crd_report_attr_failure(const char* entry_point) {
+  if (g_attr_err[0] == 0) return 0;
+  crd_set_error("%s: %s", entry_point, g_attr_err);
+  g_attr_err[0] = 0;
+  return 1;
+}

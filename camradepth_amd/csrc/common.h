@@ -32,8 +32,18 @@ void crd_set_error(const char* fmt, ...);
     }                                       \
   } while (0)
 
+// Dynamic-LDS reservations (hipFuncSetAttribute) are checked: a refusal is remembered (thread-local, api.hip) and reported by the
+// CRD_LAUNCH_CHECK that follows the launch, by kernel name and size, instead of surfacing as an opaque "invalid argument" launch failure.
+void crd_note_attr_failure(const char* kernel, int bytes, int hip_err);
+int crd_report_attr_failure(const char* entry_point);      // 1 if a refusal was pending: crd_last_error() is set
+static inline void crd_reserve_lds(const void* fn, int bytes, const char* kernel) {
+  const hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e_ != hipSuccess) crd_note_attr_failure(kernel, bytes, (int)e_);
+}
+
 #define CRD_LAUNCH_CHECK(name)                                                   \
   do {                                                                           \
+    if (crd_report_attr_failure(name)) { (void)hipGetLastError(); return CRD_E_LAUNCH; } \
     hipError_t e_ = hipGetLastError();                                           \
     if (e_ != hipSuccess) {                                                      \
       crd_set_error("%s: launch failed: %s", name, hipGetErrorString(e_));       \

@@ -296,13 +296,13 @@ int launch3(const ConvK& k0, int B, hipStream_t st, long long partial_cap, int c
   static bool attr_done[2] = {false, false};
   if (k.gather_mode == 0) {
     if (!attr_done[0]) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 0, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      crd_reserve_lds(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 0, WS>), (int)lds, "k_conv3x3");
       attr_done[0] = true;
     }
     hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 0, WS>), grid, dim3(256), lds, st, k, tiles_x);
   } else {
     if (!attr_done[1]) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 1, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      crd_reserve_lds(reinterpret_cast<const void*>(&k_conv3x3<WM, WN, TM, TN, 1, WS>), (int)lds, "k_conv3x3");
       attr_done[1] = true;
     }
     hipLaunchKernelGGL((k_conv3x3<WM, WN, TM, TN, 1, WS>), grid, dim3(256), lds, st, k, tiles_x);

@@ -337,7 +337,7 @@ int launch8(const F8K& k, int B, hipStream_t st) {
   if (gx > tiles_total) gx = tiles_total;
   const size_t lds = (size_t)(2 * HPAD * QKC + WS * BN * QKC + 16 * QKC) + BN * sizeof(float);
   static bool attr_done = false;
-  if (!attr_done) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_fp8<TN, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done = true; }
+  if (!attr_done) { crd_reserve_lds(reinterpret_cast<const void*>(&k_conv3x3_fp8<TN, WS>), (int)lds, "k_conv3x3_fp8"); attr_done = true; }
   hipLaunchKernelGGL((k_conv3x3_fp8<TN, WS>), dim3(gx, gy), dim3(256), lds, st, k, tiles_x, tiles_y, tiles_total);
   CRD_LAUNCH_CHECK("crd_conv3x3_fp8");
   return CRD_OK;

@@ -393,10 +393,10 @@ int launch_p(const ConvK& k0, int B, hipStream_t st, int col0, int col1) {
   static bool attr_done[2] = {false, false};
   const int m = k.gather_mode == 0 ? 0 : 1;
   if (m == 0) {
-    if (!attr_done[0]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 0, WS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+    if (!attr_done[0]) { crd_reserve_lds(reinterpret_cast<const void*>(&k_conv3x3p<TN, 0, WS, NW>), (int)lds, "k_conv3x3p"); attr_done[0] = true; }
     hipLaunchKernelGGL((k_conv3x3p<TN, 0, WS, NW>), dim3(gx, gy), dim3(64 * NW), lds, st, k, tiles_x, tiles_y, tiles_total);
   } else {
-    if (!attr_done[1]) { hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3p<TN, 1, WS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+    if (!attr_done[1]) { crd_reserve_lds(reinterpret_cast<const void*>(&k_conv3x3p<TN, 1, WS, NW>), (int)lds, "k_conv3x3p"); attr_done[1] = true; }
     hipLaunchKernelGGL((k_conv3x3p<TN, 1, WS, NW>), dim3(gx, gy), dim3(64 * NW), lds, st, k, tiles_x, tiles_y, tiles_total);
   }
   CRD_LAUNCH_CHECK("crd_conv_igemm(3x3 persistent)");

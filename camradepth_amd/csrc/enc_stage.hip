@@ -154,14 +154,20 @@ struct EncK {
 // one ds_read_b128 per 16-cycle MFMA with 2-way conflicts made every GEMM LDS-bound (fc1: 12.6 us per Block for 1.3 us of
 // MFMA time).  A lane ends with one pixel and 16 channels: quads q = 0..3 at channel ct * 32 + 8 q + 4 (lane >> 5) + {0..3}.
 // Units (ct, rt) are dealt to the 16 waves.
-template <int KC, int NCH, class BPtr, class Epi>
+template <int KC, int NCH, int ROT = 0, class BPtr, class Epi>
 __device__ __forceinline__ void wg_gemm(const bf16_t* __restrict__ Wf, int kstot, int ntiles, int RT, const float* __restrict__ bias,
-                                        int wv, int lane, BPtr bptr, Epi epi) {
+                                        int wave, int lane, BPtr bptr, Epi epi) {
+  const int wv = (wave + ROT) % NW;          // ROT: which waves take the first units (balances back-to-back GEMMs with few units)
   // A wave's work is the flat sequence of (unit, chunk) items of its units; the weight chunk of item i + NB - 1 is requested
-  // before item i is computed, ACROSS unit boundaries: NB - 1 chunks (KC KB each) per wave are always in flight.  What bounds
+  // before item i is computed, ACROSS unit boundaries: NB - 1 chunks (KC KB each) per wave are always in flight.  NB = 2: deeper
+  // rings were SLOWER (stage 3 forward at B = 8: NB 1 / 2 / 3 / 4 = 1340 / 1297 / 1430 / 1397 us) -- the loop body is unrolled NB
+  // times with the epilogue inlined in each copy, and this kernel is bound by instruction issue, not by the weights' latency.  What bounds
   // these GEMMs is the rate at which one CU pulls weights out of L2 (every workgroup streams all of a block's weights:
   // 768 KB per Block at stage 3) -- with a single chunk in flight and a wait per chunk the first version reached 16 GB/s.
-  constexpr int NB = 4;
+#ifndef CRD_ENC_NB
+#define CRD_ENC_NB 2
+#endif
+  constexpr int NB = CRD_ENC_NB;
   const int l = opq(lane);
   const int units = ntiles * RT;
   const int nu = units > wv ? (units - wv + NW - 1) / NW : 0;      // units of this wave: wv, wv + NW, ...
@@ -184,7 +190,7 @@ __device__ __forceinline__ void wg_gemm(const bf16_t* __restrict__ Wf, int kstot
   };
 #pragma unroll
   for (int j = 0; j < NB - 1; ++j) issue(j, a[j]);
-  f32x16 acc;
+  f32x16 acc, acc1;         // two accumulation chains (even / odd k-steps): a dependent MFMA chain issues at half rate
   f32x4 bv[4];
   for (int i0 = 0; i0 < n; i0 += NB) {
 #pragma unroll
@@ -201,17 +207,22 @@ __device__ __forceinline__ void wg_gemm(const bf16_t* __restrict__ Wf, int kstot
 #pragma unroll
           for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const f32x4*>(bp + 8 * q);
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+          for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc1[r] = 0.f; }
         }
         const bf16_t* bb = bptr(rt, ch, 0, l);
 #pragma unroll
         for (int ks = 0; ks < KC; ++ks) {
           const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bb + ks * 16);
+#ifdef CRD_ENC_ONE_ACC
           acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][ks], bf, acc, 0, 0, 0);
+#else
+          if (ks & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][ks], bf, acc1, 0, 0, 0);
+          else acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j][ks], bf, acc, 0, 0, 0);
+#endif
         }
         if (ch == NCH - 1) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[r] += bv[r >> 2][r & 3];
+          for (int r = 0; r < 16; ++r) acc[r] = (acc[r] + acc1[r]) + bv[r >> 2][r & 3];
           epi(ct, rt, acc, l);
         }
       }
@@ -243,29 +254,54 @@ __device__ __attribute__((noinline)) float2 dw_stencil(lds_bf16* sHc, const lds_
       for (int q = 0; q < 4; ++q) { wf[tap][2 * q] = bf_lo(wt[tap][q]); wf[tap][2 * q + 1] = bf_hi(wt[tap][q]); }
   }
   const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias), b1 = *reinterpret_cast<const f32x4*>(bias + 4);
-  // pixels outermost: nine 16-byte LDS reads and eight accumulators live per pixel; the compiler barrier between pixels keeps
-  // the reads of later pixels from being hoisted (all 63 of them at once is what spilled)
+  // pixels outermost; the nine 16-byte LDS reads of pixel j + 1 are requested before pixel j's arithmetic (two sets of nine in
+  // registers), the products as packed FMAs (v_pk_fma_f32: two channels per instruction).  The asm statements pin the order: the
+  // compiler otherwise hoists all 63 reads to the top and spills them, or sinks all the arithmetic below the last read.
+  typedef __attribute__((ext_vector_type(2))) float f32x2;
   u32x4 outp[PJ];
-#pragma unroll
-  for (int j = 0; j < PJ; ++j) {
+  const unsigned aH = (unsigned)(uintptr_t)sHc, aA = (unsigned)(uintptr_t)hA, aB = (unsigned)(uintptr_t)hB;
+  auto read9 = [&](int j, u32x4 (&u)[9]) {
     const int p = pc + 8 * j, pp = p < NPX ? p : 0;
     const int ly = pp >= W ? 1 : 0, x = pp - ly * W;
-    float o[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    // per stencil row: base address and pixel stride by SELECTS between values that already exist (the opaque asm keeps the
+    // compiler from sinking their computation into an if / else: written as one conditional expression per read this compiled
+    // to an exec-mask branch diamond in front of every one of the 63 reads)
+    unsigned radr[3], rstr[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int yy = ly + ky - 1;
+      unsigned a3 = aH + (unsigned)(yy * W * LDH * 2), sA = (unsigned)(HLD * 2), sH_ = (unsigned)(LDH * 2);
+      asm volatile("" : "+v"(a3), "+v"(sA), "+v"(sH_));
+      const bool up = yy < 0, dn = yy > 1;
+      radr[ky] = up ? aA : (dn ? aB : a3);
+      rstr[ky] = (up || dn) ? sA : sH_;
+    }
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3 - 1, kx = tap % 3 - 1;
-      const int yy = ly + ky, xx = x + kx;
+      const int ky = tap / 3, kx = tap % 3 - 1;
+      const int xx = x + kx;
       const bool xok = xx >= 0 && xx < W;
-      const int xc = xok ? xx : x;
-      const lds_bf16* src = yy < 0 ? hA + xc * HLD : (yy > 1 ? hB + xc * HLD : sHc + (yy * W + xc) * LDH);
-      u32x4 u = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>(src);
-      if (!xok) u = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-      for (int q = 0; q < 4; ++q) { o[2 * q] += bf_lo(u[q]) * wf[tap][2 * q]; o[2 * q + 1] += bf_hi(u[q]) * wf[tap][2 * q + 1]; }
+      const unsigned off = radr[ky] + (unsigned)(xok ? xx : x) * rstr[ky];
+      u[tap] = *reinterpret_cast<const __attribute__((address_space(3))) u32x4*>((uintptr_t)off);
+      if (!xok) u[tap] = u32x4{0u, 0u, 0u, 0u};
     }
-    outp[j][0] = pack_bf2(o[0], o[1]); outp[j][1] = pack_bf2(o[2], o[3]); outp[j][2] = pack_bf2(o[4], o[5]); outp[j][3] = pack_bf2(o[6], o[7]);
-    // the results are pinned HERE: an empty asm taking them as operands (the compiler otherwise sinks all 7 x 72 FMAs below the
-    // last pixel's reads and keeps every 16-byte read alive -- or spilled -- until then)
+  };
+  u32x4 ua[9], ub[9];
+  read9(0, ua);
+#pragma unroll
+  for (int j = 0; j < PJ; ++j) {
+    u32x4 (&cur)[9] = (j & 1) ? ub : ua;
+    u32x4 (&nxt)[9] = (j & 1) ? ua : ub;
+    if (j + 1 < PJ) read9(j + 1, nxt);
+    f32x2 o[4] = {{b0[0], b0[1]}, {b0[2], b0[3]}, {b1[0], b1[1]}, {b1[2], b1[3]}};
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x2 uv = {bf_lo(cur[tap][q]), bf_hi(cur[tap][q])}, wv2 = {wf[tap][2 * q], wf[tap][2 * q + 1]};
+        o[q] = __builtin_elementwise_fma(uv, wv2, o[q]);
+      }
+    outp[j][0] = pack_bf2(o[0][0], o[0][1]); outp[j][1] = pack_bf2(o[1][0], o[1][1]); outp[j][2] = pack_bf2(o[2][0], o[2][1]); outp[j][3] = pack_bf2(o[3][0], o[3][1]);
     asm volatile("" : "+v"(outp[j][0]), "+v"(outp[j][1]), "+v"(outp[j][2]), "+v"(outp[j][3]) :: "memory");
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -367,22 +403,32 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
       ENC_STAMP(0);
       const float dps = d->dp ? d->dp[b] : 1.f;
       const float* __restrict__ pv = d->vec;
-      // L2 warm-up: the NEXT block's weights and vectors (pf_ptr / pf_bytes) are requested into this XCD's L2, 1 KB per wave
-      // request, through LDS-DMA into a scratch kilobyte (no register destination, nothing waits for them); the sample's G
-      // workgroups share the work.  Without it every weight chunk of every GEMM is a first touch from the fabric (~1-2 us).
+      // L2 warm-up: the NEXT block's weights and vectors (pf_ptr / pf_bytes) are requested into this XCD's L2 through LDS-DMA into
+      // a scratch area (no register destination, nothing waits for them); the sample's G workgroups share the work.  Without it every weight chunk of every GEMM is a first touch from the fabric (~1-2 us).
       if (blk + 1 < a.nblocks) {
         const crd_enc_block_desc* dn = d + 1;
-#pragma unroll 1
+        // (all sixteen descriptor words first: read one range at a time, every iteration waited for its own cold scalar load --
+        // this loop took 4-5 us per Block whatever it requested)
+        const void* pptr[8];
+        int pbytes[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { pptr[r] = dn->pf_ptr[r]; pbytes[r] = dn->pf_bytes[r]; }
+#pragma unroll
         for (int r = 0; r < 8; ++r) {
-          const void* ptr = dn->pf_ptr[r];
-          const int bytes = dn->pf_bytes[r];
+          const void* ptr = pptr[r];
+          const int bytes = pbytes[r];
           if (ptr == nullptr) continue;
           const crd_rsrc_t rs = make_rsrc(ptr, (unsigned)bytes);
-          for (int c = g * NW + wv; c * 1024 < bytes; c += G * NW) lds_dma16(rs, (unsigned)CF::OFF_DUMMY, (unsigned)(c * 1024 + (tid & 63) * 16));
+          // ONE dword per 128-byte line (a wave request touches 64 lines = 8 KB): the line lands in L2, only 4 bytes travel on to
+          // the CU.  (Whole lines -- 16 bytes per lane -- made this loop 4.3 us per Block: the CU's own fill rate, ~25 GB/s.)
+          for (int c = g * NW + wv; c * 8192 < bytes; c += G * NW)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+                         :: "s"((unsigned)CF::OFF_DUMMY), "v"((unsigned)(c * 8192 + (tid & 63) * 128)), "s"(rs) : "memory", "m0");
         }
       }
       const long long rowbase = (long long)b * N + g * NPX;         // first own pixel in [B][N][.] tensors
 
+      ENC_STAMP(17);
       // ================= E0: Block.norm1 statistics, xbar =================
       NEWPHASE();
       if (t < 2 * C) {
@@ -395,6 +441,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
         if (g == 0 && d->ch1) d->ch1[(long long)b * C * 2 + t] = tot;
       }
       __syncthreads();
+      ENC_STAMP(18);
       // every thread of a channel adds its group's 16 channel sums itself (broadcast LDS reads) and takes the moments: one barrier
       // instead of three (group sums -> moments -> coefficients)
       if (t < C) {
@@ -450,7 +497,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
                      });
       if constexpr (SR > 1) {
         // kr[j][co] = bf16(sum_{tap, ci} Wsr[co][tap][ci] * xn[pixel(j, tap)][ci] + b): one key row per workgroup (keys on the columns)
-        wg_gemm<KC, 2 * SR * SR>(reinterpret_cast<const bf16_t*>(d->wsr), SR * SR * C / 16, C / 32, 1, pv + CF::V_BSR, wv, l,
+        wg_gemm<KC, 2 * SR * SR, NW - 3>(reinterpret_cast<const bf16_t*>(d->wsr), SR * SR * C / 16, C / 32, 1, pv + CF::V_BSR, wv, l,
             [&](int, int ch, int k, int l) {
               const int tap = ch >> 1;
               int j = l & 31;
@@ -843,6 +890,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
             }
           }
           __syncthreads();
+          ENC_STAMP(19 + 3 * r);
           float s = 0.f, ss = 0.f;
           if (act) {
             constexpr int PJ = (CF::NPXMAX + 7) / 8;
@@ -852,9 +900,11 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
                 d->h2 ? reinterpret_cast<bf16_t*>(d->h2) + rowbase * HID + c0 : nullptr);
             s = r2.x; ss = r2.y;
           }
+          ENC_STAMP(20 + 3 * r);
           s = wave_sum_dpp(s); ss = wave_sum_dpp(ss);   // a wave = 8 granules = 64 channels = one Mlp.norm2 group
           if (l == 0) sRedW[r * NW + wv] = make_float2(s, ss);
           __syncthreads();
+          ENC_STAMP(21 + 3 * r);
         }
       }
       ENC_STAMP(12);

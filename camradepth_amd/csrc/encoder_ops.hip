@@ -920,11 +920,11 @@ extern "C" int crd_dwconv3x3_wgrad(const void* x, const void* dy, int32_t B, int
   static bool attr_done[2] = {false, false};
   if (tw == 32) {
     const size_t lds = (size_t)((DTH + 2) * 34 * 8 + DTH * 32 * 8) * sizeof(uint4);
-    if (!attr_done[0]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_wgrad<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[0] = true; }
+    if (!attr_done[0]) { crd_reserve_lds(reinterpret_cast<const void*>(&k_dwconv_wgrad<32>), (int)lds, "k_dwconv_wgrad"); attr_done[0] = true; }
     hipLaunchKernelGGL(k_dwconv_wgrad<32>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per, inn);
   } else {
     const size_t lds = (size_t)((DTH + 2) * 18 * 8 + DTH * 16 * 8) * sizeof(uint4);
-    if (!attr_done[1]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dwconv_wgrad<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_done[1] = true; }
+    if (!attr_done[1]) { crd_reserve_lds(reinterpret_cast<const void*>(&k_dwconv_wgrad<16>), (int)lds, "k_dwconv_wgrad"); attr_done[1] = true; }
     hipLaunchKernelGGL(k_dwconv_wgrad<16>, grid, dim3(TPB), lds, st, xp, dp, H, W, C, dw10, replicas, tiles_x, tiles_y, per, inn);
   }
   CRD_LAUNCH_CHECK("crd_dwconv3x3_wgrad");
@@ -1076,7 +1076,7 @@ static int attn_scores_bwd_launch(const void* q, const void* k, const float* dS,
   CRD_CHECK_ARG(use_lds ? (dk_partials || dk) : dk != nullptr, "%s: this shape needs the dk accumulator", who);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_scores_bwd), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    crd_reserve_lds(reinterpret_cast<const void*>(&k_attn_scores_bwd), 128 * 1024, "k_attn_scores_bwd");
     attr_done = true;
   }
   if (!use_lds) {

@@ -228,8 +228,7 @@ int launch_reg(const ConvK& k0, GnIn gi, int B, hipStream_t st) {
   CRD_UNSUPPORTED(lds <= 160 * 1024, "crd_gn_conv: table does not fit in LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gngemm_reg<WM, WN, TM, TN, XF32, ACT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    crd_reserve_lds(reinterpret_cast<const void*>(&k_gngemm_reg<WM, WN, TM, TN, XF32, ACT>), 160 * 1024, "k_gngemm_reg");
     attr_done = true;
   }
   k.lds_bytes = (int)tiles;

@@ -229,8 +229,7 @@ void launch_mode(const ConvK& k, dim3 grid, hipStream_t st) {
   constexpr size_t lds = (size_t)KG * NST * (BM + BN) * BK * sizeof(bf16_t);
   static bool attr_done = false;
   if (!attr_done && lds > 64 * 1024) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_igemm<WM, WN, TM, TN, MODE, NST, KG>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    crd_reserve_lds(reinterpret_cast<const void*>(&k_igemm<WM, WN, TM, TN, MODE, NST, KG>), (int)lds, "k_igemm");
     attr_done = true;
   }
   ConvK kk = k;

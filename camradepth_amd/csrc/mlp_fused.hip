@@ -421,7 +421,7 @@ template <int NCH, int XIT>
 int mlp_launch(const MlpK& k, int slabs, size_t lds, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mlp_fwd<NCH, XIT>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    crd_reserve_lds(reinterpret_cast<const void*>(&k_mlp_fwd<NCH, XIT>), 160 * 1024, "k_mlp_fwd");
     attr_done = true;
   }
   hipLaunchKernelGGL((k_mlp_fwd<NCH, XIT>), dim3(slabs, k.B), dim3(MT), lds, st, k);

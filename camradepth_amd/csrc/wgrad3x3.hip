@@ -266,7 +266,7 @@ int launch_w3r(const Wg3K& k0, hipStream_t st, int partial_capacity) {
   const int wgs = plan_rows(k.total_rows, k.Cin, k.rows_per_wg, k.dw_part ? partial_capacity : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO, RPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    crd_reserve_lds(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO, RPS>), (int)lds, "k_wgrad3x3");
     attr_done = true;
   }
   hipLaunchKernelGGL((k_wgrad3x3<WCO, WCI, TCO, RPS>), dim3(wgs, chunks), dim3(512), lds, st, k);

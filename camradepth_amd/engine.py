@@ -232,6 +232,7 @@ class Plan:
         self.gn_conv_on = gn_conv_default()
         self.enc_persist = enc_persist_default()
         self.enc_taps = {}
+        self.block_ops = {}
         self.enc_status = []               # status words of the persistent stage launches (non-zero: a workgroup gave up waiting)
         # need_grad False (plan built under torch.no_grad()): tensors only a backward pass reads are not written
         self.need_grad = bool(getattr(model, "_need_grad", True))
@@ -939,6 +940,7 @@ class Plan:
         if persist is not None:
             self.fwd = []
         F_ = self.fwd
+        n_fwd0 = len(F_)
         # ---- attention branch ----
         XN = self.act(Cs, Hs, Ws)
         # (CRD_GN_CONV_MAXROWS restricts the fusion to the small, latency-bound stages; measured at B = 8 / 16, training and
@@ -1047,7 +1049,9 @@ class Plan:
                 self.gn_fwd(H2, sth2, ratio, ml + ".norm2", 1, None, H3)
                 self.conv(F_, fc2_spec)
 
-        # (test hook: the block's forward tensors by name, for comparisons between the per-launch and the persistent path)
+        # (test hooks: the block's own forward ops with its input / output -- tests/test_gpu_blocks.py runs ONE block on the oracle's
+        # input, "teacher forcing" -- and its forward tensors by name)
+        self.block_ops[name] = dict(ops=list(F_[n_fwd0:]), x=X, x2=X2, st1=st1, ch1=ch1, own_stats=pre is None)
         self.enc_taps[name] = dict(st1=st1, ch1=ch1, xn=XN, q=Q, k=K, ssum=Ssum, idx=idx, xbar=xbar, u=U, x1=X1, st2=st2, xn2=XN2, h1=H1,
                                    sth1=sth1, h2=H2, sth2=sth2, h3=H3, x2=X2, **(dict(kr=KR, stk=stk, krn=KRN) if sr > 1 else {}))
         if persist is not None:

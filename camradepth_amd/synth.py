@@ -97,3 +97,40 @@ def make_masks(cfg, B, seed=4321, dropout_p=0.2):
     d2 = [torch.from_numpy((rs.uniform(size=(B, 128)) < keep).astype(np.float32) / np.float32(keep))
           for _ in range(n_drop)]
     return {"drop_path": dp, "dropout2d": d2}
+
+
+def make_learnable_batch(B, H, W, seed=1234, sigma=5.0, gain=1.2):
+    """A synthetic batch whose ground truth is a deterministic, smooth function of the INPUT, so that a network can actually learn it
+    (make_batch's ground truth is independent noise: training on it only drives the output to the mean).  Used for the RMSE gate at a
+    trained operating point (tests/test_gpu_trained.py, tools/train_synth_checkpoint.py):
+        z = gaussian_blur(0.8 ch0 - 0.5 ch1 + 0.3 ch2, sigma) scaled to unit variance,   depth = sigmoid(gain z)   in (0, 1)
+    -- the reference's inverse-normalised depth (src/data/dataloader.py:236-257).  Ground truth: 20 % of the pixels, min-pooled
+    half / quarter maps as in make_batch; radar channels at K ~ U{80..400} pixels carry the metric depth (1 - depth, i.e. d / 100 m)
+    consistent with the ground truth (lib/fuse_radar.py:185-197), channels 4-6 as in make_batch."""
+    from scipy.ndimage import gaussian_filter
+    rs = np.random.RandomState(seed)
+    x = np.zeros((B, 7, H, W), dtype=np.float32)
+    x[:, 0:3] = rs.standard_normal(size=(B, 3, H, W)).astype(np.float32)
+    mix = 0.8 * x[:, 0] - 0.5 * x[:, 1] + 0.3 * x[:, 2]
+    z = np.stack([gaussian_filter(mix[b], sigma=sigma, mode="reflect") for b in range(B)])
+    z = z * (2.0 * np.sqrt(np.pi) * sigma / np.sqrt(0.98))          # white noise of variance 0.98 blurred: variance 0.98 / (4 pi sigma^2)
+    depth = (1.0 / (1.0 + np.exp(-gain * z))).astype(np.float32)
+    depth = np.clip(depth, 0.01, 0.99)
+    f = 0.8 * W
+    for b in range(B):
+        k = int(rs.randint(80, 401))
+        k = min(k, H * W // 4)
+        rows = rs.randint(0, H, size=k)
+        cols = rs.randint(0, W, size=k)
+        x[b, 3, rows, cols] = 1.0 - depth[b, rows, cols]
+        x[b, 4, rows, cols] = ((cols - W / 2) / f + rs.normal(0, 0.01, size=k)).astype(np.float32)
+        x[b, 5, rows, cols] = ((rows - H / 2) / f + rs.normal(0, 0.01, size=k)).astype(np.float32)
+        x[b, 6, rows, cols] = (rs.uniform(size=k) < 0.15).astype(np.float32)
+    valid = rs.uniform(size=(B, 1, H, W)) < 0.2
+    gt = np.zeros((B, 1, H, W), dtype=np.float32)
+    gt[valid] = depth[:, None][valid]
+    gt_full = torch.from_numpy(gt)
+    gt_half = min_pool_ignore_zero(gt_full)
+    gt_quarter = min_pool_ignore_zero(gt_half)
+    return {"image": torch.from_numpy(x), "gt_full": gt_full, "gt_half": gt_half, "gt_quarter": gt_quarter,
+            "dense_depth": torch.from_numpy(depth[:, None].copy())}

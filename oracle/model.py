@@ -91,9 +91,13 @@ def block(sd, name, x, H, W, heads, sr, quant=None, drop_path=None, taps=None):
     """Block.forward (reference: simplified_attention.py:141-145). drop_path: [B] scaled mask or None."""
     C = x.shape[1]
     dp = (lambda t: t) if drop_path is None else (lambda t: t * drop_path.view(-1, 1, 1))
+    if taps is not None:
+        taps[name + ".in"] = x.detach()
     xn = _gn(x, sd, name + ".norm1", C // GN_DIV)
     x = x + dp(attention_maxpool(sd, name + ".attn", xn, H, W, heads, sr, quant, taps))
     x = x + dp(mlp(sd, name + ".mlp1", _gn(x, sd, name + ".norm2", C // GN_DIV), H, W, C, quant))
+    if taps is not None:
+        taps[name + ".out"] = x.detach()
     return x
 
 

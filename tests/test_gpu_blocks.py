@@ -1,0 +1,92 @@
+"""Teacher-forced per-Block parity at FULL depth and at the benchmark's frame size: every one of the 34 encoder
+Blocks (reference: Block.forward, src/models/simplified_attention.py:141-145) is run ALONE on the HIP path on the oracle's input
+of that block -- the fp32 residual stream the CPU oracle (bf16 mode) has at that depth -- and its output is compared with the
+oracle's output of the same block.  The whole-model comparisons (tests/test_gpu_model.py) are chaotic at full depth (the max-pool
+attention amplifies rounding noise through 34 blocks), so their bounds are loose; here nothing is amplified: a block whose
+arithmetic were wrong by a rounding point would stand out by an order of magnitude."""
+import numpy as np
+import pytest
+import torch
+
+from camradepth_amd import lib as L
+from camradepth_amd import synth
+from camradepth_amd.config import ModelConfig
+from tests.util import golden_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _pm(t):            # oracle [B, C, N] -> pixel-major [B, N, C]
+    return t.permute(0, 2, 1).contiguous()
+
+
+@pytest.mark.parametrize("persist", [False, True])
+def test_every_block_on_the_oracles_input_256x416(persist, monkeypatch):
+    from camradepth_amd.model import CamRaDepth
+    from oracle import model as om
+    monkeypatch.setenv("CRD_ENC_PERSIST", "1" if persist else "0")
+    cfg = ModelConfig.variant("base")
+    sd = golden_state_dict(cfg)
+    B, H, W = 2, 256, 416
+    x = synth.make_batch(B, H, W, seed=1234)["image"]
+    taps = {}
+    with torch.no_grad():
+        om.forward(sd, x, cfg, quant="bf16", taps=taps)
+    model = CamRaDepth(input_channels=7, depths=cfg.depths)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        model(x.cuda())                       # builds the plan, packs the weights
+    plan = model._plans[model._plan_key(x.cuda())]
+    lib = L.load()
+    if persist:
+        _persistent_stages(plan, taps, cfg)
+        return
+    out_err, upd_err = {}, {}
+    for name, blk in plan.block_ops.items():
+        xin, xout = _pm(taps[name + ".in"]).cuda(), _pm(taps[name + ".out"]).cuda()
+        X, X2 = blk["x"], blk["x2"]
+        plan.zf_arena.zero_()
+        X.t.copy_(xin.view_as(X.t))
+        if not blk["own_stats"]:              # the previous block's epilogue would have left the sums of this block's input
+            L.check(lib.crd_gn_stats(X.t.data_ptr(), X.f32, X.ld, X.coff, plan.B, X.P, X.C, blk["st1"].data_ptr(), blk["ch1"].data_ptr(),
+                                     L.stream()), "crd_gn_stats")
+        plan.run_ops(blk["ops"])
+        torch.cuda.synchronize()
+        got = X2.t.view_as(xout)
+        out_err[name] = rel(got, xout)
+        upd_err[name] = rel(got - xin, xout - xin)
+    worst_out, worst_upd = max(out_err.items(), key=lambda kv: kv[1]), max(upd_err.items(), key=lambda kv: kv[1])
+    print("worst block output rel-L2", worst_out, "worst block UPDATE rel-L2", worst_upd,
+          "median update", float(np.median(list(upd_err.values()))))
+    assert len(out_err) == 34
+    # measured: worst output 3.6e-3 (VERDICT r3 asked for <= 1e-2), worst UPDATE x_out - x_in (what the block computes: bf16 rounding
+    # of its two branches, a few arg-max flips) 9.4e-3, median 3.7e-3; bounds = 2x measured
+    assert worst_out[1] < 8e-3, worst_out
+    assert worst_upd[1] < 2e-2 and float(np.median(list(upd_err.values()))) < 8e-3, (worst_upd, sorted(upd_err.values())[-5:])
+
+
+def _persistent_stages(plan, taps, cfg):
+    """The same for the persistent stage kernel: a whole STAGE (all its blocks in one launch) on the oracle's stage input; compared
+    block by block through the saved x2 tensors would need a training plan, so the stage OUTPUT is compared -- drift over the 16 / 5
+    blocks of stages 3 / 4 included, hence the looser bound."""
+    ops = [op for op in plan.fwd if op.name == "crd_enc_stage_fwd"]
+    assert len(ops) == 2
+    for stage, op in zip((3, 4), ops):
+        names = [n for n in plan.block_ops if f"block{stage}." in n]
+        first, last = plan.block_ops[names[0]], plan.block_ops[names[-1]]
+        xin, xout = _pm(taps[names[0] + ".in"]).cuda(), _pm(taps[names[-1] + ".out"]).cuda()
+        first["x"].t.copy_(xin.view_as(first["x"].t))
+        plan.run_ops([op])
+        torch.cuda.synchronize()
+        for st in plan.enc_status:
+            assert int(st.item()) == 0
+        got = last["x2"].t.view_as(xout)
+        e_out, e_upd = rel(got, xout), rel(got - xin, xout - xin)
+        print(f"persistent stage {stage}: output rel-L2 {e_out:.4f}, update rel-L2 {e_upd:.4f}")
+        assert e_out < 2e-2 and e_upd < 2e-2, (stage, e_out, e_upd)          # measured 0.0098 / 0.0080 (drift over 16 / 5 blocks included)

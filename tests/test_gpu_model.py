@@ -29,7 +29,7 @@ pytestmark = pytest.mark.gpu
 # 5.09e-3; tests/golden/oracle_bf16_gap.json), so the north-star 1e-3 is below the bf16 floor of the reference's own arithmetic
 # with these weights and is asserted at the reference's initialisation instead
 # (test_rmse_within_1e3_of_fp32_oracle_at_reference_init).  Measured: rel-L2 0.0283 (other equivalent builds: 0.020-0.030), gap 8.2e-3.  Bounds: 2.5x the oracle's bf16 distance; RMSE gap 2 % of the RMSE.
-REL_L2_GOLDEN_256 = 0.047
+REL_L2_GOLDEN_256 = 0.047      # (round 4: 0.0186 = the oracle's own bf16 distance, after the depthwise weights got autocast's bf16 rounding)
 RMSE_GAP_GOLDEN_256 = 2e-2
 VARIANTS = ["base", "supervised_seg", "unsupervised_seg", "sup_unsup_seg"]
 
@@ -99,10 +99,14 @@ def _shallow_vs_oracle(variant, mode, B, H, W):
         e = rel(g, go)
         (score_errs if any(t in n for t in (".attn.q.", ".attn.k.", ".attn.sr.", ".attn.norm.")) else errs).append((e, n))
     med = float(np.median([e for e, _ in errs + score_errs]))
+    print(f"MEASURED shallow {variant} {mode} {B}x{H}x{W}: loss rel {abs(float(loss) - float(lo)) / abs(float(lo)):.2e} final {rel(out['depth']['final_depth'], o['depth']['final_depth']):.4f} "
+          f"grad median {med:.4f} worst {max(errs)[0]:.4f} score-worst {max(score_errs)[0]:.4f} p90 {float(np.percentile([e for e, _ in errs], 90)):.4f}")
     assert med < 0.08, f"median per-parameter gradient error {med}"
     worst = max(errs)
-    assert worst[0] < 0.5, f"gradient mismatch {worst}"
-    assert max(score_errs)[0] < 1.2, f"attention-score gradient mismatch {max(score_errs)}"
+    # bounds = 2x the worst value measured over the eleven parametrisations of this test (round 4: median <= 0.048, worst <= 0.18,
+    # attention-score parameters <= 0.34, 90th percentile <= 0.12)
+    assert worst[0] < 0.37, f"gradient mismatch {worst}"
+    assert max(score_errs)[0] < 0.7, f"attention-score gradient mismatch {max(score_errs)}"
     assert float(np.percentile([e for e, _ in errs], 90)) < 0.2
 
 
@@ -113,9 +117,10 @@ def test_full_model_eval_matches_reference_golden_64x96():
     batch = synth.make_batch(1, 64, 96, seed=1234)
     with torch.no_grad():
         out = model(batch["image"].cuda())
-    assert rel(out["depth"]["final_depth"], torch.from_numpy(g["eval_final_depth"])) < 0.1
-    assert rel(out["depth"]["intermediate_depths"][3], torch.from_numpy(g["eval_depth_half"])) < 0.1
-    assert rel(out["depth"]["intermediate_depths"][2], torch.from_numpy(g["eval_depth_quarter"])) < 0.15
+    r = [rel(out["depth"]["final_depth"], torch.from_numpy(g["eval_final_depth"])), rel(out["depth"]["intermediate_depths"][3], torch.from_numpy(g["eval_depth_half"])),
+         rel(out["depth"]["intermediate_depths"][2], torch.from_numpy(g["eval_depth_quarter"]))]
+    print("MEASURED 64x96 golden: final / half / quarter", r)
+    assert r[0] < 0.045 and r[1] < 0.03 and r[2] < 0.09          # 2x measured (0.0202 / 0.0136 / 0.0442)
 
 
 @pytest.mark.parametrize("variant", ["base", "supervised_seg"])
@@ -132,11 +137,16 @@ def test_full_model_256x416_matches_reference_golden(variant):
     assert out["depth"]["final_depth"].shape == (1, 1, 256, 416)
     # measured over repeated runs on MI355X: 0.010-0.026 vs the golden, 0.010-0.032 run-to-run (atomic summation order
     # amplified by the deliberately ill-conditioned golden weights); 4x margin
-    assert rel(out["depth"]["final_depth"], torch.from_numpy(g["final_depth"])) < 0.1
-    assert rel(out["depth"]["intermediate_depths"][2], torch.from_numpy(g["depth_quarter"])) < 0.15
-    assert abs(float(rmse) - float(g["loss"][5])) < 3e-2 * float(g["loss"][5])
+    r_f, r_q = rel(out["depth"]["final_depth"], torch.from_numpy(g["final_depth"])), rel(out["depth"]["intermediate_depths"][2], torch.from_numpy(g["depth_quarter"]))
+    print(f"MEASURED 256x416 golden {variant}: final {r_f:.4f} quarter {r_q:.4f} rmse gap {abs(float(rmse) - float(g['loss'][5])) / float(g['loss'][5]):.4f}")
+    # 2x measured (base 0.0186 -- other builds of the same arithmetic 0.020-0.030, see REL_L2_GOLDEN_256 --, supervised_seg 0.0558;
+    # quarter 0.0617 / 0.0327; RMSE gap 0.5 % / 1.0 % of the RMSE)
+    assert r_f < (0.06 if variant == "base" else 0.11)
+    assert r_q < 0.125
+    assert abs(float(rmse) - float(g["loss"][5])) < 2e-2 * float(g["loss"][5])
     if variant == "supervised_seg":
         am = out["seg"]["final_seg"].argmax(1).cpu().numpy().astype(np.uint8)
+        print("MEASURED seg arg-max mismatch", float((am != g["seg_argmax"]).mean()))
         assert (am != g["seg_argmax"]).mean() < 0.12
 
 
@@ -180,9 +190,9 @@ def test_seg_variants_256x416_match_reference_golden(variant):
     um = out["seg"]["unsup_map"].cpu().numpy()
     miss_u = float((np.abs(um - g["unsup_map"].astype(np.float32)) > 1e-3).mean())
     print(f"{variant} 256x416 vs reference: final {r_full:.4f} quarter {r_q:.4f} unsup-map mismatch {miss_u:.4f} rmse {rmse:.5f} / {float(g['rmse'][0]):.5f}")
-    assert r_full < 0.1 and r_q < 0.15
-    assert abs(rmse - float(g["rmse"][0])) < 3e-2 * float(g["rmse"][0])
-    assert miss_u < 0.25                    # arg-max over 5 near-tied logits of the ill-conditioned golden weights
+    assert r_full < 0.11 and r_q < 0.07          # measured 0.0566 / 0.0104 and 0.0327 / 0.0119
+    assert abs(rmse - float(g["rmse"][0])) < 2e-2 * float(g["rmse"][0])
+    assert miss_u < 0.17                    # arg-max over 5 near-tied logits of the ill-conditioned golden weights (measured 0.083 / 0.034)
     if cfg.supervised_seg:
         am = out["seg"]["final_seg"].argmax(1).cpu().numpy().astype(np.uint8)
         assert (am != g["seg_argmax"]).mean() < 0.2

@@ -3,7 +3,7 @@
 // :34-43, DWConv.forward :318-323, the stage loops of forward_features :265-306).  API and rationale: include/camradepth_hip.h
 // (crd_enc_stage_fwd).
 //
-// Decomposition.  A sample is owned by G = H / 2 workgroups of 16 waves; workgroup g keeps image rows 2g and 2g + 1 of the
+// Decomposition.  A sample is owned by G = H / RPW workgroups (RPW = 1 image row each while B x H <= 256, else 2); workgroup g keeps image rows RPW g .. RPW g + RPW - 1 of the
 // stage tensor in LDS for the whole launch:
 //   sX   fp32 [2W][C]        the residual stream x -> x1 -> x2 (updated in place)
 //   sXN  bf16 [.][C + 8]     Block.norm1(x), later Block.norm2(x1): the activation operand of q / sr / k / fc1
@@ -84,13 +84,15 @@ __device__ __forceinline__ void gather(Addr addr, int n, unsigned tag, unsigned 
   }
 }
 
-template <int C_, int HID_, int HEADS_, int SR_, int WSMAX_>
+template <int C_, int HID_, int HEADS_, int SR_, int WSMAX_, int RPW_>
 struct Cfg {
   static constexpr int C = C_, HID = HID_, HEADS = HEADS_, SR = SR_, WSMAX = WSMAX_;
+  static constexpr int RPW = RPW_;                       // image rows per workgroup: 2, or 1 when that still fits the chip (B x H <= 256)
   static constexpr int D = C / HEADS, DK = (D + 31) / 32;
-  static constexpr int NPXMAX = 2 * WSMAX, RTMAX = (NPXMAX + 15) / 16, MP = RTMAX * 16;
+  static constexpr int NPXMAX = RPW * WSMAX, RTMAX = (NPXMAX + 31) / 32 * 2, MP = RTMAX * 16;
+  static constexpr int XNROWS = (SR > 1 && RPW == 1) ? (2 * WSMAX + 15) / 16 * 16 : MP;   // RPW 1, sr 2: + the partner's row (sr convolution)
   static constexpr int MMAX = 104, KTMAX = 7, MKP = KTMAX * 16;
-  static constexpr int GMAX = 8;
+  static constexpr int GMAX = 16 / RPW;
   static constexpr int LDA = C + 8, LDH = HID + 8, HC = HID / 2, HLD = HC + 8;
   static constexpr int NG = C / 16, NGH = HID / 16, CG = C / 8, HG = HID / 8;
   static constexpr int KC = C / 32;                      // 16-wide k-steps per weight chunk: a chunk = C / 2 input channels
@@ -103,13 +105,15 @@ struct Cfg {
   // exchange areas (granules per workgroup)
   static constexpr int E0N = 2 * C;
   static constexpr int E1KEYS = (SR > 1 ? WSMAX / SR : NPXMAX) * (C / 2);
+  static constexpr int EXN = (SR > 1 && RPW == 1) ? WSMAX * (C / 2) : 0;      // the odd row's xn, handed to its even partner
   static constexpr int E1N = E1KEYS + (SR > 1 ? 2 * NG : 0);
   static constexpr int E2N = 2 * NG, E3N = 2 * NGH, E4N = 2 * NG;
   static constexpr int XE0 = 0, XE1 = XE0 + GMAX * E0N, XE2 = XE1 + GMAX * E1N, XE3 = XE2 + GMAX * E2N, XE4 = XE3 + GMAX * E3N;
-  static constexpr int AREA = XE4 + GMAX * E4N;          // granules per set
+  static constexpr int XEX = XE4 + GMAX * E4N;
+  static constexpr int AREA = XEX + GMAX * EXN;          // granules per set
   // LDS (bytes)
   static constexpr int OFF_X = 0, SZ_X = NPXMAX * C * 4;
-  static constexpr int OFF_XN = OFF_X + SZ_X, SZ_XN = MP * LDA * 2;
+  static constexpr int OFF_XN = OFF_X + SZ_X, SZ_XN = XNROWS * LDA * 2;
   static constexpr int OFF_U = OFF_XN + SZ_XN;
   static constexpr int OFF_Q = OFF_U, SZ_Q = MP * LDA * 2;
   static constexpr int OFF_K = OFF_Q + SZ_Q, SZ_K = MKP * LDA * 2;
@@ -133,7 +137,7 @@ struct Cfg {
   static constexpr int OFF_DEAD = OFF_REDW + SZ_REDW;
   static constexpr int OFF_DUMMY = OFF_DEAD + 16;            // 1 KB landing zone of the L2 warm-up requests
   static constexpr int TOTAL = OFF_DUMMY + 1024;
-  static_assert(SR == 1 || SR == 2, "two image rows per workgroup: sr 1 or 2");
+  static_assert((SR == 1 || SR == 2) && (RPW == 1 || RPW == 2), "one or two image rows per workgroup: sr 1 or 2");
   static_assert(SZ_HALO <= SZ_XN, "halo row A lives in the sXN region");
   static_assert(C * 2 * 8 <= SZ_TABH, "fixed-point channel sums alias sTabH");
   static_assert(TOTAL <= 160 * 1024, "LDS");
@@ -240,7 +244,7 @@ __device__ __forceinline__ long long fx_stat(unsigned bits) { return to_fx(__uin
 // A function of its own, NOT inlined: inside the stage kernel the register allocator spilled ~300 registers around this
 // loop nest whatever its shape (taps or pixels outermost, batches of 2 / 4 / 7 pixels, scheduling barriers); alone it needs ~110.
 typedef __attribute__((address_space(3))) bf16_t lds_bf16;
-template <int PJ, int LDH, int HLD>
+template <int PJ, int LDH, int HLD, int RPW>
 __device__ __attribute__((noinline)) float2 dw_stencil(lds_bf16* sHc, const lds_bf16* hA, const lds_bf16* hB, const bf16_t* w9c, int hid,
                                                        const float* bias, int W, int NPX, int pc, bf16_t* h2c) {
   float wf[9][8];          // unpacked once: 72 registers (this function has them), 8 operations per (pixel, tap) less
@@ -262,7 +266,7 @@ __device__ __attribute__((noinline)) float2 dw_stencil(lds_bf16* sHc, const lds_
   const unsigned aH = (unsigned)(uintptr_t)sHc, aA = (unsigned)(uintptr_t)hA, aB = (unsigned)(uintptr_t)hB;
   auto read9 = [&](int j, u32x4 (&u)[9]) {
     const int p = pc + 8 * j, pp = p < NPX ? p : 0;
-    const int ly = pp >= W ? 1 : 0, x = pp - ly * W;
+    const int ly = (RPW > 1 && pp >= W) ? 1 : 0, x = pp - ly * W;
     // per stencil row: base address and pixel stride by SELECTS between values that already exist (the opaque asm keeps the
     // compiler from sinking their computation into an if / else: written as one conditional expression per read this compiled
     // to an exec-mask branch diamond in front of every one of the 63 reads)
@@ -272,7 +276,7 @@ __device__ __attribute__((noinline)) float2 dw_stencil(lds_bf16* sHc, const lds_
       const int yy = ly + ky - 1;
       unsigned a3 = aH + (unsigned)(yy * W * LDH * 2), sA = (unsigned)(HLD * 2), sH_ = (unsigned)(LDH * 2);
       asm volatile("" : "+v"(a3), "+v"(sA), "+v"(sH_));
-      const bool up = yy < 0, dn = yy > 1;
+      const bool up = yy < 0, dn = yy > RPW - 1;
       radr[ky] = up ? aA : (dn ? aB : a3);
       rstr[ky] = (up || dn) ? sA : sH_;
     }
@@ -363,12 +367,18 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
   int t = tid, l = tid & 63;                 // re-derived from an opaque copy at the head of every phase (opq above)
 #define NEWPHASE() do { t = opq(tid); l = t & 63; } while (0)
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int W = a.W, H = a.H, G = H >> 1, NPX = 2 * W, N = H * W;
+  constexpr int RPW = CF::RPW;
+  const int W = a.W, H = a.H, G = H / RPW, NPX = RPW * W, N = H * W;
   const int RT = (NPX + 15) >> 4;
   const int set = blockIdx.x % a.nsets, g = blockIdx.x / a.nsets;
-  const int KPW = SR > 1 ? W / SR : NPX;                  // keys produced by this workgroup
-  const int M = G * KPW, KT = (M + 15) >> 4;
-  const int E1S = KPW * (C / 2) + (SR > 1 ? 2 * NG : 0);  // granules per workgroup in E1
+  // keys: with sr > 1 a key row needs SR image rows -- the workgroup holding the first of them produces it ("publisher"; with one
+  // image row per workgroup its partner hands over its xn row first); without sr every workgroup's pixels are its keys
+  const int KPW = SR > 1 ? W / SR : NPX;                  // keys per publishing workgroup
+  const bool kpub = SR > 1 ? (g * RPW) % SR == 0 : true;
+  const int krow0 = SR > 1 ? (g * RPW / SR) * KPW : g * NPX;        // first key of this workgroup (publishers)
+  const int M = SR > 1 ? (H / SR) * KPW : H * W, KT = (M + 15) >> 4;
+  const int E1S = KPW * (C / 2) + (SR > 1 ? 2 * NG : 0);  // granules per workgroup slot in E1
+  auto kslot = [&](int m, int& j) { const int jy = m / KPW; j = m - jy * KPW; return SR > 1 ? jy * SR / RPW : jy; };   // key -> (slot, index)
   gu64* const xa = (gu64*)a.ws + EPOCH_WORDS + (long long)set * CF::AREA;
   unsigned seq = (unsigned)__hip_atomic_load((gu64*)a.ws + set, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid == 0) *sDead = 0;
@@ -479,13 +489,36 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
           if (gdst) *reinterpret_cast<u32x4*>(gdst + (rowbase + p) * C + cg * 8) = o;
         }
       };
+      const unsigned tagE1 = ++seq;
       normalise_to_xn(reinterpret_cast<bf16_t*>(d->xn));
+      if constexpr (SR > 1 && RPW == 1) {
+        // one image row per workgroup: the sr convolution's second row belongs to the partner -- the odd workgroup hands its xn row
+        // over (XEX), the even one takes it into sXN rows [W, 2W)
+        NEWPHASE();
+        constexpr int NXH = (CF::WSMAX * (C / 2) + NT - 1) / NT;
+        if (!kpub) {
+          __syncthreads();                       // (own sXN rows complete)
+          for (int i = t; i < W * (C / 2); i += NT) {
+            const int p = i / (C / 2), cp = i - p * (C / 2);
+            pub(xa + CF::XEX + g * CF::EXN + i, tagE1, *reinterpret_cast<const unsigned*>(sXN + p * LDA + 2 * cp));
+          }
+        } else {
+          unsigned xv[NXH];
+          const int ntot = W * (C / 2);
+          const int nmine = t < ntot ? (ntot - t + NT - 1) / NT : 0;
+          gather<NXH>([&](int k) { return xa + CF::XEX + (g + 1) * CF::EXN + t + k * NT; }, nmine, tagE1, xv, sDead, a.status);
+#pragma unroll
+          for (int k = 0; k < NXH; ++k) {
+            const int e = t + k * NT;
+            if (e < ntot) { const int p = e / (C / 2), cp = e - p * (C / 2); *reinterpret_cast<unsigned*>(sXN + (W + p) * LDA + 2 * cp) = xv[k]; }
+          }
+        }
+      }
       __syncthreads();
       ENC_STAMP(2);
 
       // ================= q (own pixels) and the key path's first GEMM =================
       NEWPHASE();
-      const unsigned tagE1 = ++seq;
       constexpr int RT32MAX = CF::RT32;
       const int RT32 = (NPX + 31) >> 5;
       wg_gemm<KC, 2>(reinterpret_cast<const bf16_t*>(d->wq), C / 16, C / 32, RT32, pv + CF::V_BQ, wv, l,
@@ -496,7 +529,8 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
                        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + 8 * q) = packq(acc, q);
                      });
       if constexpr (SR > 1) {
-        // kr[j][co] = bf16(sum_{tap, ci} Wsr[co][tap][ci] * xn[pixel(j, tap)][ci] + b): one key row per workgroup (keys on the columns)
+        // kr[j][co] = bf16(sum_{tap, ci} Wsr[co][tap][ci] * xn[pixel(j, tap)][ci] + b): one key row per publisher (keys on the columns)
+        if (kpub)
         wg_gemm<KC, 2 * SR * SR, NW - 3>(reinterpret_cast<const bf16_t*>(d->wsr), SR * SR * C / 16, C / 32, 1, pv + CF::V_BSR, wv, l,
             [&](int, int ch, int k, int l) {
               const int tap = ch >> 1;
@@ -514,7 +548,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
                   gu64* dst = xa + CF::XE1 + g * E1S + j * (C / 2) + ((c0 + 8 * q) >> 1);
                   pub(dst, tagE1, pk.x);
                   pub(dst + 1, tagE1, pk.y);
-                  if (d->kr) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d->kr) + ((long long)b * M + g * KPW + j) * C + c0 + 8 * q) = pk;
+                  if (d->kr) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(d->kr) + ((long long)b * M + krow0 + j) * C + c0 + 8 * q) = pk;
                   const float v0 = bf_lo(pk.x), v1 = bf_hi(pk.x), v2 = bf_lo(pk.y), v3 = bf_hi(pk.y);
                   s[q >> 1] += (v0 + v1) + (v2 + v3);
                   ss[q >> 1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
@@ -579,10 +613,11 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
       if constexpr (SR > 1) {
         if (t < 2 * NG) {
           unsigned v[CF::GMAX];
-          gather<CF::GMAX>([&](int k) { return xa + CF::XE1 + k * E1S + KPW * (C / 2) + t; }, G, tagE1, v, sDead, a.status);
+          const int npub = H / SR;
+          gather<CF::GMAX>([&](int k) { return xa + CF::XE1 + (k * SR / RPW) * E1S + KPW * (C / 2) + t; }, npub, tagE1, v, sDead, a.status);
           long long tot = 0;
 #pragma unroll
-          for (int k = 0; k < CF::GMAX; ++k) tot += k < G ? fx_stat(v[k]) : 0ll;
+          for (int k = 0; k < CF::GMAX; ++k) tot += k < npub ? fx_stat(v[k]) : 0ll;
           sFxG[t] = tot;
           if (g == 0 && d->stk) d->stk[(long long)b * NG * 2 + t] = tot;
         }
@@ -591,7 +626,8 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
         const int nmine = t < ntot ? (ntot - t + NT - 1) / NT : 0;
         gather<NK1>([&](int k) {
           const int e = t + k * NT, m = e / (C / 2), cp = e - m * (C / 2);
-          const int sw = m / KPW, j = m - sw * KPW;
+          int j;
+          const int sw = kslot(m, j);
           return xa + CF::XE1 + sw * E1S + j * (C / 2) + cp;
         }, nmine, tagE1, kv, sDead, a.status);
         __syncthreads();
@@ -612,11 +648,11 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
           }
         }
         __syncthreads();
-        if (d->krn) {
+        if (d->krn && kpub) {
           for (int i = t; i < KPW * CG; i += NT) {
             const int j = i / CG, cg = i - j * CG;
-            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d->krn) + ((long long)b * M + g * KPW + j) * C + cg * 8) =
-                *reinterpret_cast<const u32x4*>(sKRN + (g * KPW + j) * LDA + cg * 8);
+            *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d->krn) + ((long long)b * M + krow0 + j) * C + cg * 8) =
+                *reinterpret_cast<const u32x4*>(sKRN + (krow0 + j) * LDA + cg * 8);
           }
         }
         // k = bf16(Wk * krn + bk) for ALL keys (every workgroup: 5 MFLOP, cheaper than another exchange)
@@ -637,7 +673,8 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
         const int nmine = t < ntot ? (ntot - t + NT - 1) / NT : 0;
         gather<NK1>([&](int k) {
           const int e = t + k * NT, m = e / (C / 2), cp = e - m * (C / 2);
-          const int sw = m / KPW, j = m - sw * KPW;
+          int j;
+          const int sw = kslot(m, j);
           return xa + CF::XE1 + sw * E1S + j * (C / 2) + cp;
         }, nmine, tagE1, kv, sDead, a.status);
 #pragma unroll
@@ -647,11 +684,11 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
         }
         __syncthreads();
       }
-      if (d->k) {
+      if (d->k && kpub) {
         for (int i = t; i < KPW * CG; i += NT) {
           const int j = i / CG, cg = i - j * CG;
-          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d->k) + ((long long)b * M + g * KPW + j) * C + cg * 8) =
-              *reinterpret_cast<const u32x4*>(sK + (g * KPW + j) * LDA + cg * 8);
+          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(d->k) + ((long long)b * M + krow0 + j) * C + cg * 8) =
+              *reinterpret_cast<const u32x4*>(sK + (krow0 + j) * LDA + cg * 8);
         }
       }
 
@@ -825,7 +862,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
       }
       __syncthreads();
       // Every workgroup of the sample has published: its h1 rows are in memory.  The stencil's neighbour rows (image rows
-      // 2g - 1 and 2g + 2, both rounds) are requested NOW, with agent-scope loads, and land while the statistics are finished.
+      // RPW g - 1 and RPW g + RPW, both rounds) are requested NOW, with agent-scope loads, and land while the statistics are finished.
       constexpr int CGR = HC / 8;                                            // channel granules per round
       constexpr int HLR = (2 * CF::WSMAX * CGR + NT - 1) / NT;               // neighbour-row granules per thread and round
       u32x4 hal[2][HLR];
@@ -837,7 +874,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
           for (int k = 0; k < HLR; ++k) {
             const int i = t + k * NT;
             const int hr = i / (W * CGR), rem = i - hr * (W * CGR), x = rem / CGR, cgl = rem - x * CGR;
-            const int gy = hr ? 2 * g + 2 : 2 * g - 1;
+            const int gy = hr ? RPW * g + RPW : RPW * g - 1;
             const bool ok = i < 2 * W * CGR && gy >= 0 && gy < H;
             hal[r][k] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (unsigned)(((gy * W + x) * HID + r * HC + cgl * 8) * 2) : 0u, 0, 16);
           }
@@ -877,7 +914,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
             const int i = t + k * NT;
             if (i < 2 * W * CGR) {
               const int hr = i / (W * CGR), rem = i - hr * (W * CGR), x = rem / CGR, cl = rem - x * CGR;
-              const int gy = hr ? 2 * g + 2 : 2 * g - 1;
+              const int gy = hr ? RPW * g + RPW : RPW * g - 1;
               u32x4 u = norm8(hal[r][k], r * HC + cl * 8);
               if (gy < 0 || gy >= H) u = u32x4{0u, 0u, 0u, 0u};
               *reinterpret_cast<u32x4*>((hr ? sHaloB : sHaloA) + x * HLD + cl * 8) = u;
@@ -894,7 +931,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
           float s = 0.f, ss = 0.f;
           if (act) {
             constexpr int PJ = (CF::NPXMAX + 7) / 8;
-            const float2 r2 = dw_stencil<PJ, LDH, HLD>(
+            const float2 r2 = dw_stencil<PJ, LDH, HLD, CF::RPW>(
                 (lds_bf16*)(sH + c0), (const lds_bf16*)(sHaloA + cgl * 8), (const lds_bf16*)(sHaloB + cgl * 8),
                 reinterpret_cast<const bf16_t*>(d->w9b) + c0, HID, pv + CF::V_BDW + c0, W, NPX, pc,
                 d->h2 ? reinterpret_cast<bf16_t*>(d->h2) + rowbase * HID + c0 : nullptr);
@@ -1001,14 +1038,20 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
   if (g == 0 && tid == 0) __hip_atomic_store((gu64*)a.ws + set, (unsigned long long)seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-using Cfg3 = Cfg<160, 640, 4, 2, 26>;
-using Cfg4 = Cfg<256, 1024, 8, 1, 13>;
+template <int RPW> using Cfg3 = Cfg<160, 640, 4, 2, 26, RPW>;
+template <int RPW> using Cfg4 = Cfg<256, 1024, 8, 1, 13, RPW>;
 
 template <class CF>
 int sets_for(int B, int G) {
   int cap = 256 / G;                       // one workgroup per CU, all resident
   if (cap >= 8) cap = cap / 8 * 8;         // a multiple of the XCD count keeps a sample on one XCD
   return B < cap ? B : cap;
+}
+
+// image rows per workgroup: one while the whole batch still fits the chip that way (a workgroup per CU), else two
+int rows_per_wg(int B, int H, int want) {
+  if (want == 1 || want == 2) return want;
+  return B * H <= 256 ? 1 : 2;
 }
 
 int stage_kind(int H, int W, int C, int hid, int heads, int sr) {
@@ -1028,7 +1071,7 @@ int launch_stage(const crd_enc_stage_desc* d, hipStream_t st) {
   EncK k;
   k.x = d->x; k.blocks = d->blocks; k.nblocks = d->nblocks; k.B = d->B; k.H = d->H; k.W = d->W;
   k.xb_out = reinterpret_cast<bf16_t*>(d->xb_out); k.ws = reinterpret_cast<unsigned long long*>(d->sync_ws); k.status = d->status;
-  const int G = d->H / 2;
+  const int G = d->H / CF::RPW;
   k.nsets = sets_for<CF>(d->B, G);
   k.scale = (float)pow((double)CF::D, -0.5);      // head_dim ** -0.5 (simplified_attention.py:54)
   hipLaunchKernelGGL((k_enc_stage<CF>), dim3(k.nsets * G), dim3(NT), CF::TOTAL, st, k);
@@ -1075,16 +1118,20 @@ extern "C" int crd_pack_frag32(const crd_frag_entry* table_dev, int32_t n, int64
 
 extern "C" int crd_enc_stage_supported(int32_t B, int32_t H, int32_t W, int32_t C, int32_t hidden, int32_t heads, int32_t sr) {
   if (B < 1) return 0;
-  return stage_kind(H, W, C, hidden, heads, sr) ? H / 2 : 0;
+  return stage_kind(H, W, C, hidden, heads, sr) ? H / rows_per_wg(B, H, 0) : 0;
 }
 
 extern "C" int crd_enc_stage_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t hidden, int32_t heads, int32_t sr) {
   const int kind = stage_kind(H, W, C, hidden, heads, sr);
   if (!kind || B < 1) return 0;
-  const int G = H / 2;
-  const long long area = kind == 3 ? Cfg3::AREA : Cfg4::AREA;
-  const int sets = kind == 3 ? sets_for<Cfg3>(B, G) : sets_for<Cfg4>(B, G);
-  return (int)((EPOCH_WORDS + (long long)sets * area) * 8);
+  long long need = 0;                        // (either choice of rows per workgroup fits)
+  for (int rpw = 1; rpw <= 2; ++rpw) {
+    const int G = H / rpw;
+    const long long area = kind == 3 ? (rpw == 1 ? Cfg3<1>::AREA : Cfg3<2>::AREA) : (rpw == 1 ? Cfg4<1>::AREA : Cfg4<2>::AREA);
+    const long long sets = sets_for<void>(B, G);
+    if (sets * area > need) need = sets * area;
+  }
+  return (int)((EPOCH_WORDS + need) * 8);
 }
 
 extern "C" int crd_enc_stage_fwd(const crd_enc_stage_desc* d, crd_stream_t stream) {
@@ -1092,7 +1139,11 @@ extern "C" int crd_enc_stage_fwd(const crd_enc_stage_desc* d, crd_stream_t strea
   const int kind = stage_kind(d->H, d->W, d->C, d->hidden, d->heads, d->sr);
   CRD_UNSUPPORTED(kind != 0 && d->B >= 1, "crd_enc_stage_fwd: shape not covered (H %d W %d C %d hidden %d heads %d sr %d): see crd_enc_stage_supported",
                   d->H, d->W, d->C, d->hidden, d->heads, d->sr);
-  const int rc = kind == 3 ? launch_stage<Cfg3>(d, as_stream(stream)) : launch_stage<Cfg4>(d, as_stream(stream));
+  CRD_CHECK_ARG(d->rows_per_wg >= 0 && d->rows_per_wg <= 2, "crd_enc_stage_fwd: rows_per_wg must be 0 (choose), 1 or 2");
+  const int rpw = rows_per_wg(d->B, d->H, d->rows_per_wg);
+  hipStream_t st = as_stream(stream);
+  const int rc = kind == 3 ? (rpw == 1 ? launch_stage<Cfg3<1>>(d, st) : launch_stage<Cfg3<2>>(d, st))
+                           : (rpw == 1 ? launch_stage<Cfg4<1>>(d, st) : launch_stage<Cfg4<2>>(d, st));
   if (rc != 0) return rc;
   CRD_LAUNCH_CHECK("crd_enc_stage_fwd");
   return CRD_OK;

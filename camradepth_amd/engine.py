@@ -68,6 +68,9 @@ GN_CONV_MAXROWS = int(os.environ.get("CRD_GN_CONV_MAXROWS", str(1 << 30)))   # p
 # (stages 3 and 4 at 256 x 416).  Round 4: correct, bit-reproducible and graph-safe (tests/test_gpu_enc_stage.py), but NOT yet faster
 # than the per-launch path at B = 8 -- 87 / 85 us per Block at stages 3 / 4 against 80 / 63 us (profiles/r04_enc_stage_phases.txt;
 # DESIGN section 4 "Round 4" says where the time goes) -- so it is opt-in: CRD_ENC_PERSIST=1.
+ENC_ROWS_PER_WG = 0       # image rows per workgroup of the persistent stage kernel: 0 = the library chooses (tests force 1 / 2)
+
+
 def enc_persist_default():
     return os.environ.get("CRD_ENC_PERSIST", "0") == "1"
 
@@ -462,6 +465,7 @@ class Plan:
             d.x, d.blocks, d.nblocks = PP(sp["x"]), table.data_ptr(), len(sp["blocks"])
             d.B, d.H, d.W, d.C, d.hidden, d.heads, d.sr = sp["dims"]
             d.xb_out, d.sync_ws, d.status = PP(sp["xb"]), sp["ws"].data_ptr(), sp["status"].data_ptr()
+            d.rows_per_wg = ENC_ROWS_PER_WG
             self.keep.append(d)
             return C.byref(d)
         if sp.get("mlp"):

@@ -87,7 +87,7 @@ class FragEntry(C.Structure):
 class EncStageDesc(C.Structure):
     _fields_ = [("x", C.c_void_p), ("blocks", C.c_void_p)] + \
                [(n, C.c_int32) for n in ("nblocks", "B", "H", "W", "C", "hidden", "heads", "sr")] + \
-               [("xb_out", C.c_void_p), ("sync_ws", C.c_void_p), ("status", C.c_void_p)]
+               [("xb_out", C.c_void_p), ("sync_ws", C.c_void_p), ("status", C.c_void_p), ("rows_per_wg", C.c_int32)]
 
 
 class UnpackEntry(C.Structure):

@@ -248,11 +248,12 @@ class CamRaDepth(nn.Module):
 
     def _plan_key(self, x):
         frozen = tuple(i for i, n in enumerate(self._names) if not self._param(n).requires_grad)
+        from . import engine
         from .engine import enc_persist_default, gn_conv_default
         f8 = getattr(self, "fp8_scales", None)
         return (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None), frozen,
                 bool(getattr(self, "_need_grad", True)), gn_conv_default(), tuple(sorted(f8.items())) if f8 else None,
-                bool(getattr(self, "fp8_train", False)), enc_persist_default())
+                bool(getattr(self, "fp8_train", False)), enc_persist_default(), engine.ENC_ROWS_PER_WG)
 
     def calibrate_fp8(self, x, margin=1.0, train=False):
         """Per-stage activation scales for the fp8 (e4m3) inference path of the two largest decoder stages (their ConvLayers are

@@ -578,6 +578,7 @@ typedef struct {
   void* xb_out;                         /* optional bf16 copy of the last block's x2 */
   void* sync_ws;                        /* crd_enc_stage_ws_bytes() bytes, zeroed ONCE by the caller (never again: tags carry an epoch) */
   int32_t* status;                      /* device word, zeroed by the caller; set non-zero if a workgroup gave up waiting */
+  int32_t rows_per_wg;                  /* image rows per workgroup: 1, 2, or 0 = choose (1 while B * H <= 256: a workgroup per CU) */
 } crd_enc_stage_desc;
 /* workgroups per sample (> 0) when the persistent kernel covers the shape, else 0: (C, hidden, heads, sr) = (160, 640, 4, 2)
  * with W <= 26, or (256, 1024, 8, 1) with W <= 13; H even, H*W/sr^2 <= 104, W % sr == 0 */

@@ -69,7 +69,7 @@ def test_struct_layouts_match_header(built, tmp_path):
               "crd_unpack_entry": (built.UnpackEntry, ["src", "cmap", "Cin_pad", "replicas", "replica_stride"]),
               "crd_wgrad_group_info": (built.WgradGroupInfo, ["n_problems", "n_items", "item_offset", "bytes"]),
               "crd_enc_block_desc": (built.EncBlockDesc, ["wq", "w9b", "vec", "dp", "pf_ptr", "pf_bytes", "st1", "krn", "idx", "h1", "x2"]),
-              "crd_enc_stage_desc": (built.EncStageDesc, ["x", "blocks", "nblocks", "sr", "xb_out", "sync_ws", "status"])}
+              "crd_enc_stage_desc": (built.EncStageDesc, ["x", "blocks", "nblocks", "sr", "xb_out", "sync_ws", "status", "rows_per_wg"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/camradepth_hip.h"', "int main(void){"]
     for cname, (_, fl) in fields.items():
         src.append(f'printf("{cname} %zu", sizeof({cname}));')
@@ -125,7 +125,9 @@ def test_module_parameter_inventory_and_flat_views():
 def test_persistent_stage_host_checks_without_a_gpu(built):
     """crd_enc_stage_supported / _ws_bytes are host-only; crd_enc_stage_fwd rejects unsupported shapes before any launch."""
     L = built.load()
-    assert L.crd_enc_stage_supported(8, 16, 26, 160, 640, 4, 2) == 8 and L.crd_enc_stage_supported(8, 8, 13, 256, 1024, 8, 1) == 4
+    # workgroups per sample: one image row each while B x H <= 256 (a workgroup per CU), else two rows each
+    assert L.crd_enc_stage_supported(8, 16, 26, 160, 640, 4, 2) == 16 and L.crd_enc_stage_supported(8, 8, 13, 256, 1024, 8, 1) == 8
+    assert L.crd_enc_stage_supported(32, 16, 26, 160, 640, 4, 2) == 8 and L.crd_enc_stage_supported(64, 8, 13, 256, 1024, 8, 1) == 4
     assert L.crd_enc_stage_supported(8, 32, 52, 128, 1024, 2, 4) == 0 and L.crd_enc_stage_supported(8, 13, 25, 256, 1024, 8, 1) == 0
     assert L.crd_enc_stage_ws_bytes(8, 16, 26, 160, 640, 4, 2) > 0 and L.crd_enc_stage_ws_bytes(8, 13, 25, 256, 1024, 8, 1) == 0
     d = built.EncStageDesc()

@@ -52,10 +52,18 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
+@pytest.fixture(params=[1, 2], ids=["rows1", "rows2"])
+def rows_per_wg(request, monkeypatch):
+    """Both decompositions of the persistent kernel (one / two image rows per workgroup; the library would choose by B x H)."""
+    from camradepth_amd import engine
+    monkeypatch.setattr(engine, "ENC_ROWS_PER_WG", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("train", [False, True])
 @pytest.mark.parametrize("B,H,W,depths", [(2, 256, 416, (1, 1, 2, 2)), (8, 256, 416, (1, 1, 3, 2)), (3, 64, 96, (1, 1, 2, 1)),
                                            (1, 128, 192, (1, 1, 1, 2))])
-def test_persistent_stage_matches_per_launch_path(B, H, W, depths, train):
+def test_persistent_stage_matches_per_launch_path(B, H, W, depths, train, rows_per_wg):
     cfg = dataclasses.replace(ModelConfig.variant("base"), depths=depths)
     sd = synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0)
     model = build(cfg, sd, train)
@@ -98,13 +106,13 @@ def test_persistent_stage_matches_per_launch_path(B, H, W, depths, train):
     assert rel(out1["depth"]["final_depth"], out0["depth"]["final_depth"]) < 2e-2
 
 
-def test_persistent_stage_is_bit_reproducible_and_graph_safe(monkeypatch):
+def test_persistent_stage_is_bit_reproducible_and_graph_safe(monkeypatch, rows_per_wg):
     """Two eager runs and a graph replay of the full-depth stages give identical bits (fixed-order sums, epoch tags that survive
     replays without any re-initialisation)."""
     cfg = ModelConfig.variant("base")
     sd = synth.fill_state_dict({n: s for n, s in param_specs(cfg)}, 0)
     model = build(cfg, sd, False)
-    x = synth.make_batch(8, 256, 416, seed=5)["image"].cuda()
+    x = synth.make_batch(8, 256, 416, seed=5)["image"].cuda()          # (B x H = 128 at stage 3: the library's own choice is one row)
     monkeypatch.setenv("CRD_ENC_PERSIST", "1")
     with torch.no_grad():
         a = model(x)["depth"]["final_depth"].clone()
@@ -121,7 +129,7 @@ def test_persistent_stage_is_bit_reproducible_and_graph_safe(monkeypatch):
     assert torch.equal(a, b) and torch.equal(c, d) and torch.equal(a, c)
 
 
-def test_persistent_stage_vs_oracle(monkeypatch):
+def test_persistent_stage_vs_oracle(monkeypatch, rows_per_wg):
     """The whole model with stages 3-4 on the persistent kernel against the CPU oracle (bf16 mode), forward and every parameter
     gradient, shallow depths, train mode with injected masks (the bounds of tests/test_gpu_model.py::_shallow_vs_oracle)."""
     monkeypatch.setenv("CRD_ENC_PERSIST", "1")

@@ -39,9 +39,12 @@ def time_slice(plan, a, b, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3, len(ops)
 
 
+from camradepth_amd import engine
+
 for train in (False, True):
-    for persist in ("0", "1"):
+    for persist, rpw in (("0", 0), ("1", 2), ("1", 1)):
         os.environ["CRD_ENC_PERSIST"] = persist
+        engine.ENC_ROWS_PER_WG = rpw
         m = CamRaDepth(input_channels=cfg.input_channels, depths=cfg.depths)
         m.load_state_dict(sd)
         m = m.cuda().train(train)
@@ -55,7 +58,7 @@ for train in (False, True):
         for i in range(4):
             us, n = time_slice(plan, marks[names[i]], marks[names[i + 1]])
             row.append(f"stage{i + 1} {us:8.1f} us ({n:3d} launches)")
-        print(f"train={int(train)} persist={persist}  " + "  ".join(row), flush=True)
+        print(f"train={int(train)} persist={persist} rows/wg={rpw}  " + "  ".join(row), flush=True)
         for stt in plan.enc_status:
             assert int(stt.item()) == 0, "persistent stage timed out"
 
@@ -69,6 +72,7 @@ if hasattr(lib, "crd_dbg_enc_prof"):
              "  L2 warm-up issue", "  E0 gather", "  dw r0: stage halo + norm", "  dw r0: stencil", "  dw r0: reduce + barrier",
              "  dw r1: stage halo + norm", "  dw r1: stencil", "  dw r1: reduce + barrier"]
     os.environ["CRD_ENC_PERSIST"] = "1"
+    engine.ENC_ROWS_PER_WG = int(os.environ.get("PROF_ROWS", "0"))
     for train in (False, True):
         m = CamRaDepth(input_channels=cfg.input_channels, depths=cfg.depths)
         m.load_state_dict(sd)

@@ -36,6 +36,16 @@ void crd_set_error(const char* fmt, ...);
 // CRD_LAUNCH_CHECK that follows the launch, by kernel name and size, instead of surfacing as an opaque "invalid argument" launch failure.
 void crd_note_attr_failure(const char* kernel, int bytes, int hip_err);
 int crd_report_attr_failure(const char* entry_point);      // 1 if a refusal was pending: crd_last_error() is set
+// Tuning knobs whose verdict is recorded in DESIGN.md are CONSTANTS in the product build; a developer build (-DCRD_DEV_SWITCHES, e.g.
+// CRD_EXTRA_FLAGS=-DCRD_DEV_SWITCHES python -m camradepth_amd.build) reads them from the environment again, for tools/sweep_knobs.sh
+// and the ablation scripts under tools/.
+#ifdef CRD_DEV_SWITCHES
+#include <stdlib.h>
+static inline int crd_dev_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+#else
+static inline int crd_dev_int(const char*, int dflt) { return dflt; }
+#endif
+
 static inline void crd_reserve_lds(const void* fn, int bytes, const char* kernel) {
   const hipError_t e_ = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
   if (e_ != hipSuccess) crd_note_attr_failure(kernel, bytes, (int)e_);

@@ -349,7 +349,7 @@ int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_ca
       // how the ragged tail of a data gradient is cut (CRD_C3P_SPLIT, developer switch: 0 = 128-wide tiles + the two-workgroup
       // kernel for the tail; bits 1 / 2 below: 365.7 -> 354.8 us and 594 -> 584 us on the 256 x 416 level, 3.74 ms -> 3.71 ms per step)
       static int split_mode = -1;
-      if (split_mode < 0) { const char* e = getenv("CRD_C3P_SPLIT"); split_mode = e ? atoi(e) : 3; }
+      if (split_mode < 0) split_mode = crd_dev_int("CRD_C3P_SPLIT", 3);
       if (rest == 0 || rest > 64) rc = crd_conv3x3p(k, B, st, 0, N, 4);
       else if ((split_mode & 1) && full == 128) {    // 136 / 144 columns: 96 + 40 / 48 on the persistent kernel's 96- and 64-wide tiles
         rc = crd_conv3x3p(k, B, st, 0, 96, 3);
@@ -371,7 +371,7 @@ int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_ca
     return crd_conv3x3p_finalize(k, B, st);
   }
   {   // grids that leave most CUs without a workgroup (the 32x52 decoder level: 64 pixel tiles): narrower column tiles
-    if (g_small_thr < 0) { const char* e = getenv("CRD_CONV3_SMALL"); g_small_thr = e ? atoi(e) : 512; }
+    if (g_small_thr < 0) g_small_thr = crd_dev_int("CRD_CONV3_SMALL", 512);
     const int thr = g_small_thr;
     const long long tiles = (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * B;
     if (tiles * cdiv(k.Cout, 128) < thr && k.Cout > 32) {

@@ -406,7 +406,7 @@ int launch_p(const ConvK& k0, int B, hipStream_t st, int col0, int col1) {
 // rows of GroupNorm partial sums a launch writes per image (crd_conv_desc.stats_partial must hold B x rows x Cout/16 x 2 floats)
 int waves_per_wg() {
   static int nw = -1;
-  if (nw < 0) { const char* e = getenv("CRD_CONV3P_WAVES"); nw = (e && atoi(e) == 4) ? 4 : 8; }
+  if (nw < 0) nw = crd_dev_int("CRD_CONV3P_WAVES", 8) == 4 ? 4 : 8;
   return nw;
 }
 inline long long partial_rows(const ConvK& k) { return (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * waves_per_wg(); }
@@ -417,7 +417,7 @@ inline long long partial_rows(const ConvK& k) { return (long long)cdiv(k.IW, TW)
 // grids with enough 16 x 32 tiles to occupy the chip.
 bool crd_conv3x3p_applicable(const ConvK& k, int B) {
   static int on = -1;
-  if (on < 0) { const char* e = getenv("CRD_CONV3P"); on = e ? atoi(e) : 1; }
+  if (on < 0) { const char* e = getenv("CRD_CONV3P"); on = e ? atoi(e) : 1; }     // (a product switch: tests/test_gpu_igemm.py compares both kernels)
   if (!on) return false;
   const long long tiles = (long long)cdiv(k.IW, TW) * cdiv(k.IH, TH) * B;
   return !k.y_f32 && !k.bias && !k.act && !k.res && k.out_mode == 0 && k.vec_ok && (k.y_ld & 7) == 0 && (k.Cout & 7) == 0 &&

@@ -528,6 +528,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
 #pragma unroll
                        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + 8 * q) = packq(acc, q);
                      });
+      ENC_STAMP(25);
       if constexpr (SR > 1) {
         // kr[j][co] = bf16(sum_{tap, ci} Wsr[co][tap][ci] * xn[pixel(j, tap)][ci] + b): one key row per publisher (keys on the columns)
         if (kpub)
@@ -576,6 +577,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
               }
             });
       }
+      ENC_STAMP(26);
       NEWPHASE();
       // ---- u = Wp * xbar in fp64 (per-sample vectors broadcast over every pixel: their rounding error is coherent, see
       // k_attn_xbar_proj), while the other workgroups' keys arrive.  Thread = (row, quarter of the columns).
@@ -648,6 +650,7 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
           }
         }
         __syncthreads();
+        ENC_STAMP(27);
         if (d->krn && kpub) {
           for (int i = t; i < KPW * CG; i += NT) {
             const int j = i / CG, cg = i - j * CG;

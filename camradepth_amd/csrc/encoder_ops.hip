@@ -862,7 +862,7 @@ __global__ __launch_bounds__(TPB) void k_gsum_to_bf16(const crd_sum_t* src, bf16
 // 112 instead of 128 -- but the 32-wide tiles are faster there: 19.56 -> 19.48 ms per step.)  CRD_DW_TW (developer switch) forces one.
 static int dw_tile_width(int W) {
   static int forced = -1;
-  if (forced < 0) { const char* e = getenv("CRD_DW_TW"); forced = e ? atoi(e) : 0; }
+  if (forced < 0) forced = crd_dev_int("CRD_DW_TW", 0);
   if (forced == 16 || forced == 32) return forced;
   return W <= 16 ? 16 : 32;
 }
@@ -1008,7 +1008,7 @@ static int attn_out_bwd_launch(float* dx1, const float* u, const float* S, const
   CRD_CHECK_ARG(dx1 && u && S && t && dbp_rows && dS, "%s: null pointer", who);
   CRD_UNSUPPORTED(C % 8 == 0 && C <= 512, "%s: C must be a multiple of 8 and <= 512", who);
   static int small = -1;
-  if (small < 0) { const char* e = getenv("CRD_ATTN_OUT_BWD_CHUNK"); small = e ? atoi(e) : 32; }
+  if (small < 0) small = crd_dev_int("CRD_ATTN_OUT_BWD_CHUNK", 32);
   int nblk = cdiv(N, (long long)B * cdiv(N, 256) < 128 ? small : 256);     // fewer pixels per workgroup on small grids
   int cap = 1024 / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
@@ -1046,8 +1046,8 @@ static int attn_bwd_blocks(int B, int N, int M, int heads, int C) {
   // 1664 per sample gave 8 / 32 / 104 workgroups): 24.87 -> 24.53 ms per step, the extra partial copies included
   static int small = -1, mid = -1;
   if (small < 0) {
-    const char* e = getenv("CRD_ATTN_BWD_CHUNK"); small = e ? atoi(e) : 32;
-    e = getenv("CRD_ATTN_BWD_CHUNK2"); mid = e ? atoi(e) : 64;
+    small = crd_dev_int("CRD_ATTN_BWD_CHUNK", 32);
+    mid = crd_dev_int("CRD_ATTN_BWD_CHUNK2", 64);
   }
   int target = 128;
   if ((long long)B * cdiv(N, 128) < 128) target = N <= 512 ? small : mid;

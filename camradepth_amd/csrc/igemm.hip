@@ -296,7 +296,7 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   k.red_stats = d->red_stats; k.red_gamma = d->red_gamma; k.red_beta = d->red_beta; k.red_gmul = d->red_gmul;
   k.red_act = d->red_act; k.red_r = d->red_r;
   const long long pcap = d->stats_partial ? d->stats_partial_capacity : 0;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
+  { static int dbg = -1; if (dbg < 0) dbg = crd_dev_int("CRD_DBG", 0); k.dbg = dbg; }
   hipStream_t st = as_stream(stream);
   if (d->red_x) {
     const bool halo_shape = d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IW >= 32 && d->IH >= 8;
@@ -315,7 +315,7 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
     return crd_conv3x3_halo(k, d->B, st, pcap);
   {   // developer override of the tile choice below (tools/bench_small_gemm.py sweeps it)
     static int force = -1;
-    if (force < 0) { const char* e = getenv("CRD_IGEMM_FORCE"); force = e ? atoi(e) : 0; }
+    if (force < 0) force = crd_dev_int("CRD_IGEMM_FORCE", 0);
     switch (force) {
       case 1: return launch<2, 2, 1, 1, 4>(k, d->B, st, pcap);
       case 2: return launch<2, 2, 2, 1, 3>(k, d->B, st, pcap);

@@ -418,15 +418,15 @@ inline void grid_for(long long P, int C, int B, dim3& grid, int& chunk, bool red
   long long nblk = (P + per_block - 1) / per_block;
   static int minpix = -1, small = 256;
   if (minpix < 0) {
-    const char* e = getenv("CRD_GN_MINPIX"); minpix = e ? atoi(e) : 2;
-    e = getenv("CRD_GN_SMALL"); small = e ? atoi(e) : 256;
+    minpix = crd_dev_int("CRD_GN_MINPIX", 2);
+    small = crd_dev_int("CRD_GN_SMALL", 256);
   }
   if (nblk * B < small && minpix < 8) {              // small grids: fewer pixels per lane rather than idle CUs
     per_block = (long long)PL * minpix;
     nblk = (P + per_block - 1) / per_block;
   }
   static int cap_r = -1, cap_e = -1;
-  if (cap_r < 0) { const char* e = getenv("CRD_GN_CAP_R"); cap_r = e ? atoi(e) : 768; e = getenv("CRD_GN_CAP_E"); cap_e = e ? atoi(e) : 4096; }
+  if (cap_r < 0) { cap_r = crd_dev_int("CRD_GN_CAP_R", 768); cap_e = crd_dev_int("CRD_GN_CAP_E", 4096); }
   long long cap = (reduce ? cap_r : cap_e) / (B > 0 ? B : 1); if (cap < 1) cap = 1;
   if (nblk > cap) nblk = cap;
   if (nblk < 1) nblk = 1;
@@ -548,7 +548,7 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
   // channel slices (atomics path, C >= 256): the largest S in 8 / 4 / 2 whose slices are >= 64 channels and whole groups
   int S = 1;
   static int slicing = -1;
-  if (slicing < 0) { const char* e = getenv("CRD_GN_RED_SLICES"); slicing = e ? atoi(e) : 1; }      // developer switch (A/B)
+  if (slicing < 0) slicing = crd_dev_int("CRD_GN_RED_SLICES", 1);      // developer switch (A/B)
   if (slicing && !scratch && C >= 256) {
     const int cpg = 16 * gmul;
     for (int s_ = 8; s_ > 1; s_ >>= 1)

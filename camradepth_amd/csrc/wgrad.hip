@@ -214,7 +214,7 @@ long long plan_splits(WgK& k, int tiles, long long want, int min_steps) {
   if (splits > max_splits) splits = max_splits;
   // every split adds Cout x Ktot 64-bit atomics: keep the total around 1M per launch (2M with the fp32 atomics of round 2: 19.90 vs 19.72 ms per step) (L2 sustains ~170 G atomics/s)
   static long long atom_budget = -1;
-  if (atom_budget < 0) { const char* e = getenv("CRD_WGRAD_ATOMS"); atom_budget = e ? atoll(e) : (1ll << 20); }
+  if (atom_budget < 0) atom_budget = crd_dev_int("CRD_WGRAD_ATOMS", 1 << 20);
   const long long atom_cap = atom_budget / ((long long)k.Cout * k.Ktot) + 1;
   if (splits > atom_cap) splits = atom_cap;
   if (splits < 1) splits = 1;
@@ -315,7 +315,7 @@ extern "C" int crd_conv_wgrad_grouped(const void* dev_table, const crd_wgrad_gro
 
 static bool uses_stream3(const crd_wgrad_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->IH == d->OH && d->IW == d->OW && d->IW >= 32 &&
-         d->IH >= 8 && !getenv("CRD_NO_WGRAD3");
+         d->IH >= 8 && !crd_dev_int("CRD_NO_WGRAD3", 0);
 }
 
 extern "C" int crd_conv_wgrad_splits(const crd_wgrad_desc* d) {
@@ -331,7 +331,7 @@ extern "C" int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream) {
   if (uses_stream3(d)) return crd_wgrad3x3_stream(d, st);
   CRD_CHECK_ARG(d->dw_partials == nullptr, "crd_conv_wgrad: dw_partials is only supported where crd_conv_wgrad_splits() > 0");
   { int rc = check_generic(k); if (rc != CRD_OK) return rc; }
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("CRD_DBG"); dbg = e ? atoi(e) : 0; } k.dbg = dbg; }
+  { static int dbg = -1; if (dbg < 0) dbg = crd_dev_int("CRD_DBG", 0); k.dbg = dbg; }
   if (d->Cout <= 32) return launch<1, 4, 2, 2>(k, st);
   if (d->Cout <= 64) return launch<1, 4, 4, 2>(k, st);
   if (d->Cout <= 96) return launch<2, 2, 3, 4>(k, st);

@@ -277,7 +277,7 @@ int launch_w3r(const Wg3K& k0, hipStream_t st, int partial_capacity) {
 template <int WCO, int WCI, int TCO>
 int launch_w3(const Wg3K& k, hipStream_t st, int partial_capacity) {
   static int rps = -1;
-  if (rps < 0) { const char* e = getenv("CRD_W3_RPS"); rps = e ? atoi(e) : 2; }
+  if (rps < 0) rps = crd_dev_int("CRD_W3_RPS", 2);
   return rps == 1 ? launch_w3r<WCO, WCI, TCO, 1>(k, st, partial_capacity) : launch_w3r<WCO, WCI, TCO, 2>(k, st, partial_capacity);
 }
 

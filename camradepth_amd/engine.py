@@ -24,22 +24,35 @@ from . import trace
 from .config import MID_CHANNELS, UNSUP_CLASSES, ModelConfig
 from .params import short_res_block_plan
 
-# developer switch: CRD_NO_GROUP_WGRAD=1 runs every small weight gradient as its own launch (A/B against the grouped launch)
-GROUP_WGRAD = os.environ.get("CRD_NO_GROUP_WGRAD") is None
+# Tuning / A-B knobs whose verdict is recorded in DESIGN.md are CONSTANTS here; only with CRD_DEV_SWITCHES=1 (developer runs: the
+# sweep and ablation scripts under tools/) are they read from the environment again.
+_DEV = os.environ.get("CRD_DEV_SWITCHES") == "1"
+
+
+def _dev_flag(name):
+    return _DEV and os.environ.get(name) is not None
+
+
+def _dev_int(name, default):
+    return int(os.environ.get(name, default)) if _DEV else int(default)
+
+
+# every small weight gradient as its own launch instead of the grouped launch (A/B): dev switch CRD_NO_GROUP_WGRAD
+GROUP_WGRAD = not _dev_flag("CRD_NO_GROUP_WGRAD")
 # Side branches (q projection, rank-one vector path, depthwise weight gradient on separate graph branches) are recorded
 # only on request: measured 27.7-28.9 ms/step against 26.7 on one stream -- every fork / join costs more in the captured
 # graph than the short kernels it takes off the chain.
-SIDE_STREAMS = os.environ.get("CRD_SIDE_STREAMS") is not None
+SIDE_STREAMS = _dev_flag("CRD_SIDE_STREAMS")
 # GroupNorm-backward reduce of Mlp.norm2 inside the fc2 data-gradient epilogue (crd_conv_desc.red_*): opt-in.  It removes
 # a pass over (H2, d(H3)) per block but measured 26.6 vs 26.4 ms/step: the GELU' + fold + atomics in the GEMM epilogue
 # cost more than the streaming reduce kernel they replace.  (The same fusion into the depthwise data gradient, for
 # Mlp.norm1 without activation, does pay and is always on.)
-FUSE_GN_RED = os.environ.get("CRD_FUSE_GN_RED") is not None
+FUSE_GN_RED = _dev_flag("CRD_FUSE_GN_RED")
 # ... except on grids of <= this many pixels per sample, where the launch it saves outweighs the slower epilogue (25.2 -> 25.0 ms)
-FUSE_GN_RED_MAXPIX = int(os.environ.get("CRD_FUSE_GN_RED_MAXPIX", "416"))
+FUSE_GN_RED_MAXPIX = _dev_int("CRD_FUSE_GN_RED_MAXPIX", 416)
 # GroupNorm statistics of the residual stream produced by the kernels that write it (attn_out_residual -> norm2, fc2's
 # epilogue -> the next block's norm1) instead of crd_gn_stats launches; CRD_NO_FUSE_STATS restores the launches
-FUSE_STATS = os.environ.get("CRD_NO_FUSE_STATS") is None
+FUSE_STATS = not _dev_flag("CRD_NO_FUSE_STATS")
 # The decoder's weight gradients (2.9 ms of MFMA work nothing in the backward pass waits for) can leave the chain: the
 # single-GPU graph step replays them as a graph of their own on a second stream while the encoder's latency-bound backward
 # runs (trainer.py; CRD_NO_LATE_WGRAD keeps program order).  W3_LATE_WGS: workgroups their streaming kernels may use in
@@ -49,20 +62,20 @@ FUSE_STATS = os.environ.get("CRD_NO_FUSE_STATS") is None
 def gn_conv_default():
     """0 = off, 1 = q / k / fc1 / fc2, 2 = q / k / fc1 only (fc2's GroupNorm carries the exact GELU: ~25 VALU operations per
     element, which a GEMM workgroup does once per column tile next to its MFMAs)."""
-    return int(os.environ.get("CRD_GN_CONV", "2") or 0)
+    return _dev_int("CRD_GN_CONV", 2)
 
 
 # Mlp of a Block as ONE launch per (sample, 64-channel hidden slab) + a reduce launch (csrc/mlp_fused.hip) wherever the
 # library covers the shape (Mlp.norm2 group == 64 hidden channels and the pixel grid fits in LDS: encoder stages 3 and 4
 # at 256 x 416).  CRD_MLP_FUSED=0 keeps the four launches (A/B).
-MLP_FUSED = os.environ.get("CRD_MLP_FUSED", "1") != "0"
+MLP_FUSED = _dev_int("CRD_MLP_FUSED", 1) != 0
 # ... up to this many pixels per sample.  One workgroup per (sample, slab) is hidden/64 x B workgroups: at 8 x 13 pixels
 # (stage 4: 128 workgroups) the fused launch takes 18 us against ~45 us for the four it replaces; at 16 x 26 (stage 3: 80
 # workgroups on 256 CUs) it is bound by the VALU work of the stencil / GELU phases on those 80 CUs -- 35 us + the 11 us
 # reduce against 41 us unfused (tools/prof_mlp.py) -- so stage 3 keeps the four launches.
-MLP_FUSED_MAXPIX = int(os.environ.get("CRD_MLP_FUSED_MAXPIX", "128"))
-FC2_FOLD_MINROWS = int(os.environ.get("CRD_FC2_FOLD_MINROWS", "16384"))   # (B = 16 inference 10.51 -> 10.16 ms; B = 1, 8: unchanged)
-GN_CONV_MAXROWS = int(os.environ.get("CRD_GN_CONV_MAXROWS", str(1 << 30)))   # pixels x batch up to which a Block's GEMMs are fused
+MLP_FUSED_MAXPIX = _dev_int("CRD_MLP_FUSED_MAXPIX", 128)
+FC2_FOLD_MINROWS = _dev_int("CRD_FC2_FOLD_MINROWS", 16384)   # (B = 16 inference 10.51 -> 10.16 ms; B = 1, 8: unchanged)
+GN_CONV_MAXROWS = _dev_int("CRD_GN_CONV_MAXROWS", 1 << 30)   # pixels x batch up to which a Block's GEMMs are fused
 # Encoder stages as ONE persistent launch each (csrc/enc_stage.hip: a sample's rows stay in LDS across all Blocks of the stage, the
 # sample's workgroups exchange statistics / keys / stencil rows through tagged granules) wherever the library covers the shape
 # (stages 3 and 4 at 256 x 416).  Round 4: correct, bit-reproducible and graph-safe (tests/test_gpu_enc_stage.py), but NOT yet faster
@@ -75,11 +88,11 @@ def enc_persist_default():
     return os.environ.get("CRD_ENC_PERSIST", "0") == "1"
 
 
-LATE_WGRAD = os.environ.get("CRD_NO_LATE_WGRAD") is None
-W3_LATE_WGS = int(os.environ.get("CRD_W3_LATE_WGS", "160"))
+LATE_WGRAD = not _dev_flag("CRD_NO_LATE_WGRAD")
+W3_LATE_WGS = _dev_int("CRD_W3_LATE_WGS", 160)
 LATE = 3            # Op.stream id of those ops
-SPLIT_N = os.environ.get("CRD_NO_SPLIT_N") is None      # developer switch for the ragged-tile split of 3x3 data gradients
-W3_PARTIALS = os.environ.get("CRD_NO_W3_PARTIALS") is None   # developer switch: streaming 3x3 wgrad with atomics instead
+SPLIT_N = not _dev_flag("CRD_NO_SPLIT_N")      # developer switch for the ragged-tile split of 3x3 data gradients
+W3_PARTIALS = not _dev_flag("CRD_NO_W3_PARTIALS")   # developer switch: streaming 3x3 wgrad with atomics instead
 DW_REPLICAS = 16      # accumulator copies of a depthwise weight gradient (spreads contended fp32 atomics)
 HEAD_ROWS = 64        # same for Depth_Activation.conv_2 (2048 workgroups x 289 sums)
 
@@ -136,8 +149,8 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
     return "k_igemm<2,2,2,2>"
 
 
-FUSE_NORM2_APPLY = os.environ.get("CRD_NO_FUSE_NORM2_APPLY") is None    # developer switch (A/B): Block.norm2's backward apply inside crd_attn_out_bwd
-FUSE_BLOCK_RED = os.environ.get("CRD_NO_FUSE_BLOCK_RED") is None    # developer switch (A/B): Block.norm1 / norm2 reduces in GEMM epilogues
+FUSE_NORM2_APPLY = not _dev_flag("CRD_NO_FUSE_NORM2_APPLY")    # developer switch (A/B): Block.norm2's backward apply inside crd_attn_out_bwd
+FUSE_BLOCK_RED = not _dev_flag("CRD_NO_FUSE_BLOCK_RED")    # developer switch (A/B): Block.norm1 / norm2 reduces in GEMM epilogues
 
 
 def fused_reduce_tile_ok(cout, ohw, B):
@@ -1393,12 +1406,12 @@ class Plan:
                                     and not bool(torch.isfinite(k[5].float()).all()):
                                 print("[crd] non-finite buffer", k[1:5], flush=True)
                         raise L.CrdError(f"non-finite gradient after op {i} {op.name} (first bad param {pname})")
-                if os.environ.get("CRD_DEBUG_IDX"):
+                if _dev_flag("CRD_DEBUG_IDX"):
                     for k in self.keep:
                         if isinstance(k, tuple) and k[0] == "idx" and (int(k[2].min()) < 0 or int(k[2].max()) >= k[3]):
                             raise L.CrdError(f"argmax table of {k[1]} corrupted after op {i} {op.name}")
             return
-        pad = int(os.environ.get("CRD_EXP_PAD", "0"))       # experiment: cost of an extra tiny dispatch after every op
+        pad = _dev_int("CRD_EXP_PAD", 0)       # experiment: cost of an extra tiny dispatch after every op
         if pad and not hasattr(self, "_pad_buf"):
             self._pad_buf = torch.zeros(64, device=self.dev)
         main = torch.cuda.current_stream()

@@ -340,6 +340,43 @@ class TrainStep:
             graphs.append((g, after))
         return graphs
 
+    # stream plumbing of the late-stream replay, as methods so that the CPU control-flow test (tests/test_ddp_cpu.py, gloo world 2)
+    # can run the very same _replay_late with stand-ins for the HIP graphs and streams
+    @staticmethod
+    def _current_stream():
+        return torch.cuda.current_stream()
+
+    @staticmethod
+    def _stream_wait(waiter, on):
+        waiter.wait_stream(on)
+
+    @staticmethod
+    def _on_stream(stream):
+        return torch.cuda.stream(stream)
+
+    def _replay_late(self, g, opt):
+        """One iteration of the late-stream variant (see _capture_variant): per backward segment its main graph, then -- on the late
+        stream, behind it -- the segment's weight-gradient graph, and on the closing iteration of a window of a multi-GPU run that
+        bucket's all-reduce and optimizer slice, while the main stream already runs the next segment."""
+        _, g0, chain, go = g
+        main = self._current_stream()
+        if g0 is not None:
+            g0.replay()
+            dist.all_reduce(self.acc, group=self.sync.group)      # global loss denominators before the backward
+        for gm, gl, key, gopt in chain:
+            with trace.range("main:" + "+".join(key)):
+                gm.replay()
+            self._stream_wait(self.late_stream, main)
+            with self._on_stream(self.late_stream), trace.range("late:" + "+".join(key)):
+                gl.replay()
+                if self.dist_active and opt:
+                    self.sync.launch(key)      # this bucket's all-reduce, behind the graph that finishes its gradients
+                    self.sync.wait()           # (the LATE stream waits for it; the main stream runs on)
+                    gopt.replay()              # ... and the bucket's optimizer slice follows at once
+        self._stream_wait(main, self.late_stream)
+        if go is not None:
+            go.replay()
+
     def set_batch(self, batch):
         self.plan.x_in.copy_(batch["image"], non_blocking=True)
         self.gt["full"].copy_(batch["gt_full"], non_blocking=True)
@@ -378,25 +415,8 @@ class TrainStep:
         runs = self.graphs[(zero, opt)] if self.use_graph else [(None, a) for _, a in self._segments()]
         fns = None if self.use_graph else [f for f, _ in self._segments()]
         for i, (g, after) in enumerate(runs):
-            if isinstance(g, tuple):           # ("late", first graph, [(main graph, late graph, bucket)], optimizer graph)
-                _, g0, chain, go = g
-                main = torch.cuda.current_stream()
-                if g0 is not None:
-                    g0.replay()
-                    dist.all_reduce(self.acc, group=self.sync.group)      # global loss denominators before the backward
-                for gm, gl, key, gopt in chain:
-                    with trace.range("main:" + "+".join(key)):
-                        gm.replay()
-                    self.late_stream.wait_stream(main)
-                    with torch.cuda.stream(self.late_stream), trace.range("late:" + "+".join(key)):
-                        gl.replay()
-                        if self.dist_active and opt:
-                            self.sync.launch(key)      # this bucket's all-reduce, behind the graph that finishes its gradients
-                            self.sync.wait()           # (the LATE stream waits for it; the main stream runs on)
-                            gopt.replay()              # ... and the bucket's optimizer slice follows at once
-                main.wait_stream(self.late_stream)
-                if go is not None:
-                    go.replay()
+            if isinstance(g, tuple):           # ("late", first graph, [(main graph, late graph, bucket, optimizer slice)], -)
+                self._replay_late(g, opt)
             elif g is not None:
                 with trace.range("graph:%d" % i):
                     g.replay()

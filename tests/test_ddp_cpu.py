@@ -138,6 +138,110 @@ def test_train_step_control_flow_world2():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _worker_late(rank, world, port, q):
+    """The LATE-STREAM distributed variant of TrainStep (trainer._capture_variant / _replay_late: per backward segment a main graph,
+    behind it on a second stream the segment's weight-gradient graph, then -- closing iteration of a window only -- that bucket's
+    all-reduce and its optimizer slice) replayed end to end through TrainStep.step(), with CPU stand-ins for the HIP graphs and
+    streams, against the single-process result computed in closed form."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import contextlib
+        import types
+        from camradepth_amd.model import CamRaDepth
+        from camradepth_amd.trainer import GradSync, TrainStep
+        torch.manual_seed(0)
+        m = CamRaDepth(input_channels=7, depths=(1, 1, 1, 1))
+        m._ensure_grad_views()
+        p0 = m.flat.detach().clone()
+        ts = object.__new__(TrainStep)
+        ts.state = types.SimpleNamespace()
+        ts.model, ts.sync = m, GradSync(m)
+        ts.dist_active, ts.world, ts.update_interval, ts.use_graph = True, world, 2, True
+        ts.schedule, ts.lr, ts.betas, ts.eps, ts.wd = None, 1e-3, (0.9, 0.999), 1e-8, 0.0
+        ts.iter_count = ts.epoch_iter = ts.sched_steps = ts.step_count = 0
+        ts._window_open, ts._window_pos, ts._zero, ts._opt = False, 0, True, True
+        ts.hp, ts.hp_ring, ts.acc = torch.zeros(8), [torch.zeros(8) for _ in range(4)], torch.zeros(16, dtype=torch.int64)
+        ts.plan = types.SimpleNamespace(ensure_packed=lambda: None, packed_version=None)
+        ts._params, ts._frozen_sig = [], ()
+        ts.late_stream = "late"
+        log = []
+        ts._current_stream = lambda: "main"
+        ts._stream_wait = lambda waiter, on: log.append(("wait", waiter, on))
+        ts._on_stream = lambda stream: contextlib.nullcontext()
+        launch = ts.sync.launch
+        ts.sync.launch = lambda key: (log.append(("allreduce", key)), launch(key))[1]
+
+        class G:                                   # stand-in for a captured graph
+            def __init__(self, tag, fn):
+                self.tag, self.fn = tag, fn
+
+            def replay(self):
+                log.append(self.tag)
+                self.fn()
+
+        LR = 0.5
+
+        def variant(zero, opt):
+            def fwd():
+                if zero:
+                    m.flat_grad.zero_()
+                ts.acc.zero_()
+                ts.acc[0] += rank + 1
+                ts.acc[1] += 1
+
+            def late(key):                          # the bucket's weight gradients, rank- and iteration-dependent
+                lo, hi = ts.sync.ranges[key]
+                m.flat_grad[lo:hi] += (rank + 1.0) * (ts.iter_count + 1)
+
+            def optim(key):                         # the bucket's optimizer slice on the REDUCED gradients
+                lo, hi = ts.sync.ranges[key]
+                with torch.no_grad():
+                    m.flat[lo:hi] -= LR * m.flat_grad[lo:hi]
+            chain = [(G(("main", key), lambda: None), G(("late", key), lambda key=key: late(key)), key,
+                      G(("opt", key), lambda key=key: optim(key)) if opt else None) for key in GradSync.ORDER]
+            return [(("late", G(("fwd",), fwd), chain, None), None)]
+        ts.graphs = {(z, o): variant(z, o) for z in (True, False) for o in (True, False)}
+        ran, accs = [], []
+        for it in range(5):
+            ran.append(ts.step(last_of_epoch=(it == 4)))
+            accs.append(float(ts.acc[0] / ts.acc[1]))
+        ok = ran == [False, True, False, True, True] and ts.step_count == 3
+        ok = ok and accs == [sum(r + 1.0 for r in range(world)) / world] * 5
+        # single-process result: every optimizer step applies the SUM over ranks and over the window's iterations
+        ranks = sum(r + 1.0 for r in range(world))
+        expect = p0 - LR * ranks * ((1 + 2) + (3 + 4) + 5)
+        ok = ok and torch.allclose(m.flat.detach(), expect, rtol=1e-6, atol=1e-6) and not ts.sync.pending
+        # order inside a closing iteration: per bucket main graph -> (late stream waits for main) -> late graph -> all-reduce ->
+        # optimizer slice; buckets in backward order; the main stream joins the late stream at the end
+        last = log[len(log) - 1 - log[::-1].index(("fwd",)):]
+        want = [("fwd",)]
+        for key in GradSync.ORDER:
+            want += [("main", key), ("wait", "late", "main"), ("late", key), ("allreduce", key), ("opt", key)]
+        want += [("wait", "main", "late")]
+        ok = ok and last == want
+        # ... and an iteration that only accumulates launches no collective on the gradients
+        first = log[:log.index(("fwd",), 1)]
+        ok = ok and not any(e[0] in ("allreduce", "opt") for e in first)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_late_stream_distributed_step_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_late, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(0, True), (1, True)]
+
+
 def test_one_cycle_schedule_matches_torch():
     from camradepth_amd.trainer import one_cycle
     p = torch.nn.Parameter(torch.zeros(1))

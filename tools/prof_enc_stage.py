@@ -70,7 +70,8 @@ if hasattr(lib, "crd_dbg_enc_prof"):
     names = ["(idle)", "E0 gather+tables", "xn", "q/sr(k) gemm + u", "E1 gather (+k gemm)", "scores + S", "x1", "E2 + tables", "xn2", "fc1 gemm",
              "h1 store + publish", "E3 + tables", "dwconv (rest)", "E4 + tables", "h3 (gelu)", "fc2 gemm", "x2 store + E0 publish",
              "  L2 warm-up issue", "  E0 gather", "  dw r0: stage halo + norm", "  dw r0: stencil", "  dw r0: reduce + barrier",
-             "  dw r1: stage halo + norm", "  dw r1: stencil", "  dw r1: reduce + barrier"]
+             "  dw r1: stage halo + norm", "  dw r1: stencil", "  dw r1: reduce + barrier", "  q gemm (wave 0)", "  sr / k gemm (wave 0)",
+             "  E1 gather + attn.norm"]
     os.environ["CRD_ENC_PERSIST"] = "1"
     engine.ENC_ROWS_PER_WG = int(os.environ.get("PROF_ROWS", "0"))
     for train in (False, True):
@@ -92,7 +93,7 @@ if hasattr(lib, "crd_dbg_enc_prof"):
             torch.cuda.synchronize()
             lib.crd_dbg_enc_prof(buf, 1)
             nb = cfg.depths[2 + si]
-            tot = sum(buf[1:25]) / 100.0 / reps / nb
+            tot = sum(buf[1:28]) / 100.0 / reps / nb
             print(f"train={int(train)} stage {3 + si}: {tot:7.1f} us per block (workgroup 0), phases:")
-            for i in range(1, 25):
+            for i in range(1, 28):
                 print(f"    {names[i]:28s} {buf[i] / 100.0 / reps / nb:7.2f} us")

@@ -1,3 +1,5 @@
+# NOTE: these knobs are constants in the product build: build with CRD_EXTRA_FLAGS=-DCRD_DEV_SWITCHES python -m camradepth_amd.build
+# and run with CRD_DEV_SWITCHES=1 (camradepth_amd/csrc/common.h: crd_dev_int; camradepth_amd/engine.py: _dev_int)
 # spread of the 928x1600 golden comparison over launch geometries that only regroup float partial sums
 for tw in 16 32; do for gs in 128 256; do
   echo "CRD_DW_TW=$tw CRD_GN_SMALL=$gs"

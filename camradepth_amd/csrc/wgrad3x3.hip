@@ -22,6 +22,7 @@ struct Wg3K {
   int B, H, W;
   int strips_x;                                  // ceil(W / 32)
   int rows_per_wg;                               // strip rows per workgroup
+  int S, nchunks;                                // row splits per channel chunk, channel chunks of 64
   long long total_rows;                          // B * strips_x * H
   long long x_bytes, dy_bytes;
   crd_sum_t* dw; crd_sum_t* dbias;
@@ -51,7 +52,7 @@ __device__ __forceinline__ s16x4 tr_read3(const bf16_t* p) {
 }
 
 // WCO x WCI = 8 waves; a wave owns TCO 16-channel co tiles and NT 16-channel ci tiles of the 64-channel chunk
-// (2 x 2 tiles per wave halve the LDS fragment reads per MFMA compared with 1 x 4)
+// (fragment reads per strip row and wave: 2 TCO of dy, 18 NT of the input, for 9 TCO NT MFMAs: many co tiles x ONE ci tile is best)
 // RPS = image rows per step (per barrier): with one row a wave issues 9 x TCO x NT = 18-36 MFMAs between two barriers; two rows
 // halve the barriers and the counted waits per MFMA (the rings are twice as deep: 12 input rows, 8 dy rows).
 template <int WCO, int WCI, int TCO, int RPS>
@@ -68,7 +69,10 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wco = wv / WCI, wci = wv % WCI;
-  const int chunk = blockIdx.y;
+  // workgroup = chunk * S + split.  (Placing the chunks of a row split on one XCD, so that their re-reads of the same dy rows hit
+  // that XCD's L2, measured the same -- 304 -> 128 at 256 x 416: 0.706 vs 0.713 ms: the kernel is bound by its LDS fragment reads and
+  // MFMA issue inside the CU, about 1 us per strip row, not by the 2.5 TB/s it fetches; tools/sweep_w3.sh)
+  const int chunk = (int)blockIdx.x / a.S, split = (int)blockIdx.x - chunk * a.S;
   const int c0 = chunk * XLD;
   const unsigned OOB = 0x80000000u;
 
@@ -101,7 +105,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
   const bool do_bias = a.dbias != nullptr && chunk == 0 && t < a.Cout;
   float bsum = 0.f;
 
-  long long sr = (long long)blockIdx.x * a.rows_per_wg;
+  long long sr = (long long)split * a.rows_per_wg;
   long long sr_end = sr + a.rows_per_wg;
   if (sr_end > a.total_rows) sr_end = a.total_rows;
 
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
             const long long off = (long long)co * Ktot + tp * a.Cin + ci;
             // every (row split, chunk) workgroup owns its block of its split's copy: plain stores, the caller sums the
             // copies (crd_wgrad_unpack); otherwise Cout x 9 x Cin atomics per row split (19 M per launch, ~0.1 ms)
-            if (a.dw_part) a.dw_part[(long long)blockIdx.x * a.Cout * Ktot + off] = acc[tp][i][j][r];
+            if (a.dw_part) a.dw_part[(long long)split * a.Cout * Ktot + off] = acc[tp][i][j][r];
             else grad_add(a.dw + off, acc[tp][i][j][r]);
           }
         }
@@ -243,42 +247,42 @@ __global__ __launch_bounds__(512) void k_wgrad3x3(Wg3K a) {
   if (do_bias) grad_add(a.dbias + t, bsum);
 }
 
-// row splits (workgroups along x) and strip rows per workgroup.  cap > 0 (the number of partial copies the caller
-// provides): at most that many row splits -- how a caller leaves CUs to kernels running next to this one.
-int plan_rows(long long total_rows, int Cin, int& rows_per_wg, int cap = 0) {
+// Row splits (= partial copies) and strip rows per workgroup.  budget: workgroups the launch may use (0 = one per CU: every row
+// split adds Cout x 9 x Cin fp32 values to sum, which a second workgroup per CU does not win back: 30.0 vs 30.3 ms/step); cap > 0:
+// the number of partial copies the caller provides.
+int plan_rows(long long total_rows, int Cin, int& rows_per_wg, int budget, int cap) {
   const int chunks = cdiv(Cin, XLD);
-  // one workgroup per CU in total: every row split adds Cout x 9 x Cin fp32 atomics (37 M per launch at 512 workgroups,
-  // ~0.2 ms at the ~170 G/s the L2s sustain), which a second workgroup per CU does not win back (30.0 vs 30.3 ms/step)
-  int wgs = 256 / chunks;
-  if (wgs < 1) wgs = 1;
-  if (cap > 0 && wgs > cap) wgs = cap;
-  if (wgs > total_rows / 8) wgs = (int)(total_rows / 8 > 0 ? total_rows / 8 : 1);
-  rows_per_wg = (int)((total_rows + wgs - 1) / wgs);
+  const int W = budget > 0 ? budget : 256;
+  long long S = W / chunks;
+  if (S < 1) S = 1;
+  if (cap > 0 && S > cap) S = cap;
+  if (S > total_rows / 8) S = total_rows / 8 > 0 ? total_rows / 8 : 1;
+  rows_per_wg = (int)((total_rows + S - 1) / S);
   return (int)((total_rows + rows_per_wg - 1) / rows_per_wg);
 }
 
 template <int WCO, int WCI, int TCO, int RPS>
-int launch_w3r(const Wg3K& k0, hipStream_t st, int partial_capacity) {
+int launch_w3r(const Wg3K& k0, hipStream_t st, int budget, int partial_capacity) {
   Wg3K k = k0;
   constexpr int COT = WCO * TCO * 16;
   const size_t lds = (size_t)RPS * (XS * XPX * XLD + YS * 32 * COT) * sizeof(bf16_t);
-  const int chunks = cdiv(k.Cin, XLD);
-  const int wgs = plan_rows(k.total_rows, k.Cin, k.rows_per_wg, k.dw_part ? partial_capacity : 0);
+  k.nchunks = cdiv(k.Cin, XLD);
+  k.S = plan_rows(k.total_rows, k.Cin, k.rows_per_wg, budget, k.dw_part ? partial_capacity : 0);
   static bool attr_done = false;
   if (!attr_done) {
     crd_reserve_lds(reinterpret_cast<const void*>(&k_wgrad3x3<WCO, WCI, TCO, RPS>), (int)lds, "k_wgrad3x3");
     attr_done = true;
   }
-  hipLaunchKernelGGL((k_wgrad3x3<WCO, WCI, TCO, RPS>), dim3(wgs, chunks), dim3(512), lds, st, k);
+  hipLaunchKernelGGL((k_wgrad3x3<WCO, WCI, TCO, RPS>), dim3(k.nchunks * k.S), dim3(512), lds, st, k);
   CRD_LAUNCH_CHECK("crd_conv_wgrad(3x3 streaming)");
   return CRD_OK;
 }
 
 template <int WCO, int WCI, int TCO>
-int launch_w3(const Wg3K& k, hipStream_t st, int partial_capacity) {
+int launch_w3(const Wg3K& k, hipStream_t st, int budget, int partial_capacity) {
   static int rps = -1;
   if (rps < 0) rps = crd_dev_int("CRD_W3_RPS", 2);
-  return rps == 1 ? launch_w3r<WCO, WCI, TCO, 1>(k, st, partial_capacity) : launch_w3r<WCO, WCI, TCO, 2>(k, st, partial_capacity);
+  return rps == 1 ? launch_w3r<WCO, WCI, TCO, 1>(k, st, budget, partial_capacity) : launch_w3r<WCO, WCI, TCO, 2>(k, st, budget, partial_capacity);
 }
 
 }  // namespace
@@ -298,13 +302,18 @@ int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st) {
   k.dw = d->dw; k.dbias = d->dbias;
   k.dw_part = d->dw_partials;
   CRD_CHECK_ARG(d->dw_partials == nullptr || d->dw_partial_capacity >= 1, "crd_conv_wgrad: dw_partials needs a capacity >= 1");
-  if (d->Cout <= 32) return launch_w3<2, 4, 1>(k, st, d->dw_partial_capacity);
-  if (d->Cout <= 64) return launch_w3<2, 4, 2>(k, st, d->dw_partial_capacity);
-  if (d->Cout <= 96) return launch_w3<2, 4, 3>(k, st, d->dw_partial_capacity);     // 96-channel dy rows: no padded MFMA tiles
-  return launch_w3<4, 2, 2>(k, st, d->dw_partial_capacity);
+  CRD_CHECK_ARG(d->wg_budget >= 0, "crd_conv_wgrad: wg_budget must be >= 0");
+  if (d->Cout <= 32) return launch_w3<2, 4, 1>(k, st, d->wg_budget, d->dw_partial_capacity);
+  if (d->Cout <= 64) return launch_w3<2, 4, 2>(k, st, d->wg_budget, d->dw_partial_capacity);
+  if (d->Cout <= 96) return launch_w3<2, 4, 3>(k, st, d->wg_budget, d->dw_partial_capacity);     // 96-channel dy rows: no padded MFMA tiles
+  // 128 output channels: FOUR co tiles x one ci tile per wave.  Per strip row a wave then reads 8 dy + 18 input fragments for its 36
+  // MFMAs; with 2 x 2 tiles (round 2-3) it was 4 + 36 -- the kernel is bound by those LDS reads (0.716 -> 0.658 ms at 304 -> 128,
+  // 0.293 -> 0.262 ms at 128 -> 128, 256 x 416 x 8)
+  if (crd_dev_int("CRD_W3_T22", 0)) return launch_w3<4, 2, 2>(k, st, d->wg_budget, d->dw_partial_capacity);
+  return launch_w3<2, 4, 4>(k, st, d->wg_budget, d->dw_partial_capacity);
 }
 
 int crd_wgrad3x3_splits(const crd_wgrad_desc* d) {
   int rows = 0;
-  return plan_rows((long long)d->B * cdiv(d->IW, 32) * d->IH, d->Cin, rows, d->dw_partial_capacity > 0 ? d->dw_partial_capacity : 0);
+  return plan_rows((long long)d->B * cdiv(d->IW, 32) * d->IH, d->Cin, rows, d->wg_budget, d->dw_partial_capacity > 0 ? d->dw_partial_capacity : 0);
 }

@@ -211,6 +211,7 @@ class ConvW:
         self.identity = (cmap is None and self.cin_pad == cin_ref and self.taps == 1)
         self.w_fwd = self.w_dgrad = self.w_scatter = None   # bf16 tensors
         self.dw = None                                        # fp32 [cout][taps][cin_pad] (scratch or direct grad view)
+        self.wg_budget = 0
         self.dw_parts, self.dw_S, self.stream3_geom = None, 0, None   # per-split copies of dw for the streaming 3x3 wgrad
         self.cmap_dev = None
         self.want_frag, self.w_frag = False, None            # fragment-ordered copy of w_fwd for the persistent encoder stages
@@ -404,7 +405,7 @@ class Plan:
         stream3 = k == 3 and stride == 1 and OW >= 32 and OH >= 8
         if stream3:
             cw.stream3_geom = (x.H, x.W, spec["cin"])
-        kname = ("k_wgrad3x3<2,4,1>" if cw.cout <= 32 else "k_wgrad3x3<2,4,2>" if cw.cout <= 64 else "k_wgrad3x3<2,4,3>" if cw.cout <= 96 else "k_wgrad3x3<4,2,2>") if stream3 \
+        kname = ("k_wgrad3x3<2,4,1>" if cw.cout <= 32 else "k_wgrad3x3<2,4,2>" if cw.cout <= 64 else "k_wgrad3x3<2,4,3>" if cw.cout <= 96 else "k_wgrad3x3<2,4,4>") if stream3 \
             else wgrad_tile(cw.cout)
         meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps, "param": cw.name,
                 "shape": f"wgrad Cin{spec['cin']} Cout{cw.cout} k{k} s{stride} out{OH}x{OW}"}
@@ -508,7 +509,7 @@ class Plan:
             d.KH, d.KW, d.stride, d.pad = sp["k"], sp["k"], sp["stride"], sp["pad"]
             d.dw, d.dbias = P(cw.dw), P(sp["dbias"])
             if cw.dw_parts is not None:
-                d.dw_partials, d.dw_partial_capacity = cw.dw_parts.data_ptr(), cw.dw_S
+                d.dw_partials, d.dw_partial_capacity, d.wg_budget = cw.dw_parts.data_ptr(), cw.dw_S, cw.wg_budget
         else:
             x, y, w = sp["x"], sp["y"], sp["w"]
             if isinstance(w, tuple):
@@ -1244,8 +1245,8 @@ class Plan:
                 probe.B, probe.IH, probe.IW, probe.OH, probe.OW = self.B, cw.stream3_geom[0], cw.stream3_geom[1], cw.stream3_geom[0], cw.stream3_geom[1]
                 probe.Cin, probe.Cout, probe.KH, probe.KW, probe.stride, probe.pad = cw.stream3_geom[2], cw.cout, 3, 3, 1, 1
                 wcap = getattr(self.model, "w3_total_wgs", None)      # set by TrainStep in late-wgrad mode
-                if wcap:
-                    probe.dw_partial_capacity = max(1, wcap // -(-cw.stream3_geom[2] // 64))
+                cw.wg_budget = int(wcap or 0)
+                probe.wg_budget = cw.wg_budget
                 cw.dw_S = int(self.lib.crd_conv_wgrad_splits(C.byref(probe)))
             if cw.dw_S > 0:
                 cw.dw_parts = self.new((cw.dw_S, cw.cout, cw.taps, cw.cin_pad), F32)

@@ -49,7 +49,7 @@ class WgradDesc(C.Structure):
         ("dy", C.c_void_p), ("dy_ld", C.c_int32), ("dy_coff", C.c_int32),
         ("OH", C.c_int32), ("OW", C.c_int32), ("Cout", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
-        ("dw", C.c_void_p), ("dbias", C.c_void_p), ("dw_partials", C.c_void_p), ("dw_partial_capacity", C.c_int32),
+        ("dw", C.c_void_p), ("dbias", C.c_void_p), ("dw_partials", C.c_void_p), ("dw_partial_capacity", C.c_int32), ("wg_budget", C.c_int32),
     ]
 
 

@@ -181,8 +181,11 @@ typedef struct {
                          S copies (crd_wgrad_unpack, replicas = S).  NULL: the splits add into dw with fp32 atomics. */
   int32_t dw_partial_capacity;   /* copies dw_partials holds.  It also CAPS the number of splits (= workgroups per channel
                                     chunk): the kernel uses min(natural split count, capacity) splits and writes exactly
-                                    crd_conv_wgrad_splits(d) copies -- a caller that runs other kernels next to this one
-                                    passes a small capacity to leave them CUs */
+                                    crd_conv_wgrad_splits(d) copies */
+  int32_t wg_budget;             /* workgroups the streaming 3x3 kernel may use in total (0 = one per CU): a caller that runs
+                                    other kernels next to this one passes fewer to leave them CUs.  The splits follow from it:
+                                    budget / channel chunks, with a short last chunk (Cin = 136 / 144 / 200) given fewer
+                                    workgroups and more rows each */
 } crd_wgrad_desc;
 
 int crd_conv_wgrad(const crd_wgrad_desc* d, crd_stream_t stream);

@@ -64,7 +64,7 @@ def test_struct_layouts_match_header(built, tmp_path):
     import subprocess
     fields = {"crd_conv_desc": (built.ConvDesc, ["x", "w", "OH", "y", "bias", "res", "res_scale", "stats", "red_x", "red_act", "red_stats", "red_r"]),
               "crd_gn_input": (built.GnInput, ["x_f32", "gmul", "stats", "gamma", "beta", "act", "xn_ld", "xn"]),
-              "crd_wgrad_desc": (built.WgradDesc, ["x", "dy", "Cout", "dw", "dbias", "dw_partials", "dw_partial_capacity"]),
+              "crd_wgrad_desc": (built.WgradDesc, ["x", "dy", "Cout", "dw", "dbias", "dw_partials", "dw_partial_capacity", "wg_budget"]),
               "crd_pack_entry": (built.PackEntry, ["src", "cmap", "Cout", "dst_f32"]),
               "crd_unpack_entry": (built.UnpackEntry, ["src", "cmap", "Cin_pad", "replicas", "replica_stride"]),
               "crd_wgrad_group_info": (built.WgradGroupInfo, ["n_problems", "n_items", "item_offset", "bytes"]),

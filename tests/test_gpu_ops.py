@@ -162,6 +162,22 @@ def test_conv_wgrad(case):
         got3 = parts2[:S2].sum(0).cpu()[:, :, :Ci].reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
         assert_close(got3, w.grad, f"wgrad capped partials {case}", rel=2e-3, elem=4e-3)
         assert_close(gval(db), bias.grad, f"dbias capped partials {case}", rel=2e-3, elem=4e-3)
+        # a workgroup budget (how the two-stream step leaves CUs to the kernels running next to it): the splits follow from it, and
+        # a short last channel chunk (Cin = 136 here: 8 of 64 channels) gets fewer workgroups than copies -- its block of the
+        # remaining copies must come out as zeros, not as whatever the buffer held
+        for budget in (10, 25):
+            d.wg_budget, d.dw_partial_capacity = budget, 0
+            S3 = lb.crd_conv_wgrad_splits(C.byref(d))
+            assert 1 <= S3 <= budget
+            parts3 = torch.full((S3 + 1, Co, k * k, Cp), float("nan"), device="cuda")
+            d.dw_partials, d.dw_partial_capacity = P(parts3), S3
+            db.zero_()
+            ok(lb.crd_conv_wgrad(C.byref(d), lib.stream()), "crd_conv_wgrad budget")
+            assert bool(torch.isnan(parts3[S3:]).all()) and not bool(torch.isnan(parts3[:S3]).any())
+            got4 = parts3[:S3].sum(0).cpu()[:, :, :Ci].reshape(Co, k, k, Ci).permute(0, 3, 1, 2)
+            assert_close(got4, w.grad, f"wgrad budget {budget} {case}", rel=2e-3, elem=4e-3)
+            assert_close(gval(db), bias.grad, f"dbias budget {budget} {case}", rel=2e-3, elem=4e-3)
+        d.wg_budget = 0
 
 
 @pytest.mark.parametrize("H,W,with_add", [(9, 13, False), (16, 40, True)])

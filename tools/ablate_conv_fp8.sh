@@ -15,9 +15,8 @@ if [ "$1" = "build" ]; then
   done
   exit 0
 fi
-cp camradepth_amd/libcamradepth_hip.so /tmp/lib_orig.so
+export PYTHONPATH=.       # (each variant is loaded through CRD_LIB: the product library is never replaced)
 for v in $VARS; do
-  cp camradepth_amd/libabl_$v.so camradepth_amd/libcamradepth_hip.so
+  export CRD_LIB=$PWD/camradepth_amd/libabl_$v.so
   echo "ablate=$v: $(python tools/bench_conv_fp8.py 20 | tail -1)  |  $(CIN=144 COUT=96 python tools/bench_conv_fp8.py 20 | tail -1) | $(CIN=240 COUT=64 python tools/bench_conv_fp8.py 20 | tail -1)"
 done
-cp /tmp/lib_orig.so camradepth_amd/libcamradepth_hip.so

@@ -2,12 +2,9 @@
 # tools/bench_conv.py against it (on the GPU box: bash tools/build_prof.sh run <bench_conv args>)
 set -e
 cd "$(dirname "$0")/.."
-if [ "$1" = "run" ]; then
+if [ "$1" = "run" ]; then          # (the profiling library is loaded through CRD_LIB: the product library is never replaced)
   shift
-  cp camradepth_amd/libcamradepth_hip.so /tmp/lib_orig.so
-  cp camradepth_amd/libprof.so camradepth_amd/libcamradepth_hip.so
-  python tools/bench_conv.py "$@" || true
-  cp /tmp/lib_orig.so camradepth_amd/libcamradepth_hip.so
+  CRD_LIB=$PWD/camradepth_amd/libprof.so PYTHONPATH=. python tools/bench_conv.py "$@" || true
   exit 0
 fi
 python -m camradepth_amd.build >/dev/null

@@ -431,9 +431,14 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
           const crd_rsrc_t rs = make_rsrc(ptr, (unsigned)bytes);
           // ONE dword per 128-byte line (a wave request touches 64 lines = 8 KB): the line lands in L2, only 4 bytes travel on to
           // the CU.  (Whole lines -- 16 bytes per lane -- made this loop 4.3 us per Block: the CU's own fill rate, ~25 GB/s.)
-          for (int c = g * NW + wv; c * 8192 < bytes; c += G * NW)
+#ifndef CRD_ENC_WARM
+#define CRD_ENC_WARM 128          // bytes between the touched dwords (developer builds: 64 = every half line, 0 = no warm-up)
+#endif
+          constexpr int WSTEP = CRD_ENC_WARM > 0 ? CRD_ENC_WARM : 128, WSPAN = 64 * WSTEP;
+          if (CRD_ENC_WARM > 0)
+          for (int c = g * NW + wv; c * WSPAN < bytes; c += G * NW)
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
-                         :: "s"((unsigned)CF::OFF_DUMMY), "v"((unsigned)(c * 8192 + (tid & 63) * 128)), "s"(rs) : "memory", "m0");
+                         :: "s"((unsigned)CF::OFF_DUMMY), "v"((unsigned)(c * WSPAN + (tid & 63) * WSTEP)), "s"(rs) : "memory", "m0");
         }
       }
       const long long rowbase = (long long)b * N + g * NPX;         // first own pixel in [B][N][.] tensors

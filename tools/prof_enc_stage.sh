@@ -4,7 +4,7 @@
 set -e
 OUT=camradepth_amd/libcamradepth_prof.so
 OBJ=/tmp/enc_stage_prof.o
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-inline-asm -fno-slp-vectorize -DCRD_ENC_PROF -c camradepth_amd/csrc/enc_stage.hip -o $OBJ
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result -Wno-inline-asm -fno-slp-vectorize -DCRD_ENC_PROF $ENC_DEFS -c camradepth_amd/csrc/enc_stage.hip -o $OBJ
 OBJS=$(ls camradepth_amd/csrc/build/*.o | grep -v enc_stage.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS $OBJ
 CRD_LIB=$PWD/$OUT PYTHONPATH=. python tools/prof_enc_stage.py "$@"

@@ -429,10 +429,12 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
           const int bytes = pbytes[r];
           if (ptr == nullptr) continue;
           const crd_rsrc_t rs = make_rsrc(ptr, (unsigned)bytes);
-          // ONE dword per 128-byte line (a wave request touches 64 lines = 8 KB): the line lands in L2, only 4 bytes travel on to
+          // ONE dword per half line (a wave request touches 64 x 64 bytes = 4 KB): the data lands in L2, only 4 bytes travel on to
           // the CU.  (Whole lines -- 16 bytes per lane -- made this loop 4.3 us per Block: the CU's own fill rate, ~25 GB/s.)
 #ifndef CRD_ENC_WARM
-#define CRD_ENC_WARM 128          // bytes between the touched dwords (developer builds: 64 = every half line, 0 = no warm-up)
+#define CRD_ENC_WARM 64           // bytes between the touched dwords: every half line (fills are 64 bytes).  Stage 3 forward at B = 8, one row per
+                                  // workgroup, eval / train: no warm-up 1229 / 1356 us, 128: 1238 / 1337, 64: 1207 / 1308, 16: 1199 / 1298 -- the GEMM
+                                  // phases are NOT waiting for first-touch weights (fc1 6.3 us without, 5.0-5.3 with)
 #endif
           constexpr int WSTEP = CRD_ENC_WARM > 0 ? CRD_ENC_WARM : 128, WSPAN = 64 * WSTEP;
           if (CRD_ENC_WARM > 0)

@@ -78,14 +78,18 @@ FC2_FOLD_MINROWS = _dev_int("CRD_FC2_FOLD_MINROWS", 16384)   # (B = 16 inference
 GN_CONV_MAXROWS = _dev_int("CRD_GN_CONV_MAXROWS", 1 << 30)   # pixels x batch up to which a Block's GEMMs are fused
 # Encoder stages as ONE persistent launch each (csrc/enc_stage.hip: a sample's rows stay in LDS across all Blocks of the stage, the
 # sample's workgroups exchange statistics / keys / stencil rows through tagged granules) wherever the library covers the shape
-# (stages 3 and 4 at 256 x 416).  Round 4: correct, bit-reproducible and graph-safe (tests/test_gpu_enc_stage.py), but NOT yet faster
-# than the per-launch path at B = 8 -- 87 / 85 us per Block at stages 3 / 4 against 80 / 63 us (profiles/r04_enc_stage_phases.txt;
-# DESIGN section 4 "Round 4" says where the time goes) -- so it is opt-in: CRD_ENC_PERSIST=1.
+# (stages 3 and 4 at 256 x 416).  Correct, bit-reproducible and graph-safe (tests/test_gpu_enc_stage.py).  Measured at B = 8
+# (profiles/r04_enc_stage_*.txt, DESIGN section 4 "Round 4"): stage 3 with one image row per workgroup 1207 us against 1275 for the
+# per-launch path in inference plans, 1308 against 1282 in training plans (which store every tensor the backward pass reads);
+# stage 4 378 against 318.  Whole inference forward with stage 3 persistent: B = 8 6.53 -> 6.40 ms, B = 16 10.07 -> 9.71 ms, B = 1
+# 3.30 -> 3.34 ms (16 workgroups).  Hence the default "auto": inference plans take it for stage 3 while 64 <= B x H <= 256;
+# CRD_ENC_PERSIST=1 forces it wherever the library covers the shape, =0 turns it off.
 ENC_ROWS_PER_WG = 0       # image rows per workgroup of the persistent stage kernel: 0 = the library chooses (tests force 1 / 2)
 
 
 def enc_persist_default():
-    return os.environ.get("CRD_ENC_PERSIST", "0") == "1"
+    v = os.environ.get("CRD_ENC_PERSIST", "auto")
+    return v if v in ("0", "1") else "auto"
 
 
 LATE_WGRAD = not _dev_flag("CRD_NO_LATE_WGRAD")
@@ -703,7 +707,8 @@ class Plan:
             self._defer = [] if GROUP_WGRAD else None
             pre = dh = None
             persist = None
-            if self.enc_persist and cfg.depths[s] > 0 and int(self.lib.crd_enc_stage_supported(B, Hs, Ws, Cs, hid, heads, sr)) > 0:
+            want = self.enc_persist == "1" or (self.enc_persist == "auto" and not tr and sr == 2 and 64 <= B * Hs <= 256)
+            if want and cfg.depths[s] > 0 and int(self.lib.crd_enc_stage_supported(B, Hs, Ws, Cs, hid, heads, sr)) > 0:
                 persist = []
             X_in = X
             for i in range(cfg.depths[s]):

@@ -237,6 +237,181 @@ int launch_reg(const ConvK& k0, GnIn gi, int B, hipStream_t st) {
   return CRD_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// Wide pointwise layers (Mlp.fc1 behind Block.norm2: K = C = 64 / 128 / 160 channels in, N = hidden = 512 / 1024 / 640 out;
+// src/models/simplified_attention.py:34-37).  These launches are ALL output: 54.5 / 27 MB of bf16 for 6.8 / 3.4 MB in, and the
+// tile-per-workgroup kernel above wrote them at 1.2-1.8 TB/s -- 37 / 25 us where a fill of the same bytes takes 10 / 6 us
+// (tools/bench_write.py, tools/sweep_igemm.sh: with the K loop compiled out 33 / 21 us remain: per-workgroup prologue, LDS-staged
+// epilogue with two barriers, 16 statistics atomics per 64 x 128 tile, 3-5 workgroups per CU).  Here instead:
+//   * a workgroup owns NB = 128 or 256 output columns of ONE sample and walks over 64-row tiles of it; its weights (NB x K) are
+//     loaded ONCE, straight into MFMA A-operand registers (rows = output channels) -- no LDS, no re-reads;
+//   * the raw fp32 rows of the NEXT tile are in flight (registers) while the current one is multiplied and stored; they are
+//     normalised on their way into a double-buffered bf16 LDS tile (row stride 4 x odd dwords: conflict-free 16-byte B reads);
+//   * a lane ends with ONE pixel and runs of 4 channels: v_permlane32_swap pairs them into 16-byte stores straight from the
+//     accumulators (k_conv3x3p's epilogue): no staging tile, no barrier;
+//   * GroupNorm sums of the output stay in registers across the workgroup's tiles and leave as 8-16 atomics per wave at the end.
+template <int KS, int WCT>
+__global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb, int R) {
+  constexpr int K = KS * 16, LDA = K + 8, G4 = K / 4, NB = 4 * WCT * 32, BM = 64;
+  typedef __attribute__((ext_vector_type(4))) float f32x4t;
+  typedef __attribute__((ext_vector_type(2))) unsigned u32x2t;
+  extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
+  bf16_t* sA = lds;                                              // [2][BM][LDA]
+  float2* tab = reinterpret_cast<float2*>(lds + 2 * BM * LDA);    // [K]
+  const int t = threadIdx.x, l = t & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int cb = blockIdx.x % ncb, rest = blockIdx.x / ncb;
+  const int b = rest / R, s0 = rest - b * R;
+  const int P = a.OHW, nT = (P + BM - 1) / BM;
+  const int n0 = cb * NB + wv * WCT * 32;
+  const bool store_xn = gi.xn != nullptr && cb == 0;
+
+  // ---- everything the first tile needs is requested before anything is waited for: weights, the table's inputs, tile 0
+  bf16x8 wf[WCT][KS];
+#pragma unroll
+  for (int j = 0; j < WCT; ++j)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wf[j][ks] = *reinterpret_cast<const bf16x8*>(a.w + (long long)(n0 + j * 32 + (l & 31)) * K + ks * 16 + (l >> 5) * 8);
+  const float* xb = reinterpret_cast<const float*>(gi.x) + (long long)b * a.x_bstride;
+  f32x4t xr[KS];
+  auto load_tile = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int id = t + 256 * i, row = id / G4, g4 = id - row * G4;
+      int p = tile * BM + row;
+      p = p < P ? p : P - 1;
+      xr[i] = *reinterpret_cast<const f32x4t*>(xb + (long long)p * a.x_ld + g4 * 4);
+    }
+  };
+  auto store_tile = [&](int tile, int buf) {          // normalise -> bf16 -> LDS (and the stored copy the weight gradient reads)
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int id = t + 256 * i, row = id / G4, g4 = id - row * G4;
+      const f32x4t t0 = *reinterpret_cast<const f32x4t*>(tab + g4 * 4), t1 = *reinterpret_cast<const f32x4t*>(tab + g4 * 4 + 2);
+      const f32x4t v = xr[i];
+      u32x2t q;
+      q[0] = pack_bf2(v[0] * t0[0] + t0[1], v[1] * t0[2] + t0[3]);
+      q[1] = pack_bf2(v[2] * t1[0] + t1[1], v[3] * t1[2] + t1[3]);
+      *reinterpret_cast<u32x2t*>(sA + (buf * BM + row) * LDA + g4 * 4) = q;
+      const int p = tile * BM + row;
+      if (store_xn && p < P) *reinterpret_cast<u32x2t*>(gi.xn + (long long)b * gi.xn_bstride + (long long)p * gi.xn_ld + g4 * 4) = q;
+    }
+  };
+  if (s0 < nT) load_tile(s0);
+  build_table(a, gi, b, tab);
+  __syncthreads();
+  if (s0 >= nT) return;
+  store_tile(s0, 0);
+  __syncthreads();
+
+  float st_s[WCT][2], st_q[WCT][2];
+#pragma unroll
+  for (int j = 0; j < WCT; ++j) st_s[j][0] = st_s[j][1] = st_q[j][0] = st_q[j][1] = 0.f;
+  int le = l;
+  asm volatile("" : "+v"(le));
+  const int half = le >> 5, px = le & 31;
+  bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
+
+  int buf = 0;
+  for (int tile = s0; tile < nT; tile += R, buf ^= 1) {
+    const int nxt = tile + R;
+    if (nxt < nT) load_tile(nxt);                                   // in flight during this tile's MFMAs and stores
+    f32x16 acc[2][WCT];
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt)
+#pragma unroll
+      for (int j = 0; j < WCT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[rt][j][r] = 0.f;
+    const bf16_t* sa = sA + buf * BM * LDA;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        const bf16x8 bfr = *reinterpret_cast<const bf16x8*>(sa + (rt * 32 + (l & 31)) * LDA + ks * 16 + (l >> 5) * 8);
+#pragma unroll
+        for (int j = 0; j < WCT; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][ks], bfr, acc[rt][j], 0, 0, 0);
+      }
+    // ---- epilogue: straight from the accumulators (lane = pixel px of row tile rt; channels (r&3) + 8 (r>>2) + 4 half)
+#pragma unroll
+    for (int rt = 0; rt < 2; ++rt) {
+      const int p = tile * BM + rt * 32 + px;
+      const bool pok = p < P;
+      bf16_t* row = yb + (long long)p * a.y_ld + n0 + half * 8;
+#pragma unroll
+      for (int j = 0; j < WCT; ++j) {
+        uint32_t d[4][2];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          f32x4t bv = {0.f, 0.f, 0.f, 0.f};
+          if (a.bias) bv = *reinterpret_cast<const f32x4t*>(a.bias + (long long)b * a.bias_bstride + n0 + j * 32 + 8 * g4 + 4 * half);
+          d[g4][0] = pack_bf2(acc[rt][j][4 * g4] + bv[0], acc[rt][j][4 * g4 + 1] + bv[1]);
+          d[g4][1] = pack_bf2(acc[rt][j][4 * g4 + 2] + bv[2], acc[rt][j][4 * g4 + 3] + bv[3]);
+          if (pok) {
+            const float v0 = bf_lo(d[g4][0]), v1 = bf_hi(d[g4][0]), v2 = bf_lo(d[g4][1]), v3 = bf_hi(d[g4][1]);
+            st_s[j][g4 >> 1] += (v0 + v1) + (v2 + v3);
+            st_q[j][g4 >> 1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+          }
+        }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          auto r0 = __builtin_amdgcn_permlane32_swap(d[2 * pr][0], d[2 * pr + 1][0], false, false);
+          auto r1 = __builtin_amdgcn_permlane32_swap(d[2 * pr][1], d[2 * pr + 1][1], false, false);
+          if (pok) *reinterpret_cast<uint4*>(row + j * 32 + pr * 16) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+        }
+      }
+    }
+    if (nxt < nT) store_tile(nxt, buf ^ 1);
+    __syncthreads();
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int j = 0; j < WCT; ++j)
+#pragma unroll
+      for (int sl = 0; sl < 2; ++sl) {
+        const float sv = wave_sum(st_s[j][sl]), sq = wave_sum(st_q[j][sl]);
+        if (l == 0) {
+          crd_sum_t* dst = a.stats + ((long long)b * a.G16 + ((n0 + j * 32) >> 4) + sl) * 2;
+          stat_add(dst, sv);
+          stat_add(dst + 1, sq);
+        }
+      }
+  }
+}
+
+// Does the wide kernel take this launch?  (Mlp.fc1 of every encoder stage at the benchmark sizes.)
+bool pw_wide_applies(const ConvK& k, const GnIn& gi, int act_in) {
+  static int on = -1;
+  if (on < 0) on = crd_dev_int("CRD_PW_WIDE", 1);
+  const bool shape = k.KW == 1 && k.stride == 1 && (k.Cin == 64 || k.Cin == 128 || k.Cin == 160) && k.Ktot == k.Cin && k.Cout >= 256 &&
+                     k.Cout % 128 == 0 && k.x_ld % 4 == 0;
+  return on && shape && gi.x_f32 && act_in == 0 && !k.y_f32 && !k.res && !k.act && !k.accumulate && !k.chan && k.vec_ok &&
+         (k.y_ld & 7) == 0 && (!k.bias || ((reinterpret_cast<uintptr_t>(k.bias) & 15) == 0 && k.bias_bstride % 4 == 0)) &&
+         (!gi.xn || gi.xn_ld % 4 == 0) && (reinterpret_cast<uintptr_t>(k.w) & 15) == 0;
+}
+
+template <int KS, int WCT>
+int launch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
+  constexpr int K = KS * 16, NB = 4 * WCT * 32;
+  const int ncb = k.Cout / NB, nT = cdiv(k.OHW, 64);
+  int rmax = 512 / (ncb * B);                       // two workgroups per CU
+  if (rmax < 1) rmax = 1;
+  const int tpw = cdiv(nT, rmax);                   // tiles per workgroup, then as few streams as that needs (balanced)
+  const int R = cdiv(nT, tpw);
+  const size_t lds = (size_t)2 * 64 * (K + 8) * 2 + (size_t)K * sizeof(float2);
+  hipLaunchKernelGGL((k_gn_pw_wide<KS, WCT>), dim3(ncb * R * B), dim3(256), lds, st, k, gi, ncb, R);
+  CRD_LAUNCH_CHECK("crd_gn_conv(wide pointwise)");
+  return CRD_OK;
+}
+
+int dispatch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
+  const bool w2 = k.Cout % 256 == 0;                // 256 columns per workgroup where they divide the layer (640 = 5 x 128)
+  if (k.Cin == 64) return w2 ? launch_pw_wide<4, 2>(k, gi, B, st) : launch_pw_wide<4, 1>(k, gi, B, st);
+  if (k.Cin == 128) return w2 ? launch_pw_wide<8, 2>(k, gi, B, st) : launch_pw_wide<8, 1>(k, gi, B, st);
+  return launch_pw_wide<10, 1>(k, gi, B, st);        // (K = 160 with 256 columns would not fit the register file: 80 weight + 64 accumulator + 40 prefetch registers)
+}
+
 template <int XF32, int ACT>
 int dispatch(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
   // 64 x 64 tiles when 64 x 128 ones would not cover the chip (as crd_conv_igemm chooses)
@@ -291,6 +466,7 @@ extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_st
   gi.count = (float)d->IH * (float)d->IW * 16.f * (float)n->gmul;
   gi.xn = reinterpret_cast<bf16_t*>(n->xn); gi.xn_ld = n->xn_ld; gi.xn_bstride = (long long)d->IH * d->IW * n->xn_ld;
   hipStream_t st = as_stream(stream);
+  if (pw_wide_applies(k, gi, n->act)) return dispatch_pw_wide(k, gi, d->B, st);
   if (n->x_f32) return n->act ? dispatch<1, 1>(k, gi, d->B, st) : dispatch<1, 0>(k, gi, d->B, st);
   return n->act ? dispatch<0, 1>(k, gi, d->B, st) : dispatch<0, 0>(k, gi, d->B, st);
 }

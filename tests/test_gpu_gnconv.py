@@ -44,6 +44,10 @@ CASES = [
     (8, 512, 64, 104, 64, 1, 8, 1, 0, "res"),             # fc2 stage 1 at the benchmark size
     (2, 320, 6, 10, 96, 1, 1, 0, 1, "stats"),             # fp32 input with five K-slabs (the register path has no K limit)
     (1, 64, 7, 9, 40, 1, 1, 0, 1, "plain"),               # ragged rows and columns on a single workgroup
+    (8, 64, 64, 104, 512, 1, 1, 0, 1, "stats"),           # fc1 stage 1 at the benchmark size (the wide pointwise kernel, 4 tiles per workgroup)
+    (3, 128, 9, 11, 1024, 1, 1, 0, 1, "plain"),           # wide kernel: ragged rows (99 pixels: two tiles, the second 35 rows), no sums
+    (2, 160, 16, 26, 640, 1, 1, 0, 1, "stats"),           # fc1 stage 3 at the benchmark size: 128-column workgroups, 6.5 tiles
+    (5, 64, 20, 30, 256, 1, 1, 0, 1, "stats"),            # wide kernel: one column block, odd batch, 600 pixels
 ]
 
 

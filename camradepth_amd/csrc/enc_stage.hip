@@ -328,6 +328,7 @@ __device__ __attribute__((noinline)) float2 dw_stencil(lds_bf16* sHc, const lds_
 #ifdef CRD_ENC_PROF
 // per-phase wall-clock ticks (100 MHz) of workgroup 0, summed over the blocks of a launch (tools/prof_enc_stage.py --phases)
 __device__ unsigned long long g_enc_prof[32];
+__device__ unsigned g_enc_place[512];           // per workgroup of the last launch: XCC id << 16 | HW_ID bits (CU, SE)
 #define ENC_STAMP(i) do { if (blockIdx.x == 0 && tid == 0) { const unsigned long long now_ = wall_clock64(); g_enc_prof[i] += now_ - prof_last; prof_last = now_; } } while (0)
 #else
 #define ENC_STAMP(i) do {} while (0)
@@ -363,6 +364,14 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
   const int tid = threadIdx.x;
 #ifdef CRD_ENC_PROF
   unsigned long long prof_last = wall_clock64();
+#endif
+#ifdef CRD_ENC_PROF
+  if (tid == 0 && blockIdx.x < 512) {
+    unsigned xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    g_enc_place[blockIdx.x] = (xcc & 0xf) << 16 | (hw & 0xffff);
+  }
 #endif
   int t = tid, l = tid & 63;                 // re-derived from an opaque copy at the head of every phase (opq above)
 #define NEWPHASE() do { t = opq(tid); l = t & 63; } while (0)
@@ -1091,6 +1100,7 @@ int launch_stage(const crd_enc_stage_desc* d, hipStream_t st) {
 }  // namespace
 
 #ifdef CRD_ENC_PROF
+extern "C" int crd_dbg_enc_place(unsigned* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_place), sizeof(g_enc_place)); }
 extern "C" int crd_dbg_enc_prof(unsigned long long* out, int reset) {
   int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_enc_prof), sizeof(g_enc_prof));
   if (reset) { unsigned long long z[32] = {0}; rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(g_enc_prof), z, sizeof(z)); }

@@ -247,17 +247,23 @@ int launch_reg(const ConvK& k0, GnIn gi, int B, hipStream_t st) {
 //     loaded ONCE, straight into MFMA A-operand registers (rows = output channels) -- no LDS, no re-reads;
 //   * the raw fp32 rows of the NEXT tile are in flight (registers) while the current one is multiplied and stored; they are
 //     normalised on their way into a double-buffered bf16 LDS tile (row stride 4 x odd dwords: conflict-free 16-byte B reads);
-//   * a lane ends with ONE pixel and runs of 4 channels: v_permlane32_swap pairs them into 16-byte stores straight from the
-//     accumulators (k_conv3x3p's epilogue): no staging tile, no barrier;
+//   * a wave turns its 32-pixel x 32 WCT-column strip through a private piece of LDS (no workgroup barrier) and stores whole
+//     128-byte rows: 8 lanes per row, eight full lines per wave instruction;
 //   * GroupNorm sums of the output stay in registers across the workgroup's tiles and leave as 8-16 atomics per wave at the end.
-template <int KS, int WCT>
+// XF = 1: the fp32 rows behind a GroupNorm (fc1); XF = 0: plain bf16 rows (fc2's data gradient at stages 1-2: d(h3) = W2^T d(x2), the
+// same shape transposed -- crd_conv_igemm sends it here).
+template <int KS, int WCT, int XF>
 __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb, int R) {
   constexpr int K = KS * 16, LDA = K + 8, G4 = K / 4, NB = 4 * WCT * 32, BM = 64;
+  constexpr int G8 = K / 8, NX = XF ? KS : (KS + 1) / 2;          // 16-byte granules per row / per thread
+  constexpr int LDT = WCT * 32 + 8;                                // per-wave transposition strip [32 pixels][LDT] (rows of 16 x odd bytes)
+  constexpr int GPRW = WCT * 4, RPP = 64 / GPRW;                   // 16-byte granules per strip row; strip rows per store instruction
   typedef __attribute__((ext_vector_type(4))) float f32x4t;
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2t;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   bf16_t* sA = lds;                                              // [2][BM][LDA]
   float2* tab = reinterpret_cast<float2*>(lds + 2 * BM * LDA);    // [K]
+  bf16_t* sT = reinterpret_cast<bf16_t*>(tab + K);                 // [4 waves][32][LDT]
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int cb = blockIdx.x % ncb, rest = blockIdx.x / ncb;
@@ -274,17 +280,35 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
     for (int ks = 0; ks < KS; ++ks)
       wf[j][ks] = *reinterpret_cast<const bf16x8*>(a.w + (long long)(n0 + j * 32 + (l & 31)) * K + ks * 16 + (l >> 5) * 8);
   const float* xb = reinterpret_cast<const float*>(gi.x) + (long long)b * a.x_bstride;
-  f32x4t xr[KS];
+  const bf16_t* xh = reinterpret_cast<const bf16_t*>(gi.x) + (long long)b * a.x_bstride;
+  f32x4t xr[NX];
   auto load_tile = [&](int tile) {
 #pragma unroll
-    for (int i = 0; i < KS; ++i) {
-      const int id = t + 256 * i, row = id / G4, g4 = id - row * G4;
-      int p = tile * BM + row;
-      p = p < P ? p : P - 1;
-      xr[i] = *reinterpret_cast<const f32x4t*>(xb + (long long)p * a.x_ld + g4 * 4);
+    for (int i = 0; i < NX; ++i) {
+      if (XF) {
+        const int id = t + 256 * i, row = id / G4, g4 = id - row * G4;
+        int p = tile * BM + row;
+        p = p < P ? p : P - 1;
+        xr[i] = *reinterpret_cast<const f32x4t*>(xb + (long long)p * a.x_ld + g4 * 4);
+      } else {
+        int id = t + 256 * i;
+        id = id < BM * G8 ? id : BM * G8 - 1;           // (K = 160: 1280 granules on 5 x 256 threads exactly; K = 64 / 128 too)
+        const int row = id / G8, g8 = id - row * G8;
+        int p = tile * BM + row;
+        p = p < P ? p : P - 1;
+        xr[i] = *reinterpret_cast<const f32x4t*>(xh + (long long)p * a.x_ld + g8 * 8);
+      }
     }
   };
   auto store_tile = [&](int tile, int buf) {          // normalise -> bf16 -> LDS (and the stored copy the weight gradient reads)
+    if (!XF) {
+#pragma unroll
+      for (int i = 0; i < NX; ++i) {
+        const int id = t + 256 * i;
+        if (id < BM * G8) { const int row = id / G8, g8 = id - row * G8; *reinterpret_cast<f32x4t*>(sA + (buf * BM + row) * LDA + g8 * 8) = xr[i]; }
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       const int id = t + 256 * i, row = id / G4, g4 = id - row * G4;
@@ -299,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
     }
   };
   if (s0 < nT) load_tile(s0);
-  build_table(a, gi, b, tab);
+  if (XF) build_table(a, gi, b, tab);
   __syncthreads();
   if (s0 >= nT) return;
   store_tile(s0, 0);
@@ -333,34 +357,42 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
 #pragma unroll
         for (int j = 0; j < WCT; ++j) acc[rt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j][ks], bfr, acc[rt][j], 0, 0, 0);
       }
-    // ---- epilogue: straight from the accumulators (lane = pixel px of row tile rt; channels (r&3) + 8 (r>>2) + 4 half)
+    // ---- epilogue.  A lane holds pixel px of row tile rt and the channels (r&3) + 8 (r>>2) + 4 half of each 32-column tile: stored
+    // from there, a wave instruction wrote 32-byte pieces of 32 different rows, four instructions per 128-byte line, and the
+    // launch stayed at 2.2 TB/s (64 -> 512 at 64 x 104 x 8: 27.8 us).  So the wave turns its 32 x (32 WCT) strip through a PRIVATE
+    // piece of LDS (no workgroup barrier: a wave's LDS operations execute in order) and stores whole rows: 8 lanes = 128 bytes.
+    bf16_t* T = sT + wv * 32 * LDT;
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt) {
-      const int p = tile * BM + rt * 32 + px;
-      const bool pok = p < P;
-      bf16_t* row = yb + (long long)p * a.y_ld + n0 + half * 8;
+      const bool pok = tile * BM + rt * 32 + px < P;
 #pragma unroll
       for (int j = 0; j < WCT; ++j) {
-        uint32_t d[4][2];
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
           f32x4t bv = {0.f, 0.f, 0.f, 0.f};
           if (a.bias) bv = *reinterpret_cast<const f32x4t*>(a.bias + (long long)b * a.bias_bstride + n0 + j * 32 + 8 * g4 + 4 * half);
-          d[g4][0] = pack_bf2(acc[rt][j][4 * g4] + bv[0], acc[rt][j][4 * g4 + 1] + bv[1]);
-          d[g4][1] = pack_bf2(acc[rt][j][4 * g4 + 2] + bv[2], acc[rt][j][4 * g4 + 3] + bv[3]);
+          u32x2t d;
+          d[0] = pack_bf2(acc[rt][j][4 * g4] + bv[0], acc[rt][j][4 * g4 + 1] + bv[1]);
+          d[1] = pack_bf2(acc[rt][j][4 * g4 + 2] + bv[2], acc[rt][j][4 * g4 + 3] + bv[3]);
           if (pok) {
-            const float v0 = bf_lo(d[g4][0]), v1 = bf_hi(d[g4][0]), v2 = bf_lo(d[g4][1]), v3 = bf_hi(d[g4][1]);
+            const float v0 = bf_lo(d[0]), v1 = bf_hi(d[0]), v2 = bf_lo(d[1]), v3 = bf_hi(d[1]);
             st_s[j][g4 >> 1] += (v0 + v1) + (v2 + v3);
             st_q[j][g4 >> 1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
           }
-        }
-#pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-          auto r0 = __builtin_amdgcn_permlane32_swap(d[2 * pr][0], d[2 * pr + 1][0], false, false);
-          auto r1 = __builtin_amdgcn_permlane32_swap(d[2 * pr][1], d[2 * pr + 1][1], false, false);
-          if (pok) *reinterpret_cast<uint4*>(row + j * 32 + pr * 16) = make_uint4(r0[0], r1[0], r0[1], r1[1]);
+          *reinterpret_cast<u32x2t*>(T + px * LDT + j * 32 + 8 * g4 + 4 * half) = d;
         }
       }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int it = 0; it < 32 / RPP; ++it) {
+        const int r = it * RPP + le / GPRW, gq = le % GPRW;
+        const int p = tile * BM + rt * 32 + r;
+        const uint4 u = *reinterpret_cast<const uint4*>(T + r * LDT + gq * 8);
+        if (p < P) *reinterpret_cast<uint4*>(yb + (long long)p * a.y_ld + n0 + gq * 8) = u;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
     if (nxt < nT) store_tile(nxt, buf ^ 1);
     __syncthreads();
@@ -391,7 +423,7 @@ bool pw_wide_applies(const ConvK& k, const GnIn& gi, int act_in) {
          (!gi.xn || gi.xn_ld % 4 == 0) && (reinterpret_cast<uintptr_t>(k.w) & 15) == 0;
 }
 
-template <int KS, int WCT>
+template <int KS, int WCT, int XF>
 int launch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
   constexpr int K = KS * 16, NB = 4 * WCT * 32;
   const int ncb = k.Cout / NB, nT = cdiv(k.OHW, 64);
@@ -399,17 +431,18 @@ int launch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
   if (rmax < 1) rmax = 1;
   const int tpw = cdiv(nT, rmax);                   // tiles per workgroup, then as few streams as that needs (balanced)
   const int R = cdiv(nT, tpw);
-  const size_t lds = (size_t)2 * 64 * (K + 8) * 2 + (size_t)K * sizeof(float2);
-  hipLaunchKernelGGL((k_gn_pw_wide<KS, WCT>), dim3(ncb * R * B), dim3(256), lds, st, k, gi, ncb, R);
+  const size_t lds = (size_t)2 * 64 * (K + 8) * 2 + (size_t)K * sizeof(float2) + (size_t)4 * 32 * (WCT * 32 + 8) * 2;
+  hipLaunchKernelGGL((k_gn_pw_wide<KS, WCT, XF>), dim3(ncb * R * B), dim3(256), lds, st, k, gi, ncb, R);
   CRD_LAUNCH_CHECK("crd_gn_conv(wide pointwise)");
   return CRD_OK;
 }
 
+template <int XF>
 int dispatch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
   const bool w2 = k.Cout % 256 == 0;                // 256 columns per workgroup where they divide the layer (640 = 5 x 128)
-  if (k.Cin == 64) return w2 ? launch_pw_wide<4, 2>(k, gi, B, st) : launch_pw_wide<4, 1>(k, gi, B, st);
-  if (k.Cin == 128) return w2 ? launch_pw_wide<8, 2>(k, gi, B, st) : launch_pw_wide<8, 1>(k, gi, B, st);
-  return launch_pw_wide<10, 1>(k, gi, B, st);        // (K = 160 with 256 columns would not fit the register file: 80 weight + 64 accumulator + 40 prefetch registers)
+  if (k.Cin == 64) return w2 ? launch_pw_wide<4, 2, XF>(k, gi, B, st) : launch_pw_wide<4, 1, XF>(k, gi, B, st);
+  if (k.Cin == 128) return w2 ? launch_pw_wide<8, 2, XF>(k, gi, B, st) : launch_pw_wide<8, 1, XF>(k, gi, B, st);
+  return launch_pw_wide<10, 1, XF>(k, gi, B, st);        // (K = 160 with 256 columns would not fit the register file: 80 weight + 64 accumulator + 40 prefetch registers)
 }
 
 template <int XF32, int ACT>
@@ -421,6 +454,22 @@ int dispatch(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
 }
 
 }  // namespace
+
+// crd_conv_igemm's wide pointwise launches without a GroupNorm in front (igemm.hip): plain bf16 rows in, bf16 out, optional sums
+bool crd_pw_wide_plain_applicable(const ConvK& k) {
+  static int on = -1;
+  if (on < 0) on = crd_dev_int("CRD_PW_WIDE", 1);
+  return on && k.KW == 1 && k.stride == 1 && k.pad == 0 && (k.Cin == 64 || k.Cin == 128 || k.Cin == 160) && k.Ktot == k.Cin && k.Cout >= 256 &&
+         k.Cout % 128 == 0 && (k.x_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && k.IH * k.IW == k.OHW && !k.y_f32 && !k.res &&
+         !k.act && !k.accumulate && !k.chan && !k.red_x && !k.stats_partial && k.out_mode == 0 && k.vec_ok && (k.y_ld & 7) == 0 &&
+         (!k.bias || ((reinterpret_cast<uintptr_t>(k.bias) & 15) == 0 && k.bias_bstride % 4 == 0)) && (reinterpret_cast<uintptr_t>(k.w) & 15) == 0;
+}
+int crd_pw_wide_plain(const ConvK& k, int B, hipStream_t st) {
+  GnIn gi;
+  gi.x = k.x; gi.x_f32 = 0; gi.stats = nullptr; gi.gmul = 1; gi.gamma = nullptr; gi.beta = nullptr; gi.count = 1.f;
+  gi.xn = nullptr; gi.xn_ld = 0; gi.xn_bstride = 0;
+  return dispatch_pw_wide<0>(k, gi, B, st);
+}
 
 extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stream) {
   CRD_CHECK_ARG(d && n && d->x && d->w && d->y && n->stats && n->gamma && n->beta, "crd_gn_conv: null pointer");
@@ -466,7 +515,7 @@ extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_st
   gi.count = (float)d->IH * (float)d->IW * 16.f * (float)n->gmul;
   gi.xn = reinterpret_cast<bf16_t*>(n->xn); gi.xn_ld = n->xn_ld; gi.xn_bstride = (long long)d->IH * d->IW * n->xn_ld;
   hipStream_t st = as_stream(stream);
-  if (pw_wide_applies(k, gi, n->act)) return dispatch_pw_wide(k, gi, d->B, st);
+  if (pw_wide_applies(k, gi, n->act)) return dispatch_pw_wide<1>(k, gi, d->B, st);
   if (n->x_f32) return n->act ? dispatch<1, 1>(k, gi, d->B, st) : dispatch<1, 0>(k, gi, d->B, st);
   return n->act ? dispatch<0, 1>(k, gi, d->B, st) : dispatch<0, 0>(k, gi, d->B, st);
 }

@@ -12,6 +12,8 @@
 
 using namespace crdk;
 int crd_conv3x3_halo(const ConvK& k, int B, hipStream_t st, long long partial_cap);   // conv3x3.hip
+bool crd_pw_wide_plain_applicable(const ConvK& k);                                      // gngemm.hip: wide pointwise layers
+int crd_pw_wide_plain(const ConvK& k, int B, hipStream_t st);
 
 namespace crdk {
 __global__ __launch_bounds__(256) void k_stats_finalize(const float* partial, int n_tiles, int G16, crd_sum_t* stats) {
@@ -313,6 +315,8 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == 0 && d->IH == d->OH && d->IW == d->OW &&
       d->IW >= 32 && d->IH >= 8)
     return crd_conv3x3_halo(k, d->B, st, pcap);
+  // pointwise layers that are all output (fc2's data gradient at encoder stages 1-2): the register-resident-weight kernel
+  if (d->KH == 1 && d->KW == 1 && crd_pw_wide_plain_applicable(k)) return crd_pw_wide_plain(k, d->B, st);
   {   // developer override of the tile choice below (tools/bench_small_gemm.py sweeps it)
     static int force = -1;
     if (force < 0) force = crd_dev_int("CRD_IGEMM_FORCE", 0);

@@ -81,15 +81,17 @@ GN_CONV_MAXROWS = _dev_int("CRD_GN_CONV_MAXROWS", 1 << 30)   # pixels x batch up
 # (stages 3 and 4 at 256 x 416).  Correct, bit-reproducible and graph-safe (tests/test_gpu_enc_stage.py).  Measured at B = 8
 # (profiles/r04_enc_stage_*.txt, DESIGN section 4 "Round 4"): stage 3 with one image row per workgroup 1207 us against 1275 for the
 # per-launch path in inference plans, 1308 against 1282 in training plans (which store every tensor the backward pass reads);
-# stage 4 378 against 318.  Whole inference forward with stage 3 persistent: B = 8 6.53 -> 6.40 ms, B = 16 10.07 -> 9.71 ms, B = 1
-# 3.30 -> 3.34 ms (16 workgroups).  Hence the default "auto": inference plans take it for stage 3 while 64 <= B x H <= 256;
-# CRD_ENC_PERSIST=1 forces it wherever the library covers the shape, =0 turns it off.
+# stage 4 378 against 318.  Whole inference forward with stage 3 persistent ("auto": inference plans, stage 3, 64 <= B x H <= 256):
+# B = 8 6.12 -> 6.01 ms, B = 16 10.07 -> 9.71 ms -- in most processes.  In 4 of 9 `bench.py --inference` processes the same graph took
+# 7.7-7.8 ms (the per-launch path: 6.10-6.13 in 7 of 7): a slow mode per process that the eager / per-stage measurements never showed
+# and that is not the workgroup -> XCD placement (tools/enc_place.py: every sample's workgroups share an XCC in every process).
+# Until that is understood the persistent path stays opt-in: CRD_ENC_PERSIST=1 (everywhere the library covers the shape) or =auto.
 ENC_ROWS_PER_WG = 0       # image rows per workgroup of the persistent stage kernel: 0 = the library chooses (tests force 1 / 2)
 
 
 def enc_persist_default():
-    v = os.environ.get("CRD_ENC_PERSIST", "auto")
-    return v if v in ("0", "1") else "auto"
+    v = os.environ.get("CRD_ENC_PERSIST", "0")
+    return v if v in ("0", "1", "auto") else "0"
 
 
 LATE_WGRAD = not _dev_flag("CRD_NO_LATE_WGRAD")

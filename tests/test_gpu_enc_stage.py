@@ -5,8 +5,7 @@ Both paths implement the same arithmetic with the same rounding points (bf16 GEM
 GroupNorm from fixed-point sums); they differ in the ORDER of fp32 partial sums, so tensors agree to a few bf16 ulps on the
 first Block and drift apart at the rate the chaotic max-pool attention amplifies that; the bounds below are on
 the FIRST block of each stage (tight) and on the stage output (loose), the arg-max table agrees except at near-ties.  The
-persistent path is the default only for stage 3 of inference plans (engine.enc_persist_default; CRD_ENC_PERSIST=1 / 0 force it on / off,
-as the tests here do); test_persistent_stage_vs_oracle below holds it to the
+persistent path is opt-in (engine.enc_persist_default; CRD_ENC_PERSIST=1 / 0 as the tests here set it); test_persistent_stage_vs_oracle below holds it to the
 oracle directly."""
 import dataclasses
 import os

@@ -104,6 +104,11 @@ CASES = [
     (3, 256, 256, 4, 7, 256, 1, 1, 0),
     (2, 64, 64, 20, 26, 512, 1, 1, 0),
     (1, 640, 640, 6, 7, 160, 1, 1, 0),
+    # wide pointwise layers (k_gn_pw_wide, plain rows): ragged tiles, 256- and 128-column workgroups, atomic sums (odd pixel counts)
+    (3, 128, 128, 9, 11, 1024, 1, 1, 0),
+    (2, 64, 64, 21, 31, 512, 1, 1, 0),
+    (2, 160, 160, 15, 27, 640, 1, 1, 0),
+    (5, 64, 64, 13, 17, 384, 1, 1, 0),
     # 3x3 / stride 1 on grids >= 32 wide: halo-tile kernel (conv3x3.hip), all Cout tile variants, ragged borders
     (2, 136, 136, 19, 45, 96, 3, 1, 1),
     (1, 232, 232, 8, 64, 64, 3, 1, 1),
@@ -224,6 +229,9 @@ DGRAD_CASES = [
     (1, 128, 9, 64, 32, 3, 1, 1),
     (1, 296, 9, 33, 128, 3, 1, 1),       # 160-column tiles: N = 296 (two tiles), 136 (one)
     (2, 136, 17, 40, 96, 3, 1, 1),
+    (2, 512, 20, 26, 64, 1, 1, 0),       # Mlp.fc2's data gradient (64 -> 512 columns): the wide pointwise kernel
+    (2, 1024, 9, 11, 128, 1, 1, 0),
+    (1, 640, 16, 26, 160, 1, 1, 0),
 ]
 
 

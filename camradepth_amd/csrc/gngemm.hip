@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
   constexpr int GPRW = WCT * 4, RPP = 64 / GPRW;                   // 16-byte granules per strip row; strip rows per store instruction
   typedef __attribute__((ext_vector_type(4))) float f32x4t;
   typedef __attribute__((ext_vector_type(2))) unsigned u32x2t;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4r;
   extern __shared__ __attribute__((aligned(16))) bf16_t lds[];
   bf16_t* sA = lds;                                              // [2][BM][LDA]
   float2* tab = reinterpret_cast<float2*>(lds + 2 * BM * LDA);    // [K]
@@ -281,8 +282,9 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
       wf[j][ks] = *reinterpret_cast<const bf16x8*>(a.w + (long long)(n0 + j * 32 + (l & 31)) * K + ks * 16 + (l >> 5) * 8);
   const float* xb = reinterpret_cast<const float*>(gi.x) + (long long)b * a.x_bstride;
   const bf16_t* xh = reinterpret_cast<const bf16_t*>(gi.x) + (long long)b * a.x_bstride;
-  f32x4t xr[NX];
-  auto load_tile = [&](int tile) {
+  constexpr bool D2 = KS <= 8;                         // two tiles ahead (K = 160: 80 more registers would spill; its workgroups have 1-2 tiles)
+  f32x4t xr0[NX], xr1[D2 ? NX : 1];                    // rows of the tiles one and two steps ahead (in flight)
+  auto load_tile = [&](int tile, f32x4t (&xr)[NX]) {
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
       if (XF) {
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
       }
     }
   };
-  auto store_tile = [&](int tile, int buf) {          // normalise -> bf16 -> LDS (and the stored copy the weight gradient reads)
+  auto store_tile = [&](int tile, int buf, const f32x4t (&xr)[NX]) {          // normalise -> bf16 -> LDS (and the stored copy the weight gradient reads)
     if (!XF) {
 #pragma unroll
       for (int i = 0; i < NX; ++i) {
@@ -322,12 +324,16 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
       if (store_xn && p < P) *reinterpret_cast<u32x2t*>(gi.xn + (long long)b * gi.xn_bstride + (long long)p * gi.xn_ld + g4 * 4) = q;
     }
   };
-  if (s0 < nT) load_tile(s0);
+  // invariant at the head of step(tile, P): sA[P] holds `tile`, xr(P^1) (in flight) tile + R, xr(P) tile + 2R.  One tile ahead was
+  // not enough: a tile's MFMAs and stores take ~1 us, a first-touch row ~3 (24.7 us per launch at 64 -> 512, 64 x 104 x 8)
+  if (s0 < nT) load_tile(s0, xr0);
+  if constexpr (D2) { if (s0 + R < nT) load_tile(s0 + R, xr1); }
   if (XF) build_table(a, gi, b, tab);
   __syncthreads();
   if (s0 >= nT) return;
-  store_tile(s0, 0);
-  __syncthreads();
+  store_tile(s0, 0, xr0);
+  if (D2 && s0 + 2 * R < nT) load_tile(s0 + 2 * R, xr0);
+  lds_barrier();
 
   float st_s[WCT][2], st_q[WCT][2];
 #pragma unroll
@@ -335,19 +341,28 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
   int le = l;
   asm volatile("" : "+v"(le));
   const int half = le >> 5, px = le & 31;
+  // the bias of this lane's 16 channels per column tile, once (as loads inside the epilogue they were waited for one by one with
+  // vmcnt(0), which also drained the rows in flight and the tile's stores): the accumulators start from it
+  f32x4t bvr[WCT][4];
+#pragma unroll
+  for (int j = 0; j < WCT; ++j)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      bvr[j][g4] = f32x4t{0.f, 0.f, 0.f, 0.f};
+      if (a.bias) bvr[j][g4] = *reinterpret_cast<const f32x4t*>(a.bias + (long long)b * a.bias_bstride + n0 + j * 32 + 8 * g4 + 4 * half);
+    }
   bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
 
-  int buf = 0;
-  for (int tile = s0; tile < nT; tile += R, buf ^= 1) {
+  auto step = [&](int tile, int buf, f32x4t (&xnext)[NX]) __attribute__((always_inline)) {
     const int nxt = tile + R;
-    if (nxt < nT) load_tile(nxt);                                   // in flight during this tile's MFMAs and stores
+    if (!D2 && nxt < nT) load_tile(nxt, xnext);
     f32x16 acc[2][WCT];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
 #pragma unroll
       for (int j = 0; j < WCT; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][j][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[rt][j][r] = bvr[j][r >> 2][r & 3];
     const bf16_t* sa = sA + buf * BM * LDA;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
@@ -369,11 +384,9 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
       for (int j = 0; j < WCT; ++j) {
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          f32x4t bv = {0.f, 0.f, 0.f, 0.f};
-          if (a.bias) bv = *reinterpret_cast<const f32x4t*>(a.bias + (long long)b * a.bias_bstride + n0 + j * 32 + 8 * g4 + 4 * half);
           u32x2t d;
-          d[0] = pack_bf2(acc[rt][j][4 * g4] + bv[0], acc[rt][j][4 * g4 + 1] + bv[1]);
-          d[1] = pack_bf2(acc[rt][j][4 * g4 + 2] + bv[2], acc[rt][j][4 * g4 + 3] + bv[3]);
+          d[0] = pack_bf2(acc[rt][j][4 * g4], acc[rt][j][4 * g4 + 1]);
+          d[1] = pack_bf2(acc[rt][j][4 * g4 + 2], acc[rt][j][4 * g4 + 3]);
           if (pok) {
             const float v0 = bf_lo(d[0]), v1 = bf_hi(d[0]), v2 = bf_lo(d[1]), v3 = bf_hi(d[1]);
             st_s[j][g4 >> 1] += (v0 + v1) + (v2 + v3);
@@ -388,14 +401,21 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
       for (int it = 0; it < 32 / RPP; ++it) {
         const int r = it * RPP + le / GPRW, gq = le % GPRW;
         const int p = tile * BM + rt * 32 + r;
-        const uint4 u = *reinterpret_cast<const uint4*>(T + r * LDT + gq * 8);
-        if (p < P) *reinterpret_cast<uint4*>(yb + (long long)p * a.y_ld + n0 + gq * 8) = u;
+        // (ext_vector_type accesses: through HIP's uint4 struct the compiler split the LDS read into dwords and put vmcnt(0) in front)
+        const u32x4r u = *reinterpret_cast<const u32x4r*>(__builtin_assume_aligned(T + r * LDT + gq * 8, 16));
+        if (p < P && (!(a.dbg & 32) || u[0] == 0x12345u))
+          *reinterpret_cast<u32x4r*>(__builtin_assume_aligned(yb + (long long)p * a.y_ld + n0 + gq * 8, 16)) = u;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    if (nxt < nT) store_tile(nxt, buf ^ 1);
-    __syncthreads();
+    if (nxt < nT) store_tile(nxt, buf ^ 1, xnext);
+    if (D2 && nxt + 2 * R < nT) load_tile(nxt + 2 * R, xnext);
+    lds_barrier();          // (NOT __syncthreads(): its vmcnt(0) waits for the rows just requested and for this tile's stores -- 2 us per tile)
+  };
+  for (int tile = s0; tile < nT; tile += 2 * R) {
+    if constexpr (D2) step(tile, 0, xr1); else step(tile, 0, xr0);
+    if (tile + R < nT) step(tile + R, 1, xr0);
   }
   if (a.stats) {
 #pragma unroll
@@ -427,7 +447,8 @@ template <int KS, int WCT, int XF>
 int launch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
   constexpr int K = KS * 16, NB = 4 * WCT * 32;
   const int ncb = k.Cout / NB, nT = cdiv(k.OHW, 64);
-  int rmax = 512 / (ncb * B);                       // two workgroups per CU
+  const int wg_per_cu = crd_dev_int("CRD_PW_OCC", 2);
+  int rmax = 256 * wg_per_cu / (ncb * B);
   if (rmax < 1) rmax = 1;
   const int tpw = cdiv(nT, rmax);                   // tiles per workgroup, then as few streams as that needs (balanced)
   const int R = cdiv(nT, tpw);
@@ -439,7 +460,8 @@ int launch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
 
 template <int XF>
 int dispatch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
-  const bool w2 = k.Cout % 256 == 0;                // 256 columns per workgroup where they divide the layer (640 = 5 x 128)
+  // 128 columns per workgroup (256 measured 10 % slower: 27.2 vs 24.7 us at 64 -> 512 -- fewer, fatter workgroups hide less latency)
+  const bool w2 = k.Cout % 256 == 0 && crd_dev_int("CRD_PW_WCT2", 0);
   if (k.Cin == 64) return w2 ? launch_pw_wide<4, 2, XF>(k, gi, B, st) : launch_pw_wide<4, 1, XF>(k, gi, B, st);
   if (k.Cin == 128) return w2 ? launch_pw_wide<8, 2, XF>(k, gi, B, st) : launch_pw_wide<8, 1, XF>(k, gi, B, st);
   return launch_pw_wide<10, 1, XF>(k, gi, B, st);        // (K = 160 with 256 columns would not fit the register file: 80 weight + 64 accumulator + 40 prefetch registers)

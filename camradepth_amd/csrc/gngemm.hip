@@ -328,8 +328,7 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
   // not enough: a tile's MFMAs and stores take ~1 us, a first-touch row ~3 (24.7 us per launch at 64 -> 512, 64 x 104 x 8)
   if (s0 < nT) load_tile(s0, xr0);
   if constexpr (D2) { if (s0 + R < nT) load_tile(s0 + R, xr1); }
-  if (XF) build_table(a, gi, b, tab);
-  __syncthreads();
+  if (XF) { build_table(a, gi, b, tab); lds_barrier(); }          // (the table only: the weights and rows in flight are not waited for here)
   if (s0 >= nT) return;
   store_tile(s0, 0, xr0);
   if (D2 && s0 + 2 * R < nT) load_tile(s0 + 2 * R, xr0);

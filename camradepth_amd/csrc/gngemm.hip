@@ -252,8 +252,13 @@ int launch_reg(const ConvK& k0, GnIn gi, int B, hipStream_t st) {
 //   * GroupNorm sums of the output stay in registers across the workgroup's tiles and leave as 8-16 atomics per wave at the end.
 // XF = 1: the fp32 rows behind a GroupNorm (fc1); XF = 0: plain bf16 rows (fc2's data gradient at stages 1-2: d(h3) = W2^T d(x2), the
 // same shape transposed -- crd_conv_igemm sends it here).
-template <int KS, int WCT, int XF>
+// RED (XF = 0, one column tile per wave): the reduce phase of the backward of the GroupNorm (+ GELU) whose dy this launch produces
+// (Mlp.norm2 behind fc2's data gradient; crd_conv_desc.red_*): every lane keeps (sum g, sum g xhat) of its 16 channels in registers
+// across the workgroup's tiles -- g = dy x GELU'(xhat gamma + beta) from the ROUNDED output, as crd_gn_bwd_reduce reads it back -- and
+// they leave once per workgroup: a half-wave fold, one atomic pair per channel, one per group for the gamma-weighted sums.
+template <int KS, int WCT, int XF, bool RED = false>
 __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb, int R) {
+  static_assert(!RED || (XF == 0 && WCT == 1), "fused reduce: plain rows, 128-column workgroups");
   constexpr int K = KS * 16, LDA = K + 8, G4 = K / 4, NB = 4 * WCT * 32, BM = 64;
   constexpr int G8 = K / 8, NX = XF ? KS : (KS + 1) / 2;          // 16-byte granules per row / per thread
   constexpr int LDT = WCT * 32 + 8;                                // per-wave transposition strip [32 pixels][LDT] (rows of 16 x odd bytes)
@@ -350,11 +355,37 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
       bvr[j][g4] = f32x4t{0.f, 0.f, 0.f, 0.f};
       if (a.bias) bvr[j][g4] = *reinterpret_cast<const f32x4t*>(a.bias + (long long)b * a.bias_bstride + n0 + j * 32 + 8 * g4 + 4 * half);
     }
+  // fused reduce: gamma / beta of the lane's 16 channels, the moments of their group, the running sums
+  f32x4t rga[RED ? 4 : 1], rbe[RED ? 4 : 1], rs0[RED ? 4 : 1], rs1[RED ? 4 : 1];
+  float rmean = 0.f, rrstd = 0.f;
+  const bf16_t* rxb = nullptr;
+  if constexpr (RED) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      rga[g4] = *reinterpret_cast<const f32x4t*>(a.red_gamma + n0 + 8 * g4 + 4 * half);
+      rbe[g4] = *reinterpret_cast<const f32x4t*>(a.red_beta + n0 + 8 * g4 + 4 * half);
+      rs0[g4] = f32x4t{0.f, 0.f, 0.f, 0.f};
+      rs1[g4] = f32x4t{0.f, 0.f, 0.f, 0.f};
+    }
+    const int cpg = 16 * a.red_gmul;
+    gn_mean_rstd(a.red_stats + (long long)b * (a.Cout >> 4) * 2, (n0 / cpg) * a.red_gmul, a.red_gmul, (float)P * cpg, rmean, rrstd);
+    rxb = reinterpret_cast<const bf16_t*>(a.red_x) + (long long)b * a.red_x_bstride + n0 + 4 * half;
+  }
   bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
 
   auto step = [&](int tile, int buf, f32x4t (&xnext)[NX]) __attribute__((always_inline)) {
     const int nxt = tile + R;
     if (!D2 && nxt < nT) load_tile(nxt, xnext);
+    u32x2t rxv[RED ? 2 : 1][RED ? 4 : 1];              // the GroupNorm's raw input at this lane's pixels and channels (requested now)
+    if constexpr (RED) {
+#pragma unroll
+      for (int rt = 0; rt < 2; ++rt) {
+        int p = tile * BM + rt * 32 + px;
+        p = p < P ? p : P - 1;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) rxv[rt][g4] = *reinterpret_cast<const u32x2t*>(rxb + (long long)p * a.red_x_ld + 8 * g4);
+      }
+    }
     f32x16 acc[2][WCT];
 #pragma unroll
     for (int rt = 0; rt < 2; ++rt)
@@ -390,6 +421,18 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
             const float v0 = bf_lo(d[0]), v1 = bf_hi(d[0]), v2 = bf_lo(d[1]), v3 = bf_hi(d[1]);
             st_s[j][g4 >> 1] += (v0 + v1) + (v2 + v3);
             st_q[j][g4 >> 1] += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+            if constexpr (RED) {
+              const float dq[4] = {v0, v1, v2, v3};
+              const float xq[4] = {bf_lo(rxv[rt][g4][0]), bf_hi(rxv[rt][g4][0]), bf_lo(rxv[rt][g4][1]), bf_hi(rxv[rt][g4][1])};
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float xh = (xq[e] - rmean) * rrstd;
+                float gg = dq[e];
+                if (a.red_act == 1) gg *= gelu_grad(xh * rga[g4][e] + rbe[g4][e]);
+                rs0[g4][e] += gg;
+                rs1[g4][e] += gg * xh;
+              }
+            }
           }
           *reinterpret_cast<u32x2t*>(T + px * LDT + j * 32 + 8 * g4 + 4 * half) = d;
         }
@@ -415,6 +458,33 @@ __global__ __launch_bounds__(256, 2) void k_gn_pw_wide(ConvK a, GnIn gi, int ncb
   for (int tile = s0; tile < nT; tile += 2 * R) {
     if constexpr (D2) step(tile, 0, xr1); else step(tile, 0, xr0);
     if (tile + R < nT) step(tile + R, 1, xr0);
+  }
+  if constexpr (RED) {
+    // lanes 0-31 / 32-63 hold the same channels for 32 different pixels: fold each half-wave, then lane 0 / 32 adds its 16 channels
+    float w[2][2] = {{0.f, 0.f}, {0.f, 0.f}};        // gamma-weighted sums of the wave's two 16-channel slabs: [slab][moment]
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v0 = rs0[g4][e], v1 = rs1[g4][e];
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) { v0 += __shfl_xor(v0, o); v1 += __shfl_xor(v1, o); }
+        if ((l & 31) == 0) {
+          const int c = n0 + 8 * g4 + 4 * half + e;
+          grad_add(&a.red_r[((long long)b * a.Cout + c) * 2], v0);
+          grad_add(&a.red_r[((long long)b * a.Cout + c) * 2 + 1], v1);
+        }
+        w[g4 >> 1][0] += v0 * rga[g4][e];
+        w[g4 >> 1][1] += v1 * rga[g4][e];
+      }
+    const int Bn = (int)gridDim.x / (ncb * R), cpg = 16 * a.red_gmul;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const float tot = w[sl][m] + __shfl_xor(w[sl][m], 32);          // lane 0 (channels + 0) and lane 32 (channels + 4)
+        if (l == 0) grad_add(&a.red_r[(long long)Bn * a.Cout * 2 + ((long long)b * (a.Cout / cpg) + (n0 + 16 * sl) / cpg) * 2 + m], tot);
+      }
   }
   if (a.stats) {
 #pragma unroll
@@ -442,7 +512,7 @@ bool pw_wide_applies(const ConvK& k, const GnIn& gi, int act_in) {
          (!gi.xn || gi.xn_ld % 4 == 0) && (reinterpret_cast<uintptr_t>(k.w) & 15) == 0;
 }
 
-template <int KS, int WCT, int XF>
+template <int KS, int WCT, int XF, bool RED = false>
 int launch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
   constexpr int K = KS * 16, NB = 4 * WCT * 32;
   const int ncb = k.Cout / NB, nT = cdiv(k.OHW, 64);
@@ -452,7 +522,7 @@ int launch_pw_wide(const ConvK& k, const GnIn& gi, int B, hipStream_t st) {
   const int tpw = cdiv(nT, rmax);                   // tiles per workgroup, then as few streams as that needs (balanced)
   const int R = cdiv(nT, tpw);
   const size_t lds = (size_t)2 * 64 * (K + 8) * 2 + (size_t)K * sizeof(float2) + (size_t)4 * 32 * (WCT * 32 + 8) * 2;
-  hipLaunchKernelGGL((k_gn_pw_wide<KS, WCT, XF>), dim3(ncb * R * B), dim3(256), lds, st, k, gi, ncb, R);
+  hipLaunchKernelGGL((k_gn_pw_wide<KS, WCT, XF, RED>), dim3(ncb * R * B), dim3(256), lds, st, k, gi, ncb, R);
   CRD_LAUNCH_CHECK("crd_gn_conv(wide pointwise)");
   return CRD_OK;
 }
@@ -482,13 +552,22 @@ bool crd_pw_wide_plain_applicable(const ConvK& k) {
   if (on < 0) on = crd_dev_int("CRD_PW_WIDE", 1);
   return on && k.KW == 1 && k.stride == 1 && k.pad == 0 && (k.Cin == 64 || k.Cin == 128 || k.Cin == 160) && k.Ktot == k.Cin && k.Cout >= 256 &&
          k.Cout % 128 == 0 && (k.x_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && k.IH * k.IW == k.OHW && !k.y_f32 && !k.res &&
-         !k.act && !k.accumulate && !k.chan && !k.red_x && !k.stats_partial && k.out_mode == 0 && k.vec_ok && (k.y_ld & 7) == 0 &&
+         !k.act && !k.accumulate && !k.chan && !k.stats_partial && k.out_mode == 0 && k.vec_ok && (k.y_ld & 7) == 0 &&
+         (!k.red_x || (crd_dev_int("CRD_PW_WIDE_RED", 0) && !k.red_x_f32 && (k.red_x_ld & 3) == 0 && (reinterpret_cast<uintptr_t>(k.red_x) & 7) == 0 && k.red_gmul >= 2 &&
+                       (reinterpret_cast<uintptr_t>(k.red_gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(k.red_beta) & 15) == 0)) &&
          (!k.bias || ((reinterpret_cast<uintptr_t>(k.bias) & 15) == 0 && k.bias_bstride % 4 == 0)) && (reinterpret_cast<uintptr_t>(k.w) & 15) == 0;
 }
 int crd_pw_wide_plain(const ConvK& k, int B, hipStream_t st) {
   GnIn gi;
   gi.x = k.x; gi.x_f32 = 0; gi.stats = nullptr; gi.gmul = 1; gi.gamma = nullptr; gi.beta = nullptr; gi.count = 1.f;
   gi.xn = nullptr; gi.xn_ld = 0; gi.xn_bstride = 0;
+  if (k.red_x) {          // with the reduce phase of the following GroupNorm's backward in the epilogue (128-column workgroups)
+                          // (correct -- tests/test_gpu_igemm.py runs it in a developer build -- but SLOWER in the step: 18.01 vs 17.91 ms;
+                          //  the GELU' of 27-54 M elements costs more in this epilogue than the streaming reduce kernel it replaces)
+    if (k.Cin == 64) return launch_pw_wide<4, 1, 0, true>(k, gi, B, st);
+    if (k.Cin == 128) return launch_pw_wide<8, 1, 0, true>(k, gi, B, st);
+    return launch_pw_wide<10, 1, 0, true>(k, gi, B, st);
+  }
   return dispatch_pw_wide<0>(k, gi, B, st);
 }
 

@@ -50,6 +50,9 @@ SIDE_STREAMS = _dev_flag("CRD_SIDE_STREAMS")
 FUSE_GN_RED = _dev_flag("CRD_FUSE_GN_RED")
 # ... except on grids of <= this many pixels per sample, where the launch it saves outweighs the slower epilogue (25.2 -> 25.0 ms)
 FUSE_GN_RED_MAXPIX = _dev_int("CRD_FUSE_GN_RED_MAXPIX", 416)
+# ... and, as an experiment (dev switch CRD_FUSE_GN_RED_WIDE + a library built with CRD_PW_WIDE_RED), wherever the wide pointwise
+# kernel (k_gn_pw_wide, round 4) runs fc2's data gradient: there the reduce's sums never leave the registers until the workgroup ends
+FUSE_GN_RED_WIDE = _dev_flag("CRD_FUSE_GN_RED_WIDE")       # measured: 18.01 ms per step with it, 17.91 without (the GELU' in the epilogue)
 # GroupNorm statistics of the residual stream produced by the kernels that write it (attn_out_residual -> norm2, fc2's
 # epilogue -> the next block's norm1) instead of crd_gn_stats launches; CRD_NO_FUSE_STATS restores the launches
 FUSE_STATS = not _dev_flag("CRD_NO_FUSE_STATS")
@@ -1117,7 +1120,9 @@ class Plan:
             self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
         self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=ml + ".fc2.bias")
         # fc2's data gradient also runs the reduce phase of Mlp.norm2's backward on its own output (FUSE_GN_RED)
-        r2 = self.zb(B * hid * 2 + B * (hid // (16 * ratio)) * 2) if hid > 160 and (FUSE_GN_RED or N <= FUSE_GN_RED_MAXPIX) else None
+        # (on every grid where the wide pointwise kernel takes the launch: its sums stay in registers across a workgroup's tiles)
+        wide = FUSE_GN_RED_WIDE and Cs in (64, 128, 160) and hid >= 256 and hid % 128 == 0 and ratio >= 2
+        r2 = self.zb(B * hid * 2 + B * (hid // (16 * ratio)) * 2) if hid > 160 and (FUSE_GN_RED or wide or N <= FUSE_GN_RED_MAXPIX) else None
         red = None if r2 is None else (H2, sth2, self.p(ml + ".norm2.weight"), self.p(ml + ".norm2.bias"), ratio, 1, r2)
         self.conv(g, self.conv_desc(DH, ("dgrad", c2), hid, 1, 1, 0, Hs, Ws, DHID, gather=1, red=red))
         self.gn_bwd(g, H2, sth2, ratio, ml + ".norm2", 1, None, DHID, DHID, r=r2)           # in place: d(H2)

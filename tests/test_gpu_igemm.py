@@ -254,7 +254,7 @@ def test_conv_dgrad_gather_mode(case):
 
 
 @pytest.mark.parametrize("Ci,Co,H,W,gmul,act,xf32", [(640, 160, 16, 26, 4, 1, 0), (512, 64, 24, 40, 8, 1, 0), (256, 64, 9, 7, 1, 0, 0),
-                                                      (1024, 256, 2, 3, 4, 1, 0), (1024, 256, 8, 13, 4, 1, 0),
+                                                      (1024, 256, 2, 3, 4, 1, 0), (1024, 256, 8, 13, 4, 1, 0), (1024, 128, 19, 27, 8, 1, 0), (512, 64, 64, 104, 8, 1, 0),
                                                       # Mlp.fc1's data gradient feeding Block.norm2 (fp32 residual stream, no activation)
                                                       (160, 640, 16, 26, 1, 0, 1), (128, 1024, 32, 52, 1, 0, 1), (64, 512, 64, 104, 1, 0, 1)])
 def test_conv_dgrad_with_fused_groupnorm_backward_reduce(Ci, Co, H, W, gmul, act, xf32):

@@ -1060,9 +1060,21 @@ __global__ __launch_bounds__(NT) void k_enc_stage(EncK a) {
 template <int RPW> using Cfg3 = Cfg<160, 640, 4, 2, 26, RPW>;
 template <int RPW> using Cfg4 = Cfg<256, 1024, 8, 1, 13, RPW>;
 
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount; 256 on a whole MI355X, fewer in a CPX / DPX partition).
+// The inter-workgroup exchanges need every workgroup of a launch RESIDENT (one per CU: 124-152 KB of LDS each), so the grid is sized
+// from this, never from a literal.  0 when no device can be queried (the entry points then report "unsupported").
+int device_cus() {
+  static int cus = -1;
+  if (cus < 0) {
+    int dev = 0, n = 0;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 0;
+  }
+  return cus;
+}
+
 template <class CF>
-int sets_for(int B, int G) {
-  int cap = 256 / G;                       // one workgroup per CU, all resident
+int sets_for(int B, int G, int cus = -1) {
+  int cap = (cus < 0 ? device_cus() : cus) / G;      // one workgroup per CU, all resident
   if (cap >= 8) cap = cap / 8 * 8;         // a multiple of the XCD count keeps a sample on one XCD
   return B < cap ? B : cap;
 }
@@ -1070,7 +1082,7 @@ int sets_for(int B, int G) {
 // image rows per workgroup: one while the whole batch still fits the chip that way (a workgroup per CU), else two
 int rows_per_wg(int B, int H, int want) {
   if (want == 1 || want == 2) return want;
-  return B * H <= 256 ? 1 : 2;
+  return B * H <= device_cus() ? 1 : 2;
 }
 
 int stage_kind(int H, int W, int C, int hid, int heads, int sr) {
@@ -1137,8 +1149,9 @@ extern "C" int crd_pack_frag32(const crd_frag_entry* table_dev, int32_t n, int64
 }
 
 extern "C" int crd_enc_stage_supported(int32_t B, int32_t H, int32_t W, int32_t C, int32_t hidden, int32_t heads, int32_t sr) {
-  if (B < 1) return 0;
-  return stage_kind(H, W, C, hidden, heads, sr) ? H / rows_per_wg(B, H, 0) : 0;
+  if (B < 1 || !stage_kind(H, W, C, hidden, heads, sr)) return 0;
+  const int G = H / rows_per_wg(B, H, 0);
+  return device_cus() >= G ? G : 0;          // a sample's G workgroups must be co-resident (one per CU): else not supported here
 }
 
 extern "C" int crd_enc_stage_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t hidden, int32_t heads, int32_t sr) {
@@ -1148,7 +1161,7 @@ extern "C" int crd_enc_stage_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t C
   for (int rpw = 1; rpw <= 2; ++rpw) {
     const int G = H / rpw;
     const long long area = kind == 3 ? (rpw == 1 ? Cfg3<1>::AREA : Cfg3<2>::AREA) : (rpw == 1 ? Cfg4<1>::AREA : Cfg4<2>::AREA);
-    const long long sets = sets_for<void>(B, G);
+    const long long sets = sets_for<void>(B, G, device_cus() > 256 ? device_cus() : 256);      // (an upper bound: valid without a device too)
     if (sets * area > need) need = sets * area;
   }
   return (int)((EPOCH_WORDS + need) * 8);
@@ -1161,6 +1174,8 @@ extern "C" int crd_enc_stage_fwd(const crd_enc_stage_desc* d, crd_stream_t strea
                   d->H, d->W, d->C, d->hidden, d->heads, d->sr);
   CRD_CHECK_ARG(d->rows_per_wg >= 0 && d->rows_per_wg <= 2, "crd_enc_stage_fwd: rows_per_wg must be 0 (choose), 1 or 2");
   const int rpw = rows_per_wg(d->B, d->H, d->rows_per_wg);
+  CRD_UNSUPPORTED(device_cus() >= d->H / rpw, "crd_enc_stage_fwd: %d workgroups per sample cannot be co-resident on %d compute units",
+                  d->H / rpw, device_cus());
   hipStream_t st = as_stream(stream);
   const int rc = kind == 3 ? (rpw == 1 ? launch_stage<Cfg3<1>>(d, st) : launch_stage<Cfg3<2>>(d, st))
                            : (rpw == 1 ? launch_stage<Cfg4<1>>(d, st) : launch_stage<Cfg4<2>>(d, st));

@@ -93,7 +93,9 @@ ENC_ROWS_PER_WG = 0       # image rows per workgroup of the persistent stage ker
 
 
 def enc_persist_default():
-    v = os.environ.get("CRD_ENC_PERSIST", "0")
+    """Round 5: a DEVELOPER switch (CRD_DEV_SWITCHES=1 CRD_ENC_PERSIST=1|auto).  The path is parked: forward-only, at parity in time,
+    and its per-process slow mode under graph replay was never root-caused ("Round 4")."""
+    v = os.environ.get("CRD_ENC_PERSIST", "0") if os.environ.get("CRD_DEV_SWITCHES") == "1" else "0"
     return v if v in ("0", "1", "auto") else "0"
 
 
@@ -136,11 +138,31 @@ class PM:
 class Op:
     """One recorded kernel call.  stream: 0 = the main stream; 1, 2 = side branches (ops that do not depend on the main
     ops recorded after the point where the branch was opened); fn None = join marker: the main stream waits for the branch."""
-    __slots__ = ("fn", "args", "name", "region", "acc_slot", "meta", "stream")
+    __slots__ = ("fn", "args", "name", "region", "acc_slot", "meta", "stream", "io")
 
-    def __init__(self, fn, args, name, region=None, acc_slot=None, meta=None, stream=0):
+    def __init__(self, fn, args, name, region=None, acc_slot=None, meta=None, stream=0, io=None):
         self.fn, self.args, self.name, self.region, self.acc_slot, self.meta = fn, args, name, region, acc_slot, meta
         self.stream = stream
+        self.io = io            # algorithmic HBM bytes of the launch (int, or a callable evaluated after Plan._finalise): see nbytes()
+
+
+def nbytes(*ts):
+    """ALGORITHMIC bytes of the tensors a launch must read or write once (bench.py's floor budget, tools/floor_table.py): a PM
+    counts its own C channels of every pixel, not the row stride of the buffer it is a slice of; halo re-reads, padding channels
+    and cache effects are deliberately not in here -- that is what the measured traffic is compared against."""
+    n = 0
+    for t in ts:
+        if t is None:
+            continue
+        if isinstance(t, PM):
+            n += t.t.shape[0] * t.P * t.C * (4 if t.f32 else 2)
+        elif isinstance(t, _Lazy):
+            n += t.numel * 8
+        elif isinstance(t, torch.Tensor):
+            n += t.numel() * t.element_size()
+        else:
+            n += int(t)
+    return n
 
 
 def igemm_tile(cout, ohw=1 << 30, batch=1):
@@ -309,10 +331,16 @@ class Plan:
         return arena
 
     # ------------------------------------------------------------------ op emitters
-    def _emit(self, lst, fn_name, args, region=None, acc_slot=None):
-        op = Op(getattr(self.lib, fn_name), list(args), fn_name, region, acc_slot, stream=self._cur_stream)
+    def _emit(self, lst, fn_name, args, region=None, acc_slot=None, io=None):
+        op = Op(getattr(self.lib, fn_name), list(args), fn_name, region, acc_slot, stream=self._cur_stream, io=io)
         lst.append(op)
         return op
+
+    @staticmethod
+    def op_bytes(op):
+        """Algorithmic HBM bytes of a recorded launch (0 where none were recorded)."""
+        io = op.io
+        return int(io() if callable(io) else (io or 0))
 
     class _Side:
         def __init__(self, plan, s):
@@ -379,8 +407,17 @@ class Plan:
         meta = {"kernel": kname, "flops": flops,
                 "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
                          f"out{spec['OH']}x{spec['OW']}"}
+        wbytes = spec["cout"] * spec["k"] * spec["k"] * spec["cin"] * 2
+
+        def io(spec=spec, wbytes=wbytes):        # (accumulate flags of gradient regions are only known after _finalise)
+            xs, ys = spec["x"], spec["y"]
+            n = xs.t.shape[0] * xs.P * spec["cin"] * (4 if xs.f32 else 2) + wbytes
+            n += nbytes(ys) * (2 if spec["accumulate"] else 1) + nbytes(spec["res"])
+            if spec.get("red") is not None:
+                n += nbytes(spec["red"][0])
+            return n
         op = Op(self.lib.crd_conv_igemm, [spec], "crd_conv_igemm", region, ("spec", spec) if region else None, meta,
-                stream=self._cur_stream)
+                stream=self._cur_stream, io=io)
         lst.append(op)
         return op
 
@@ -396,7 +433,8 @@ class Plan:
                 "shape": f"gn+fwd Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} out{spec['OH']}x{spec['OW']}"}
         gn = dict(gn_in=True, x_f32=x.f32, gmul=gmul, stats=stats, gamma=self.p(gname + ".weight"), beta=self.p(gname + ".bias"),
                   act=act, xn=xn)
-        op = Op(self.lib.crd_gn_conv, [spec, gn], "crd_gn_conv", None, None, meta, stream=self._cur_stream)
+        io = nbytes(x, spec["y"], xn, spec["res"]) + spec["cout"] * spec["cin"] * 2
+        op = Op(self.lib.crd_gn_conv, [spec, gn], "crd_gn_conv", None, None, meta, stream=self._cur_stream, io=io)
         lst.append(op)
         return op
 
@@ -418,11 +456,12 @@ class Plan:
             else wgrad_tile(cw.cout)
         meta = {"kernel": kname, "flops": 2.0 * self.B * OH * OW * cw.cout * cw.cin_ref * cw.taps, "param": cw.name,
                 "shape": f"wgrad Cin{spec['cin']} Cout{cw.cout} k{k} s{stride} out{OH}x{OW}"}
+        meta["bytes"] = x.t.shape[0] * x.P * spec["cin"] * (4 if x.f32 else 2) + nbytes(dy) + cw.cout * cw.taps * spec["cin"] * 4
         if self._defer is not None and not stream3:
             self._defer.append((spec, meta))      # runs in the segment's grouped launch (see flush_deferred)
             return
         stream = LATE if self._cur_stream == 0 else self._cur_stream     # nothing in the backward pass waits for a weight gradient
-        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta, stream=stream))
+        lst.append(Op(self.lib.crd_conv_wgrad, [spec], "crd_conv_wgrad", meta=meta, stream=stream, io=meta["bytes"]))
 
     def flush_deferred(self, lst):
         """Emit ONE grouped weight-gradient launch for every wgrad deferred since `self._defer = []` (the small GEMMs
@@ -433,7 +472,7 @@ class Plan:
         meta = {"kernel": "k_wgrad_grouped", "flops": sum(m["flops"] for _, m in items), "shape": f"{len(items)} wgrads",
                 "params": [m["param"] for _, m in items]}
         lst.append(Op(self.lib.crd_conv_wgrad_grouped, [{"wg_group": [sp for sp, _ in items]}], "crd_conv_wgrad_grouped", meta=meta,
-                      stream=LATE))
+                      stream=LATE, io=sum(m["bytes"] for _, m in items)))
 
     def _make_group(self, specs):
         descs = (L.WgradDesc * len(specs))()
@@ -585,13 +624,13 @@ class Plan:
     def gn_fwd(self, x, stats, gmul, gname, act, mask, y):
         op = self._emit(self.fwd, "crd_gn_apply", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, gmul,
                                                    self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask, y.t, y.f32, y.ld,
-                                                   y.coff])
+                                                   y.coff], io=nbytes(x, y))
         op.meta = None
         self.shapes[id(op)] = f"P{x.P} C{x.C} xf32={x.f32}"
 
     def gn_stats_apply(self, x, stats, chan, gmul, gname, act, mask, y):
         """GroupNorm whose statistics no producer epilogue supplies (norm1 / norm2 on the residual stream)."""
-        self._emit(self.fwd, "crd_gn_stats", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, chan])
+        self._emit(self.fwd, "crd_gn_stats", [x.t, x.f32, x.ld, x.coff, self.B, x.P, x.C, stats, chan], io=nbytes(x))
         self.gn_fwd(x, stats, gmul, gname, act, mask, y)
 
     def gn_bwd(self, grp, x, stats, gmul, gname, act, mask, dy, dx, region=None, dx_acc=0, r=None, dx2=None, scale2=None):
@@ -601,12 +640,13 @@ class Plan:
                   self.p(gname + ".weight"), self.p(gname + ".bias"), act, mask]
         if r is None:
             r = self.zb(self.B * x.C * 2 + self.B * (x.C // (16 * gmul)) * 2)
-            self._emit(grp, "crd_gn_bwd_reduce", common + [r, None, 0])
+            self._emit(grp, "crd_gn_bwd_reduce", common + [r, None, 0], io=nbytes(x, dy))
         args = common + [r, self.g(gname + ".weight"), self.g(gname + ".bias"), dx.t, dx.f32, dx.ld, dx.coff, dx_acc]
         acc_idx = len(args) - 1
         assert dx2 is None or dx2.coff == 0
         args += [dx2.t if dx2 is not None else None, dx2.ld if dx2 is not None else 0, scale2]
-        self._emit(grp, "crd_gn_bwd_apply", args, region, acc_idx if region else None)
+        op = self._emit(grp, "crd_gn_bwd_apply", args, region, acc_idx if region else None)
+        op.io = lambda op=op, i=acc_idx, x=x, dy=dy, dx=dx, dx2=dx2: nbytes(x, dy, dx, dx2) + (nbytes(dx) if op.args[i] else 0)
 
     def conv_layer(self, name, x, k, out, mask=None, dout=None, dx=None, dx_region=None, x8=None, out8=None):
         """ConvLayer (utils.py:210-228): conv(no bias) -> GN(Cout/16) -> GELU [-> Dropout2d mask].
@@ -627,7 +667,8 @@ class Plan:
             spec = dict(fp8=True, x8=x8[0], x8_ld=x8[1], cin=cin16, H=H, W=W, cw=cw, y=raw, stats=stats, cout=cw.cout)
             meta = {"kernel": "k_conv3x3_fp8<%d>" % (2 if cw.cout <= 64 else 3 if cw.cout <= 96 else 4),
                     "flops": 2.0 * self.B * H * W * cw.cout * cw.cin_ref * 9, "shape": f"fwd fp8 Cin{cin16} Cout{cw.cout} k3 s1 out{H}x{W}"}
-            self.fwd.append(Op(self.lib.crd_conv3x3_fp8, [spec, cw.w8_scales, float(x8[2])], "crd_conv3x3_fp8", meta=meta))
+            self.fwd.append(Op(self.lib.crd_conv3x3_fp8, [spec, cw.w8_scales, float(x8[2])], "crd_conv3x3_fp8", meta=meta,
+                               io=self.B * H * W * cin16 + nbytes(raw) + cw.cout * 9 * cin16))
         else:
             self.conv(self.fwd, self.conv_desc(x, cw, cw.cout, k, 1, k // 2, H, W, raw, stats=stats))
         if out8 is not None:       # the output feeds fp8 convolutions: its e4m3 copy (inference: all that is stored)
@@ -636,6 +677,7 @@ class Plan:
                                                            self.p(name + ".model.1.weight"), self.p(name + ".model.1.bias"), 1, mask,
                                                            out8[0], out8[1], out8[2], float(out8[3])] + yb)
             op.meta = None
+            op.io = nbytes(raw, out) + raw.t.shape[0] * raw.P * raw.C
             self.shapes[id(op)] = f"P{raw.P} C{raw.C} -> fp8"
         else:
             self.gn_fwd(raw, stats, 1, name + ".model.1", 1, mask, out)
@@ -675,7 +717,7 @@ class Plan:
         # ---- input: NCHW fp32 -> pixel-major bf16 (8 channels) ----
         self.x_in = torch.zeros((B, Cin, H, W), dtype=F32, device=self.dev)   # static input (graph-safe)
         X8 = self.act(8, H, W)
-        self._emit(self.fwd, "crd_nchw_to_pm", [self.x_in, B, Cin, H, W, X8.t, X8.ld, 0, 8])
+        self._emit(self.fwd, "crd_nchw_to_pm", [self.x_in, B, Cin, H, W, X8.t, X8.ld, 0, 8], io=nbytes(self.x_in, X8))
 
         # ---- encoder ----
         enc_out_b = []          # bf16 copies of the four stage outputs
@@ -735,7 +777,7 @@ class Plan:
                 per_blk = 2.0 * B * (N * Cs * Cs + (M_ * Cs * Cs * sr * sr if sr > 1 else 0) + M_ * Cs * Cs + 2 * N * Cs * hid + N * M_ * Cs)
                 op.meta = {"kernel": "k_enc_stage", "flops": per_blk * cfg.depths[s], "shape": f"stage {s + 1}: {cfg.depths[s]} blocks C{Cs} {Hs}x{Ws}"}
             else:
-                self._emit(self.fwd, "crd_f32_to_bf16_rows", [X.t, Cs, Xb.t, Cs, 0, B * N, Cs, None, 1, None, 0, 0])
+                self._emit(self.fwd, "crd_f32_to_bf16_rows", [X.t, Cs, Xb.t, Cs, 0, B * N, Cs, None, 1, None, 0, 0], io=nbytes(X, Xb))
             enc_out_b.append(Xb)
             d_enc_out.append(DX)
             src = Xb
@@ -793,13 +835,16 @@ class Plan:
                 cb8 = self.new((B, Hj * Wj, ld8), torch.uint8)
                 keep = self.fp8_keep_bf16           # a backward pass follows: the bf16 tensors are stored as well
                 self._emit(self.fwd, "crd_bicubic2x_fp8", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb8, ld8, 0, sc8]
-                           + ([cb.t, cb.ld, 0] if keep else [None, 0, 0]))
+                           + ([cb.t, cb.ld, 0] if keep else [None, 0, 0]),
+                           io=nbytes(up_src.sl(0, up_p)) * (1 + (4 if keep else 0)) + B * Hj * Wj * up_p)
                 if sk_p:
-                    self._emit(self.fwd, "crd_quant_fp8", [cb.t, B * Hj * Wj, cb.ld, up_p, sk_p, cb8, ld8, up_p, sc8])
+                    self._emit(self.fwd, "crd_quant_fp8", [cb.t, B * Hj * Wj, cb.ld, up_p, sk_p, cb8, ld8, up_p, sc8],
+                               io=B * Hj * Wj * sk_p * 3)
                 if keep:
                     grp = []
                     args = [dcb.t, dcb.ld, 0, B, up_src.H, up_src.W, up_p, d_up_src.t, d_up_src.ld, d_up_src.coff, 0]
-                    self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
+                    op = self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
+                    op.io = lambda op=op, n=nbytes(up_src.sl(0, up_p)): n * (5 + (1 if op.args[-1] else 0))
                     self._push(grp)
                 bw = lambda c0, c1: dict(dout=dcb.sl(c0, c1), dx=dcb.sl(0, c0), dx_region=("dcb", id(dcb), 0, c0)) if keep else {}
                 self._cmap = cat_map(j, 0)
@@ -813,10 +858,12 @@ class Plan:
                 self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, x8=(cb8, ld8, sc8), **last)
                 self._cmap = None
                 return
-            self._emit(self.fwd, "crd_bicubic2x", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb.t, cb.ld, 0])
+            self._emit(self.fwd, "crd_bicubic2x", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb.t, cb.ld, 0],
+                       io=5 * nbytes(up_src.sl(0, up_p)))
             grp = []
             args = [dcb.t, dcb.ld, 0, B, up_src.H, up_src.W, up_p, d_up_src.t, d_up_src.ld, d_up_src.coff, 0]
-            self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
+            op = self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
+            op.io = lambda op=op, n=nbytes(up_src.sl(0, up_p)): n * (5 + (1 if op.args[-1] else 0))
             self._push(grp)
             self._cmap = cat_map(j, 0)
             self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, cb.sl(o0, o0 + 96), dout=dcb.sl(o0, o0 + 96),
@@ -852,7 +899,7 @@ class Plan:
             depth = PM(self.new((B, Hj * Wj, 1), F32), 1, Hj, Wj)
             w2, b2 = self.p(name + ".conv_2.weight"), self.p(name + ".conv_2.bias")
             cp = (src.t, src.ld, 128) if j < 5 else (None, 0, 0)
-            self._emit(self.fwd, "crd_head_conv2_fwd", [A.t, w2, b2, B, Hj, Wj, depth.t, cp[0], cp[1], cp[2]])
+            self._emit(self.fwd, "crd_head_conv2_fwd", [A.t, w2, b2, B, Hj, Wj, depth.t, cp[0], cp[1], cp[2]], io=nbytes(A, depth) + B * Hj * Wj * 2)
             self.out_depth[j] = depth
             # backward: dy = loss gradient (fp32 [B,P,1]) [+ d(src[128]) from the next stage]
             gd = PM(self.new((B, Hj * Wj, 1), F32), 1, Hj, Wj)
@@ -863,9 +910,10 @@ class Plan:
             rows = self.zb(HEAD_ROWS, 289)            # copies of [dw (288) | dbias]; the unpack kernel sums them
             self.row_grads.append((name + ".conv_2.weight", 288, rows, HEAD_ROWS, self._tag, 0, 289))
             self.row_grads.append((name + ".conv_2.bias", 1, rows, HEAD_ROWS, self._tag, 288, 289))
-            self._emit(grp, "crd_head_conv2_bwd_data", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t])
+            self._emit(grp, "crd_head_conv2_bwd_data", [gd.t, add[0], add[1], add[2], A.t, w2, B, Hj, Wj, dA.t], io=nbytes(gd, A, dA) + B * Hj * Wj * 2)
             if not self.is_frozen(name + ".conv_2.weight", name + ".conv_2.bias"):
-                self._emit(grp, "crd_head_conv2_wgrad", [gd.t, add[0], add[1], add[2], A.t, B, Hj, Wj, rows, HEAD_ROWS]).stream = LATE
+                self._emit(grp, "crd_head_conv2_wgrad", [gd.t, add[0], add[1], add[2], A.t, B, Hj, Wj, rows, HEAD_ROWS],
+                           io=nbytes(gd, A) + B * Hj * Wj * 2).stream = LATE
             self.wgrad(grp, xin, dA, c1, 3, 1, 1, Hj, Wj, dbias=name + ".conv_1.bias")
             self.conv(grp, self.conv_desc(dA, ("dgrad", c1), 128, 3, 1, 1, Hj, Wj, dsrc.sl(0, 128), gather=1),
                       region=("ds", id(dsrc), 0, 128))
@@ -888,9 +936,9 @@ class Plan:
             self.conv(self.fwd, self.conv_desc(feat.sl(0, 128), cw, classes, 3, 1, 1, Hj, Wj, logits, bias=cw.bias))
             for (buf, ch) in dests:
                 if ch is None:    # fp32 [B,1,H,W] module output
-                    self._emit(self.fwd, "crd_seg_argmax", [logits.t, logits.ld, B, Hj * Wj, classes, classes, buf, 1, 1, 0])
+                    self._emit(self.fwd, "crd_seg_argmax", [logits.t, logits.ld, B, Hj * Wj, classes, classes, buf, 1, 1, 0], io=nbytes(logits) + B * Hj * Wj * 4)
                 else:
-                    self._emit(self.fwd, "crd_seg_argmax", [logits.t, logits.ld, B, Hj * Wj, classes, classes, buf.t, 0, buf.ld, ch])
+                    self._emit(self.fwd, "crd_seg_argmax", [logits.t, logits.ld, B, Hj * Wj, classes, classes, buf.t, 0, buf.ld, ch], io=nbytes(logits) + B * Hj * Wj * 2)
             return cw, logits
 
         if seg:
@@ -911,10 +959,12 @@ class Plan:
         stage(4, "depth_upsample.4", CB[4], dCB[4], S[3], dS[3], ("ds", id(dS[3]), 0, 136), S[4].sl(0, 128), dS[4].sl(0, 128), dmask())
         # the raw 7-channel input is the skip of the last stage (CamRaDepth.py:149,152)
         up_p, sk_p = lay[4]
-        self.fwd.insert(1, Op(self.lib.crd_slice_copy, [X8.t, 8, 0, CB[4].t, CB[4].ld, up_p, B * H * W, 8, 0], "crd_slice_copy"))
+        self.fwd.insert(1, Op(self.lib.crd_slice_copy, [X8.t, 8, 0, CB[4].t, CB[4].ld, up_p, B * H * W, 8, 0], "crd_slice_copy", io=2 * nbytes(X8)))
+        self.fwd_marks = [(n_, i_ + (1 if i_ > 1 else 0)) for n_, i_ in self.fwd_marks]      # (the phase marks behind the inserted op)
         if seg:
             CBs1, dCBs1 = self.act(CB[4].ld, *hs[5]), self.act(CB[4].ld, *hs[5])
-            self.fwd.insert(2, Op(self.lib.crd_slice_copy, [X8.t, 8, 0, CBs1.t, CBs1.ld, up_p, B * H * W, 8, 0], "crd_slice_copy"))
+            self.fwd.insert(2, Op(self.lib.crd_slice_copy, [X8.t, 8, 0, CBs1.t, CBs1.ld, up_p, B * H * W, 8, 0], "crd_slice_copy", io=2 * nbytes(X8)))
+            self.fwd_marks = [(n_, i_ + (1 if i_ > 2 else 0)) for n_, i_ in self.fwd_marks]
             SF1, dSF1 = self.act(128, *hs[5]), self.act(128, *hs[5])
             stage_seg(4, "seg_upsample.1", CBs1, dCBs1, SF0, dSF0, ("ds", id(dSF0), 0, 136), SF1, dSF1, dmask())
             ch = 136
@@ -923,11 +973,11 @@ class Plan:
                 ch += 1
                 self.seg_logits = logits
                 self.seg_out = torch.zeros((B, cfg.num_classes, H, W), dtype=F32, device=self.dev)
-                self._emit(self.fwd, "crd_pm_to_nchw", [logits.t, 1, logits.ld, 0, B, cfg.num_classes, H, W, self.seg_out])
+                self._emit(self.fwd, "crd_pm_to_nchw", [logits.t, 1, logits.ld, 0, B, cfg.num_classes, H, W, self.seg_out], io=nbytes(logits, self.seg_out))
                 self.seg_grad_in = torch.zeros((B, cfg.num_classes, H, W), dtype=F32, device=self.dev)
                 DL = self.act(rup(cfg.num_classes), H, W)
                 grp = []
-                self._emit(grp, "crd_nchw_to_pm", [self.seg_grad_in, B, cfg.num_classes, H, W, DL.t, DL.ld, 0, DL.ld])
+                self._emit(grp, "crd_nchw_to_pm", [self.seg_grad_in, B, cfg.num_classes, H, W, DL.t, DL.ld, 0, DL.ld], io=nbytes(self.seg_grad_in, DL))
                 self.wgrad(grp, SF1, DL, cw, 3, 1, 1, H, W, dbias="seg_conv_final.bias")
                 self.conv(grp, self.conv_desc(DL, ("dgrad", cw), 128, 3, 1, 1, H, W, dSF1, gather=1, cin=DL.ld),
                           region=("ds", id(dSF1), 0, 128))
@@ -978,7 +1028,7 @@ class Plan:
             st1, ch1 = pre
         else:
             st1, ch1 = self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)
-            self._emit(F_, "crd_gn_stats", [X.t, X.f32, X.ld, X.coff, self.B, X.P, X.C, st1, ch1])
+            self._emit(F_, "crd_gn_stats", [X.t, X.f32, X.ld, X.coff, self.B, X.P, X.C, st1, ch1], io=nbytes(X))
         if not fused:
             self.gn_fwd(X, st1, 1, name + ".norm1", 0, None, XN)
         cq, ck, cp = self.new_conv(a + ".q"), self.new_conv(a + ".k"), self.new_conv(a + ".proj")
@@ -1019,23 +1069,26 @@ class Plan:
         self.keep.append(("idx", name, idx, M))
         # scores + the rank-one value path (xbar = mean_n GN(x), U = proj(xbar): needs norm1's sums only) in one launch
         self._emit(F_, "crd_attn_fwd", [Q.t, K.t, B, N, M, heads, dh, scale, Ssum, idx, ch1, st1, self.p(name + ".norm1.weight"),
-                                        self.p(name + ".norm1.bias"), _WPtr(cp, "w_fwd"), xbar.t, U.t])
+                                        self.p(name + ".norm1.bias"), _WPtr(cp, "w_fwd"), xbar.t, U.t],
+                   io=nbytes(Q, K, Ssum, idx))
         X1 = self.act(Cs, Hs, Ws, F32)
         # ---- MLP branch ----
         st2 = self.zf(B, Cs // 16, 2)
         XN2 = self.act(Cs, Hs, Ws)
         if FUSE_STATS:       # norm2's statistics come out of the kernel that writes X1
-            self._emit(F_, "crd_attn_out_residual_stats", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t, st2])
+            self._emit(F_, "crd_attn_out_residual_stats", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t, st2], io=nbytes(X, Ssum, X1))
         else:
-            self._emit(F_, "crd_attn_out_residual", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t])
-            self._emit(F_, "crd_gn_stats", [X1.t, X1.f32, X1.ld, X1.coff, self.B, X1.P, X1.C, st2, None])
+            self._emit(F_, "crd_attn_out_residual", [X.t, U.t, Ssum, cp.bias, dp, B, N, Cs, X1.t], io=nbytes(X, Ssum, X1))
+            self._emit(F_, "crd_gn_stats", [X1.t, X1.f32, X1.ld, X1.coff, self.B, X1.P, X1.C, st2, None], io=nbytes(X1))
         c1, c2 = self.new_conv(ml + ".fc1"), self.new_conv(ml + ".fc2")
         H1, H2, H3 = (self.act(hid, Hs, Ws) for _ in range(3))
         sth1, sth2 = self.zf(B, hid // 16, 2), self.zf(B, hid // 16, 2)
         fc1_spec = self.conv_desc(XN2, c1, hid, 1, 1, 0, Hs, Ws, H1, bias=c1.bias, stats=sth1)
         n1 = [sth1, 1, self.p(ml + ".norm1.weight"), self.p(ml + ".norm1.bias")]
         w9 = self.new((9, hid), F32)
-        self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9, 2))     # fp32 [9][hid], values rounded to bf16
+        # fp32 [9][hid], values rounded to bf16 like every convolution weight under autocast (developer switch CRD_DW_F32: un-rounded,
+        # the round-3 behaviour -- the A/B of tools/ab_dw_rounding.sh)
+        self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9, 1 if _dev_flag("CRD_DW_F32") else 2))
         X2 = self.act(Cs, Hs, Ws, F32)
         nxt = (self.zf(B, Cs // 16, 2), self.zf(B, Cs, 2)) if (want_next and FUSE_STATS) else None
         # Mlp.norm1 is applied by the depthwise kernels while they stage H1 (the normalised tensor is never stored)
@@ -1057,8 +1110,10 @@ class Plan:
                         fc2_partials=_BufPtr(self, "mlp_parts"))
             op = self._emit(F_, "crd_mlp_fwd", [dict(mlp=True, ptrs=ptrs, dims=(B, Hs, Ws, Cs, hid))])
             op.meta = {"kernel": "k_mlp_fwd", "flops": 2.0 * B * N * hid * Cs * 2, "shape": f"fused Mlp C{Cs} hid{hid} {Hs}x{Ws}"}
+            op.io = nbytes(X1) + (nbytes(XN2, H1, H2, H3) if tr else 0) + slabs * B * N * Cs * 4 + 2 * hid * Cs * 2
             self._emit(F_, "crd_mlp_reduce", [_BufPtr(self, "mlp_parts"), slabs, X1.t, c2.bias, dp, B, N, Cs, X2.t,
-                                             nxt[0] if nxt else None, nxt[1] if nxt else None])
+                                             nxt[0] if nxt else None, nxt[1] if nxt else None],
+                       io=slabs * B * N * Cs * 4 + nbytes(X1, X2))
         else:
             if fused:            # Block.norm2 applied while fc1 loads X1
                 fc1_spec["x"] = X1
@@ -1066,7 +1121,7 @@ class Plan:
             else:
                 self.gn_fwd(X1, st2, 1, name + ".norm2", 0, None, XN2)
                 self.conv(F_, fc1_spec)
-            self._emit(F_, "crd_dwconv3x3", dw_args)
+            self._emit(F_, "crd_dwconv3x3", dw_args, io=nbytes(H1, H2))
             # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only).  Inference plans
             # (nothing saved) take it from FC2_FOLD_MINROWS pixels x batch on: on small grids fc2 is a long-K GEMM on few
             # workgroups, which k_igemm's intra-workgroup split-K handles better than the register-path kernel
@@ -1117,7 +1172,7 @@ class Plan:
         if want_next and FUSE_STATS and self._defer is not None:
             dh_out = (DH, dp)        # d(X2) arrives in bf16 from the next block's norm1 backward
         else:
-            self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0])
+            self._emit(g, "crd_f32_to_bf16_rows", [DX.t, Cs, DH.t, Cs, 0, B * N, Cs, dp, N, None, 0, 0], io=nbytes(DX, DH))
         self.wgrad(g, H3, DH, c2, 1, 1, 0, Hs, Ws, dbias=ml + ".fc2.bias")
         # fc2's data gradient also runs the reduce phase of Mlp.norm2's backward on its own output (FUSE_GN_RED)
         # (on every grid where the wide pointwise kernel takes the launch: its sums stay in registers across a workgroup's tiles)
@@ -1130,12 +1185,12 @@ class Plan:
         self.dw_grads.append((ml + ".dwconv.dwconv", hid, dw10, self._tag))
         late = self._defer is not None   # off the chain: nothing reads dw10 before the segment's unpack, DHID is this block's own
         if not self.is_frozen(ml + ".dwconv.dwconv.weight", ml + ".dwconv.dwconv.bias"):
-            op = self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1)
+            op = self._emit(g, "crd_dwconv3x3_wgrad", [H1.t, DHID.t, B, Hs, Ws, hid, dw10, DW_REPLICAS] + n1, io=nbytes(H1, DHID))
             op.stream = LATE if late else op.stream
         # d(H1N), with the reduce phase of Mlp.norm1's backward fused in (it needs exactly this output and H1)
         r1 = self.zb(B * hid * 2 + B * (hid // 16) * 2)
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None,
-                                        H1.t, sth1, self.p(ml + ".norm1.weight"), r1])
+                                        H1.t, sth1, self.p(ml + ".norm1.weight"), r1], io=nbytes(DHID, DHID2, H1))
         self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2, r=r1)             # in place: d(H1)
         self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=ml + ".fc1.bias")
         # fc1's data gradient also runs the reduce phase of Block.norm2's backward on its own output (a launch less per block;
@@ -1151,10 +1206,10 @@ class Plan:
             # the apply phase of Block.norm2's backward (DX += ...: DX = d(X1)) runs inside the launch that reads DX next
             self._emit(g, "crd_attn_out_bwd_gn", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv, X1.t, DXN.t, st2,
                                                    self.p(name + ".norm2.weight"), rb2, self.g(name + ".norm2.weight"),
-                                                   self.g(name + ".norm2.bias")])
+                                                   self.g(name + ".norm2.bias")], io=nbytes(DX, DX, X1, DXN, Ssum, dSv))
         else:
             self.gn_bwd(g, X1, st2, 1, name + ".norm2", 0, None, DXN, DX, dx_acc=1, r=rb2)       # DX = d(X1)
-            self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv])
+            self._emit(g, "crd_attn_out_bwd", [DX.t, U.t, Ssum, dp, B, N, Cs, T, dbp_rows, dSv], io=nbytes(DX, Ssum, dSv))
         Tb = PM(self.new((B, 1, Cs)), Cs, 1, 1)
         Es = PM(self.new((B, 1, Cs), F32), Cs, 1, 1)
         # rank-one vector path (Tb = bf16(T), Es = d(xbar)/N: the bias of the q data gradient) rides in the launch of the
@@ -1167,10 +1222,12 @@ class Plan:
             if self.attn_parts is None or self.attn_parts.numel() < nparts * B * M * Cs:
                 self.attn_parts = self.new((nparts * B * M * Cs,), F32)     # shared scratch: produced and consumed back to back
             dK = None
-            self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, None, self.attn_parts] + vec)
+            self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, None, self.attn_parts] + vec,
+                       io=nbytes(Q, K, dSv, idx, DQ) + nparts * B * M * Cs * 4)
         else:
             dK = self.zb(B, M, Cs)
-            self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None] + vec)
+            self._emit(g, "crd_attn_bwd", [Q.t, K.t, dSv, idx, B, N, M, heads, dh, scale, DQ.t, dK, None] + vec,
+                       io=nbytes(Q, K, dSv, idx, DQ, dK))
         self.wgrad(g, xbar, Tb, cp, 1, 1, 0, 1, 1)
         self.wgrad(g, XN, DQ, cq, 1, 1, 0, Hs, Ws, dbias=a + ".q.bias")
         # d(norm1(X)) = q's data gradient (+ the rank-one vector path's Es) + the key path's.  With the fused reduce the key path
@@ -1185,9 +1242,9 @@ class Plan:
         key_acc = 1 if rb1 is None else 0
         DKb = self.act(Cs, Hs // sr, Ws // sr)
         if dK is None:
-            self._emit(g, "crd_sum_partials_bf16", [self.attn_parts, nparts, B * M * Cs, DKb.t, B * M * Cs])
+            self._emit(g, "crd_sum_partials_bf16", [self.attn_parts, nparts, B * M * Cs, DKb.t, B * M * Cs], io=nparts * B * M * Cs * 4 + nbytes(DKb))
         else:
-            self._emit(g, "crd_gsum_to_bf16", [dK, DKb.t, B * M * Cs])
+            self._emit(g, "crd_gsum_to_bf16", [dK, DKb.t, B * M * Cs], io=nbytes(dK, DKb))
         if sr > 1:
             self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=a + ".k.bias")
             DKR = self.act(Cs, Hs // sr, Ws // sr)
@@ -1459,6 +1516,16 @@ class Plan:
             ev = torch.cuda.Event()
             ev.record(self._side_streams[sid - 1])
             main.wait_event(ev)
+
+    def check_enc_status(self):
+        """Persistent encoder stages (developer path): a workgroup that gave up waiting for its peers (3 s: they were not all
+        resident) sets the launch's status word and the activations behind it are garbage -- raise instead of carrying on
+        (ADVICE r4).  Synchronises; called where the host reads results anyway (TrainStep.losses, InferenceGraph.run, eager forward)."""
+        for st in self.enc_status:
+            if int(st.item()) != 0:
+                st.zero_()
+                raise L.CrdError("crd_enc_stage_fwd: a workgroup timed out waiting for its sample's other workgroups (not all "
+                                 "resident on the device?); the stage's outputs are invalid")
 
     def pack(self, lo=None, hi=None):
         """fp32 parameters -> the bf16 (and e4m3) operand layouts of the kernels, on the current stream: all of them, or those

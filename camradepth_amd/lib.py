@@ -174,6 +174,16 @@ def nonfinite(reset=True):
     return rc == 1
 
 
+def stat_checked(acc):
+    """stat_value(acc) as the reference would report it: NaN in every slot when a non-finite / out-of-range partial was dropped
+    from a crd_sum_t sum since the flag was last cleared (the sums are then finite but too small; the reference's float sums
+    would be NaN or inf there -- src/utils/loss_funcs.py:85-91 has no guard).  Reads and CLEARS the sticky flag; synchronises."""
+    v = stat_value(acc)
+    if nonfinite():
+        v = torch.full_like(v, float("nan"))
+    return v
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = load().crd_last_error().decode()

@@ -31,7 +31,7 @@ class _MaskedL1(torch.autograd.Function):
         _allreduce_acc(acc)
         ctx.save_for_backward(pred_c, target_c, acc)
         ctx.mode = mode
-        a = L.stat_value(acc)
+        a = L.stat_checked(acc)              # NaN when a non-finite partial was dropped (the reference's float sums report it)
         return ((a[0] if mode == "smooth_l1" else a[2]) / a[1]).float()
 
     @staticmethod
@@ -76,7 +76,7 @@ class _Focal(torch.autograd.Function):
         L.check(lb.crd_ce_fwd(lg.data_ptr(), tg.data_ptr(), B, Cc, HW, acc.data_ptr(), L.stream()), "crd_ce_fwd")
         _allreduce_acc(acc)
         ctx.save_for_backward(lg, tg, acc)
-        a = L.stat_value(acc)
+        a = L.stat_checked(acc)
         ce = (a[0] / a[1]).float()
         pt = torch.exp(-ce)
         return (1 - pt) ** 2 * ce

@@ -96,6 +96,16 @@ class diffGradNorm(Optimizer):
                 continue
             i0 = act_host.index(True)
             g0 = ps[i0].grad
+            # The kernel's bias corrections use ONE step count per group (st["step"]).  The reference keeps one per parameter
+            # (diffGradNorm.py:66,76-77): they differ only for a parameter that is frozen for some steps and unfrozen later
+            # (or a checkpoint with non-uniform steps) -- including the case where the WHOLE active set switches (A frozen after
+            # n steps, B unfrozen: B's own count is 0, the group's is n).  Refuse that silently-different case instead of
+            # approximating it, BEFORE anything is modified (no kernel launch, no change of st["active"] / st["act_host"]).
+            steps = {self.state[p]["step"] + 1 for p, a_ in zip(ps, act_host) if a_}
+            if steps != {st["step"] + 1}:
+                raise L.CrdError("camradepth_amd.diffGradNorm: the active parameters' step counts "
+                                 f"({sorted(steps)}) differ from the group's ({st['step'] + 1}): unfreezing a parameter mid-run (or "
+                                 "loading such a checkpoint) needs one param_group per step count")
             # frozen parameters (grad None) are skipped through the `active` mask; the others' grads are used in place
             parallel = all(p.grad is None or (p.grad.data_ptr() - g0.data_ptr()) == 4 * (o - offs[i0]) for p, o in zip(ps, offs))
             if parallel:
@@ -111,15 +121,6 @@ class diffGradNorm(Optimizer):
                 gptr = fg.data_ptr()
                 st["active"].copy_(torch.tensor(act_host, dtype=torch.uint8))
                 st["act_host"] = None
-            # The kernel's bias corrections use ONE step count per group.  The reference keeps one per parameter
-            # (diffGradNorm.py:66,76-77): they differ only for a parameter that is frozen for some steps and unfrozen later
-            # (or a checkpoint with non-uniform steps).  Refuse that silently-different case instead of approximating it --
-            # BEFORE anything is modified (no kernel launch, no state change on the refused call).
-            steps = {self.state[p]["step"] + 1 for p, a_ in zip(ps, act_host) if a_}
-            if len(steps) > 1:
-                raise L.CrdError("camradepth_amd.diffGradNorm: parameters of one group have different step counts "
-                                 f"({sorted(steps)}): unfreezing a parameter mid-run (or loading such a checkpoint) needs one "
-                                 "param_group per step count")
             st["step"] += 1
             beta1, beta2 = group["betas"]
             pbase = st["flat_p"].data_ptr() if st["flat_p"] is not None else st["base"]

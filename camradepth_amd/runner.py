@@ -79,6 +79,7 @@ class Trainer:
         accumulating gradients); the optimizer runs every update_interval-th batch and on the last one (runner.py:222); the
         scheduler lags as in runner.py:269-270.  Returns the epoch means the reference shows in its progress bar."""
         self.model.train()
+        L.nonfinite()          # clear the sticky non-finite flag: what a validation pass raised must not turn this epoch's first loss into NaN
         n = len(self.train_dataloader)
         depth, stage4, rmse, seg = [], [], [], []
         for i, batch in enumerate(self.train_dataloader):
@@ -104,7 +105,8 @@ class Trainer:
     def eval(self, epoch, save=False):
         """-> (val_loss, RMSE): the mean final-depth SmoothL1 loss and the mean RMSE (x max_depth) over val_dataloader."""
         self.model.eval()
-        rows = []
+        L.nonfinite()          # ... and the other way round.  The loss modules report a dropped non-finite partial as NaN
+        rows = []              # (lib.stat_checked), which the nanmean below leaves out exactly like the reference's np.nanmean (runner.py:320-347)
         with torch.no_grad():
             for batch in self.val_dataloader:
                 b = unpack_batch(batch, self.cfg.input_channels)

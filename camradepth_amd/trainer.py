@@ -373,7 +373,14 @@ class TrainStep:
                     self.sync.launch(key)      # this bucket's all-reduce, behind the graph that finishes its gradients
                     self.sync.wait()           # (the LATE stream waits for it; the main stream runs on)
                     gopt.replay()              # ... and the bucket's optimizer slice follows at once
+        probe = getattr(self, "tail_probe", None)
+        if probe is not None:                  # bench.py: how long the main stream idles behind the late stream at the end of an iteration
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main)
         self._stream_wait(main, self.late_stream)
+        if probe is not None:
+            e1.record(main)
+            probe.append((e0, e1))
         if go is not None:
             go.replay()
 
@@ -444,6 +451,8 @@ class TrainStep:
     def losses(self):
         """Host view of the last iteration's loss terms (synchronises)."""
         a = L.stat_value(self.acc.cpu())
+        if self.plan.enc_status:               # (developer path, CRD_ENC_PERSIST)
+            self.plan.check_enc_status()
         if L.nonfinite():
             # a NaN / infinite / out-of-range partial was dropped from a fixed-point sum since the last check (include/camradepth_hip.h:
             # crd_nonfinite_status): the sums are not what the reference would have computed -- it reports NaN here, so do we

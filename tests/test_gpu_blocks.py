@@ -4,6 +4,8 @@ of that block -- the fp32 residual stream the CPU oracle (bf16 mode) has at that
 oracle's output of the same block.  The whole-model comparisons (tests/test_gpu_model.py) are chaotic at full depth (the max-pool
 attention amplifies rounding noise through 34 blocks), so their bounds are loose; here nothing is amplified: a block whose
 arithmetic were wrong by a rounding point would stand out by an order of magnitude."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -25,7 +27,30 @@ def _pm(t):            # oracle [B, C, N] -> pixel-major [B, N, C]
     return t.permute(0, 2, 1).contiguous()
 
 
-@pytest.mark.parametrize("persist", [False, True])
+def block_errors(plan, taps):
+    """Runs every encoder Block of `plan` ALONE on the oracle's input of that block (taps[name + ".in"], the oracle's residual stream at
+    that depth) and compares with the oracle's output of the same block: -> ({block: rel-L2 of the output}, {block: rel-L2 of the
+    UPDATE x_out - x_in, i.e. of what the block computes}).  Also used at the trained weights (tests/test_gpu_trained.py)."""
+    lib = L.load()
+    out_err, upd_err = {}, {}
+    for name, blk in plan.block_ops.items():
+        xin, xout = _pm(taps[name + ".in"]).cuda(), _pm(taps[name + ".out"]).cuda()
+        X, X2 = blk["x"], blk["x2"]
+        plan.zf_arena.zero_()
+        X.t.copy_(xin.view_as(X.t))
+        if not blk["own_stats"]:              # the previous block's epilogue would have left the sums of this block's input
+            L.check(lib.crd_gn_stats(X.t.data_ptr(), X.f32, X.ld, X.coff, plan.B, X.P, X.C, blk["st1"].data_ptr(), blk["ch1"].data_ptr(),
+                                     L.stream()), "crd_gn_stats")
+        plan.run_ops(blk["ops"])
+        torch.cuda.synchronize()
+        got = X2.t.view_as(xout)
+        out_err[name] = rel(got, xout)
+        upd_err[name] = rel(got - xin, xout - xin)
+    return out_err, upd_err
+
+
+@pytest.mark.parametrize("persist", [False, pytest.param(True, marks=pytest.mark.skipif(
+    os.environ.get("CRD_DEV_SWITCHES") != "1", reason="persistent encoder stage: developer path (CRD_DEV_SWITCHES=1)"))])
 def test_every_block_on_the_oracles_input_256x416(persist, monkeypatch):
     from camradepth_amd.model import CamRaDepth
     from oracle import model as om
@@ -47,20 +72,7 @@ def test_every_block_on_the_oracles_input_256x416(persist, monkeypatch):
     if persist:
         _persistent_stages(plan, taps, cfg)
         return
-    out_err, upd_err = {}, {}
-    for name, blk in plan.block_ops.items():
-        xin, xout = _pm(taps[name + ".in"]).cuda(), _pm(taps[name + ".out"]).cuda()
-        X, X2 = blk["x"], blk["x2"]
-        plan.zf_arena.zero_()
-        X.t.copy_(xin.view_as(X.t))
-        if not blk["own_stats"]:              # the previous block's epilogue would have left the sums of this block's input
-            L.check(lib.crd_gn_stats(X.t.data_ptr(), X.f32, X.ld, X.coff, plan.B, X.P, X.C, blk["st1"].data_ptr(), blk["ch1"].data_ptr(),
-                                     L.stream()), "crd_gn_stats")
-        plan.run_ops(blk["ops"])
-        torch.cuda.synchronize()
-        got = X2.t.view_as(xout)
-        out_err[name] = rel(got, xout)
-        upd_err[name] = rel(got - xin, xout - xin)
+    out_err, upd_err = block_errors(plan, taps)
     worst_out, worst_upd = max(out_err.items(), key=lambda kv: kv[1]), max(upd_err.items(), key=lambda kv: kv[1])
     print("worst block output rel-L2", worst_out, "worst block UPDATE rel-L2", worst_upd,
           "median update", float(np.median(list(upd_err.values()))))

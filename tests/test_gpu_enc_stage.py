@@ -18,7 +18,10 @@ from camradepth_amd import synth
 from camradepth_amd.config import ModelConfig
 from camradepth_amd.params import param_specs
 
-pytestmark = pytest.mark.gpu
+# Round 5: the persistent stage is a parked DEVELOPER path (forward-only, at parity in time, an unexplained per-process slow mode under
+# graph replay -- DESIGN section 4): these tests run only with CRD_DEV_SWITCHES=1 and no longer take ~2 minutes of every GPU test run.
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("CRD_DEV_SWITCHES") != "1", reason="persistent encoder stage: developer path (CRD_DEV_SWITCHES=1)")]
 
 
 def build(cfg, sd, train):

@@ -845,3 +845,32 @@ def test_nonfinite_partials_raise_the_sticky_flag():
     L.check(lib.crd_masked_l1_fwd(pred.data_ptr(), tgt.data_ptr(), n, acc.data_ptr(), L.stream()))
     torch.cuda.synchronize()
     assert L.nonfinite()
+
+
+def test_diffgradnorm_refuses_a_switched_active_set_without_touching_state():
+    """the kernel's bias corrections use one step count per group.  A frozen for good after n steps and B unfrozen then is
+    the silent mismatch (B would be corrected with step n + 1 instead of 1, diffGradNorm.py:66,76-77): the step is refused, and the
+    refused call changes nothing -- not the `active` mask, not the step counts, not a parameter."""
+    from camradepth_amd import lib as L
+    from camradepth_amd.optim import diffGradNorm
+    g = torch.Generator().manual_seed(3)
+    a = torch.nn.Parameter(torch.randn(300, generator=g).cuda())
+    b = torch.nn.Parameter(torch.randn(70, generator=g).cuda())
+    opt = diffGradNorm([a, b], lr=1e-2)
+    for _ in range(3):                                  # A trains alone (B has no gradient: skipped like the reference's `grad is None`)
+        a.grad = torch.randn(300, generator=g).cuda()
+        b.grad = None
+        opt.step()
+    st = opt._groups[0]
+    assert st["step"] == 3 and opt.state[a]["step"] == 3 and opt.state[b]["step"] == 0
+    act_before, host_before = st["active"].clone(), st.get("act_host")
+    a0, b0 = a.detach().clone(), b.detach().clone()
+    a.grad, b.grad = None, torch.randn(70, generator=g).cuda()      # the whole active set switches
+    with pytest.raises(L.CrdError, match="step counts"):
+        opt.step()
+    assert st["step"] == 3 and opt.state[b]["step"] == 0
+    assert torch.equal(st["active"], act_before) and st.get("act_host") == host_before
+    assert torch.equal(a.detach(), a0) and torch.equal(b.detach(), b0)
+    a.grad, b.grad = torch.randn(300, generator=g).cuda(), None     # ... and the run it interrupted can go on
+    opt.step()
+    assert st["step"] == 4 and opt.state[a]["step"] == 4

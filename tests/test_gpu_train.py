@@ -408,6 +408,12 @@ def test_per_rank_dropout_streams_differ_and_rank0_is_unchanged():
     assert set(np.unique(drawn[1][0].cpu().numpy()).round(4)) <= {0.0, 1.25}
 
 
+# The streaming 3x3 weight gradients split the pixels S ways and add their fp32 partial copies in index order; the graph step caps their
+# workgroups (late stream: 160) and so uses another S than the eager step: a different summation TREE of the same fp32 products, not a
+# different sum order of integers.  Measured round 5: see the print below (bound = 2 x measured).
+B16_GRAPH_VS_EAGER = 2e-2
+
+
 def test_graph_step_matches_eager_step_at_batch16():
     """Config C5's per-GPU batch (16 x 7 x 256 x 416): the two-stream graph step against the same step run eagerly in program order
     (different grid caps and weight-gradient split counts than at batch 8): same loss bits, gradients within the summation-tree
@@ -433,7 +439,12 @@ def test_graph_step_matches_eager_step_at_batch16():
         torch.cuda.empty_cache()
     (lg, gg), (le, ge) = res
     assert lg == le, (lg, le)
-    assert rel(gg, ge) < 2e-2 and float(ge.abs().sum()) > 0
+    r16 = rel(gg, ge)
+    print(f"B=16 graph vs eager gradient rel-L2 {r16:.3e}")
+    assert r16 < B16_GRAPH_VS_EAGER and float(ge.abs().sum()) > 0
+
+
+C2_GRAPH_VS_EAGER_GRAD, C2_GRAPH_VS_EAGER_UPDATE = 2e-2, 0.2      # TIGHTEN: set from the round-5 measurement (printed below)
 
 
 def test_train_step_at_benchmark_size_graph_vs_eager_and_oracle():
@@ -473,8 +484,10 @@ def test_train_step_at_benchmark_size_graph_vs_eager_and_oracle():
     g_rel = rel(m2.flat_grad, g1)
     d_rel = rel(m2.flat - p_before, m1.flat - p_before)
     print(f"C2 train step, graph vs eager: loss {l2['loss']:.6f} / {float(loss):.6f}, grad rel-L2 {g_rel:.4f}, update rel-L2 {d_rel:.4f}")
-    assert g_rel < 2e-2, g_rel          # measured 6e-4
-    assert d_rel < 0.2, d_rel           # measured 0.07: sign-like first diffGradNorm step on near-zero gradient elements
+    print(f"C2 graph vs eager: bit-equal gradient {torch.equal(m2.flat_grad, g1)}, update {torch.equal(m2.flat, m1.flat)}; "
+          f"grad rel-L2 {g_rel:.3e}, update rel-L2 {d_rel:.3e}")
+    assert g_rel < C2_GRAPH_VS_EAGER_GRAD, g_rel
+    assert d_rel < C2_GRAPH_VS_EAGER_UPDATE, d_rel
     # oracle at batch 2 (same weights, masks of the first two samples)
     b2 = {k: v[:2] for k, v in batch_h.items()}
     mk2 = {"drop_path": [t[:2] for t in masks["drop_path"]], "dropout2d": [t[:2] for t in masks["dropout2d"]]}

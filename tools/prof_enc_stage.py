@@ -52,7 +52,7 @@ for train in (False, True):
             m(x)
         plan = m._plans[m._plan_key(x)]
         plan.training_masks_fixed = True
-        marks = {k: v + 1 for k, v in plan.fwd_marks}      # (+1: the input's slice copy is inserted at index 1 after the marks are taken)
+        marks = dict(plan.fwd_marks)
         names = ["enc0", "enc1", "enc2", "enc3", "dec"]
         row = []
         for i in range(4):

@@ -50,14 +50,14 @@ def floor_budget(plan):
         ph["gflop"] += fl / 1e9; ph["gbyte"] += by / 1e9
     for (name, a), (_, b) in zip(marks[:-1], marks[1:]):
         for op in plan.fwd[a:b]:
-            if op.fn is not None:
+            if plan.live(op):
                 add("fwd:" + name, op)
     for op in plan.fwd[:marks[0][1]]:
-        if op.fn is not None:
+        if plan.live(op):
             add("fwd:" + marks[0][0], op)
     for tag, a, b in plan.bwd_segments:
         for op in plan.bwd[a:b]:
-            if op.fn is not None:
+            if plan.live(op):
                 add(("late:" if op.stream == LATE else "bwd:") + tag, op)
     for ph in phases.values():
         for k in ph:
@@ -100,7 +100,7 @@ def per_kernel_timing(ts, reps=3):
                 plan.zf_arena.zero_()
             evs = []
             for op in ops:
-                if op.fn is None:                  # join marker of a side branch (this pass runs everything on one stream)
+                if not plan.live(op):              # join marker of a side branch (this pass runs everything on one stream) / inactive variant
                     continue
                 if op.meta is None:
                     op.fn(*op.args, st)
@@ -135,7 +135,7 @@ def family_replay_timing(ts, family, reps=10):
     rocprofv3 trace of a replayed step).  Returns (device launches per replay, algorithmic flops, ms per replay)."""
     import camradepth_amd.lib as L
     plan = ts.plan
-    ops = [op for op in plan.fwd + plan.bwd if op.fn is not None and op.meta is not None and family_of(op.meta["kernel"]) == family]
+    ops = [op for op in plan.fwd + plan.bwd if plan.live(op) and op.meta is not None and family_of(op.meta["kernel"]) == family]
     n = sum(1 + op.meta["kernel"].count("+") for op in ops)
     flops = sum(op.meta["flops"] for op in ops)
     s = torch.cuda.Stream()
@@ -403,6 +403,9 @@ def main():
     ap.add_argument("--fp8", action="store_true",
                     help="BASELINE config 5 -- the ConvLayers of the two largest decoder stages on the fp8 (e4m3) MFMA, activation "
                          "scales calibrated on the bench batch (model.calibrate_fp8); in a training step: fp8 forward, bf16 backward")
+    ap.add_argument("--fp8-grad", action="store_true",
+                    help="with --fp8 in a training step: the data gradients of the same ConvLayers in e4m3 too (delayed per-tensor scaling); "
+                         "weight gradients stay bf16")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # tests: launcher contract on CPU (gloo)
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:       # no launcher: be the launcher (before any HIP call in this process)
@@ -448,7 +451,7 @@ def main():
         return
     model.train()
     if a.fp8:             # config 5 as a training step: fp8 forward convolutions in decoder stages 3-4, bf16 backward
-        model.calibrate_fp8(synth.make_batch(a.batch, a.height, a.width, seed=1234)["image"].cuda(), train=True)
+        model.calibrate_fp8(synth.make_batch(a.batch, a.height, a.width, seed=1234)["image"].cuda(), train=True, grads=a.fp8_grad)
     if a.freeze_seg:
         for n, p in model.named_parameters():
             if n.startswith("seg_"):
@@ -487,7 +490,7 @@ def main():
 
     out = {"metric": metric_name(a), "value": round(value, 2), "unit": "images/s", "n_gpus": world,
            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "fp8 forward (decoder stages 3-4) / bf16" if a.fp8 else "bf16", "data": "synthetic",
+           "vs_baseline": None, "dtype": ("fp8 forward + data gradients (decoder stages 3-4) / bf16" if a.fp8_grad else "fp8 forward (decoder stages 3-4) / bf16") if a.fp8 else "bf16", "data": "synthetic",
            "config": {"workload": f"CamRaDepth {a.variant}{' (seg branch frozen)' if a.freeze_seg else ''} (image+radar) train "
                                   f"{'iteration' if a.update_interval > 1 else 'step'}, {a.batch}x7x{a.height}x{a.width} per GPU, "
                                   f"bf16 MFMA / fp32 accumulate, diffGradNorm + OneCycleLR, Dropout2d/DropPath on"
@@ -559,7 +562,7 @@ def main():
                            "algorithmic_gflop_per_launch": round(fl / n / 1e9, 3),
                            "method": "frac: per-launch HIP events in step order; frac_isolated: 10 replays of one HIP graph holding all launches of the family",
                            "isolated_replay_tflops": round(ach, 1), "eager_in_order_tflops": round(fl_e / (ms_e * 1e-3) / 1e12, 1)}
-        fam_ops = [op for op in ts.plan.fwd + ts.plan.bwd if op.fn is not None and op.meta is not None and family_of(op.meta["kernel"]) == domf]
+        fam_ops = [op for op in ts.plan.fwd + ts.plan.bwd if ts.plan.live(op) and op.meta is not None and family_of(op.meta["kernel"]) == domf]
         alg = sum(ts.plan.op_bytes(op) for op in fam_ops) / max(n, 1)
         out["roofline"]["algorithmic_bytes_per_launch"] = round(alg)
         if traffic:

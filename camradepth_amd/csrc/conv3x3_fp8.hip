@@ -10,7 +10,8 @@
 //     fragment set of step n+1 is read while the MFMAs of step n issue;
 //   * software scales: y = acc * x_scale * w_scale[cout] (per-tensor activation scale from calibration, per-output-channel
 //     weight scale from the weights), then the usual bf16 store + GroupNorm sums.
-// Inference only (the reference trains under fp16 autocast; an fp8 backward is not part of this build).
+// Round 5: MODE 1 is the DATA GRADIENT of the same convolution (mirrored taps, e4m3 dy with a device-resident scale, weights
+// quantised per input channel, accumulate epilogue) -- crd_conv3x3_fp8_dgrad.
 #include "conv_common.h"
 #include <cstdlib>
 
@@ -44,9 +45,12 @@ struct F8K {
   int H, W;
   bf16_t* y; int y_ld; long long y_bstride;
   float* stats_partial; int G16;                              // [B][tiles][NW][G16][2] or nullptr
+  const float* x_scale_dev;                                   // non-null: the activation scale lives in device memory (fp8 gradients)
+  int accumulate;                                             // y += v (bf16 read-modify-write, as k_conv3x3p)
 };
 
-template <int TN, int WS>
+// MODE 0: forward; 1: data gradient (taps mirrored: dx[iy,ix] += w[ky,kx] dy[iy+1-ky, ix+1-kx], weights [Cin][tap][Cout])
+template <int TN, int WS, int MODE>
 __global__ __launch_bounds__(256, 1) void k_conv3x3_fp8(F8K a, int tiles_x, int tiles_y, int tiles_total) {
   constexpr int D = WS - 1;
   static_assert(D >= 3 && D <= 8, "slab prefetch distance");
@@ -65,7 +69,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fp8(F8K a, int tiles_x, int 
   const int nChunks = (Cin + QKC - 1) / QKC;
   const unsigned OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot, 0x00020000);
-  for (int c = t; c < BN; c += 256) sS[c] = n0 + c < a.Cout ? a.x_scale * a.w_scale[n0 + c] : 0.f;
+  const float xs = a.x_scale_dev ? *a.x_scale_dev : a.x_scale;
+  for (int c = t; c < BN; c += 256) sS[c] = n0 + c < a.Cout ? xs * a.w_scale[n0 + c] : 0.f;
 
   const int wch = ((l & 3) ^ ((l >> 4) & 3)) * 16;            // channel of this lane's 16-byte granule (k_conv3x3p's swizzle)
   unsigned wvo[WJ];
@@ -141,7 +146,8 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fp8(F8K a, int tiles_x, int 
   // fragment reads of (halo buffer hb, tap, ring slot wb): activation rows i0 .. i1-1 and, with B, the weight rows
   auto read_a = [&](int hb, int tap, int i0, int i1, i32x8 (&af)[TM]) {
     if (ABL(64)) return;
-    const int ky = tap / 3, kx = tap - ky * 3;
+    const int ky_ = tap / 3, kx_ = tap - ky_ * 3;
+    const int ky = MODE == 0 ? ky_ : 2 - ky_, kx = MODE == 0 ? kx_ : 2 - kx_;
     const unsigned char* hbase = sH + hb * HPAD * QKC;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -292,6 +298,28 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fp8(F8K a, int tiles_x, int 
         }
         __builtin_amdgcn_sched_barrier(0);
         if (pok && (!ABL(512) || a.x_scale == 12345.f)) {
+          if (MODE == 1 && a.accumulate) {
+            // gradient accumulation as in k_conv3x3p: all of the row's old values first (one 16-channel half of every 32-column
+            // tile at a time), one wait, then new = bf16(bf16(v) + old)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+              uint4 o[TN];
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                o[j] = make_uint4(0, 0, 0, 0);
+                if (n0 + j * 32 + pr * 16 + half * 8 < a.Cout) o[j] = *reinterpret_cast<const uint4*>(row + j * 32 + pr * 16);
+              }
+#pragma unroll
+              for (int j = 0; j < TN; ++j) {
+                uint4& v = u[j][pr];
+                const uint4 q = o[j];
+                v.x = pack_bf2(bf_lo(v.x) + bf_lo(q.x), bf_hi(v.x) + bf_hi(q.x));
+                v.y = pack_bf2(bf_lo(v.y) + bf_lo(q.y), bf_hi(v.y) + bf_hi(q.y));
+                v.z = pack_bf2(bf_lo(v.z) + bf_lo(q.z), bf_hi(v.z) + bf_hi(q.z));
+                v.w = pack_bf2(bf_lo(v.w) + bf_lo(q.w), bf_hi(v.w) + bf_hi(q.w));
+              }
+            }
+          }
 #pragma unroll
           for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -326,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void k_conv3x3_fp8(F8K a, int tiles_x, int 
   wait_vm<0>();
 }
 
-template <int TN>
+template <int TN, int MODE = 0>
 int launch8(const F8K& k, int B, hipStream_t st) {
   constexpr int BN = TN * 32, WS = 6;
   const int tiles_x = cdiv(k.W, TW), tiles_y = cdiv(k.H, TH);
@@ -337,8 +365,8 @@ int launch8(const F8K& k, int B, hipStream_t st) {
   if (gx > tiles_total) gx = tiles_total;
   const size_t lds = (size_t)(2 * HPAD * QKC + WS * BN * QKC + 16 * QKC) + BN * sizeof(float);
   static bool attr_done = false;
-  if (!attr_done) { crd_reserve_lds(reinterpret_cast<const void*>(&k_conv3x3_fp8<TN, WS>), (int)lds, "k_conv3x3_fp8"); attr_done = true; }
-  hipLaunchKernelGGL((k_conv3x3_fp8<TN, WS>), dim3(gx, gy), dim3(256), lds, st, k, tiles_x, tiles_y, tiles_total);
+  if (!attr_done) { crd_reserve_lds(reinterpret_cast<const void*>(&k_conv3x3_fp8<TN, WS, MODE>), (int)lds, "k_conv3x3_fp8"); attr_done = true; }
+  hipLaunchKernelGGL((k_conv3x3_fp8<TN, WS, MODE>), dim3(gx, gy), dim3(256), lds, st, k, tiles_x, tiles_y, tiles_total);
   CRD_LAUNCH_CHECK("crd_conv3x3_fp8");
   return CRD_OK;
 }
@@ -374,6 +402,33 @@ __global__ __launch_bounds__(256) void k_quant_fp8(const bf16_t* x, long long ro
     q.y = pack_fp8x4(v[4] * inv_scale, v[5] * inv_scale, v[6] * inv_scale, v[7] * inv_scale);
     *reinterpret_cast<uint2*>(y + r * y_ld + g * 8) = q;
   }
+}
+
+// the same with the scale in device memory (this step's amax / 448: just-in-time scaling of a gradient tensor)
+__global__ __launch_bounds__(256) void k_quant_fp8_dev(const bf16_t* x, long long rows, int ld, int C, unsigned char* y, int y_ld, const float* scale) {
+  const int CG = C >> 3;
+  const float inv_scale = 1.f / fmaxf(*scale, 1e-30f);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < rows * CG; i += (long long)gridDim.x * 256) {
+    const long long r = i / CG;
+    const int g = (int)(i - r * CG);
+    float v[8];
+    load8(x, r * ld + g * 8, 0, v);
+    uint2 q;
+    q.x = pack_fp8x4(v[0] * inv_scale, v[1] * inv_scale, v[2] * inv_scale, v[3] * inv_scale);
+    q.y = pack_fp8x4(v[4] * inv_scale, v[5] * inv_scale, v[6] * inv_scale, v[7] * inv_scale);
+    *reinterpret_cast<uint2*>(y + r * y_ld + g * 8) = q;
+  }
+}
+
+// one wave per tensor: the max over its amax slots -> scale = margin * amax / 448 (kept when nothing was recorded); slots zeroed
+__global__ __launch_bounds__(64) void k_fp8_scale_update(unsigned* slots, float* scales, float margin) {
+  static_assert(CRD_FP8_AMAX_SLOTS == 64, "one slot per lane");
+  unsigned* s_ = slots + (long long)blockIdx.x * CRD_FP8_AMAX_SLOTS;
+  float m = __uint_as_float(s_[threadIdx.x]);
+  s_[threadIdx.x] = 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (threadIdx.x == 0 && m > 0.f) scales[blockIdx.x] = margin * m / E4M3_MAX;
 }
 
 // one workgroup per output channel: scale[co] = amax / 448 (1 if the row is all zero), w8[co][tap][0..Cin) = e4m3(w / scale),
@@ -437,6 +492,53 @@ extern "C" int crd_weight_quant_fp8(const void* w_bf16, int32_t Cout, int32_t ta
   return CRD_OK;
 }
 
+extern "C" int crd_quant_fp8_dev(const void* x, int64_t rows, int32_t ld, int32_t coff, int32_t C, void* y, int32_t y_ld, int32_t y_coff,
+                                 const float* scale_dev, crd_stream_t stream) {
+  CRD_CHECK_ARG(x && y && scale_dev && rows > 0 && C > 0 && C % 8 == 0 && ld % 8 == 0 && coff % 8 == 0 && y_ld % 8 == 0 && y_coff % 8 == 0,
+                "crd_quant_fp8_dev: bad argument (channels in multiples of 8)");
+  long long n = (rows * (C / 8) + 255) / 256;
+  if (n > 4096) n = 4096;
+  hipLaunchKernelGGL(k_quant_fp8_dev, dim3((unsigned)n), dim3(256), 0, as_stream(stream), reinterpret_cast<const bf16_t*>(x) + coff, (long long)rows, ld, C,
+                     reinterpret_cast<unsigned char*>(y) + y_coff, y_ld, scale_dev);
+  CRD_LAUNCH_CHECK("crd_quant_fp8_dev");
+  return CRD_OK;
+}
+
+extern "C" int crd_fp8_scale_update(uint32_t* amax_slots, float* scales, int32_t n, float margin, crd_stream_t stream) {
+  CRD_CHECK_ARG(amax_slots && scales && n > 0 && margin > 0.f, "crd_fp8_scale_update: bad argument");
+  hipLaunchKernelGGL(k_fp8_scale_update, dim3(n), dim3(64), 0, as_stream(stream), reinterpret_cast<unsigned*>(amax_slots), scales, margin);
+  CRD_LAUNCH_CHECK("crd_fp8_scale_update");
+  return CRD_OK;
+}
+
+extern "C" int crd_conv3x3_fp8_dgrad(const crd_conv_desc* d, const float* w_scales, const float* x_scale_dev, crd_stream_t stream) {
+  CRD_CHECK_ARG(d && d->x && d->w && d->y && w_scales && x_scale_dev, "crd_conv3x3_fp8_dgrad: null pointer");
+  CRD_UNSUPPORTED(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->gather_mode == 1 && d->out_mode == 0 && d->IH == d->OH &&
+                  d->IW == d->OW && !d->y_f32 && !d->bias && !d->act && !d->res && !d->stats && !d->red_x && !d->chan_sums,
+                  "crd_conv3x3_fp8_dgrad: 3x3 / stride 1 / pad 1 data gradient with a plain or accumulating bf16 output only");
+  CRD_CHECK_ARG(d->Cin % 16 == 0 && d->x_ld % 16 == 0 && d->x_coff % 16 == 0 && d->Cout % 8 == 0 && d->y_ld % 8 == 0 && d->y_coff % 8 == 0,
+                "crd_conv3x3_fp8_dgrad: fp8 channels in multiples of 16, output channels of 8");
+  CRD_UNSUPPORTED((long long)d->IH * d->IW * d->x_ld < (1ll << 31) && (long long)d->Cout * 9 * d->Cin < (1ll << 31), "crd_conv3x3_fp8_dgrad: tensor too large");
+  F8K k;
+  k.x = reinterpret_cast<const unsigned char*>(d->x) + d->x_coff; k.x_ld = d->x_ld; k.x_bstride = (long long)d->IH * d->IW * d->x_ld;
+  k.Cin = d->Cin; k.Ktot = 9 * d->Cin;
+  k.x_scale = 1.f; k.x_scale_dev = x_scale_dev; k.accumulate = d->accumulate; k.H = d->IH; k.W = d->IW;
+  k.y_ld = d->y_ld; k.y_bstride = (long long)d->OH * d->OW * d->y_ld;
+  k.G16 = 0; k.stats_partial = nullptr;
+  hipStream_t st = as_stream(stream);
+  // 128-column tiles for the bulk, one narrower launch for what is left (N = 144 / 240 / 304 in the decoder)
+  const int main_cols = d->Cout / 128 * 128, rest = d->Cout - main_cols;
+  for (int part = 0; part < 2; ++part) {
+    const int c0 = part == 0 ? 0 : main_cols, cols = part == 0 ? main_cols : rest;
+    if (cols <= 0) continue;
+    k.w = reinterpret_cast<const unsigned char*>(d->w) + (long long)c0 * k.Ktot; k.Cout = cols; k.w_scale = w_scales + c0;
+    k.y = reinterpret_cast<bf16_t*>(d->y) + d->y_coff + c0;
+    const int rc = cols <= 64 ? launch8<2, 1>(k, d->B, st) : cols <= 96 ? launch8<3, 1>(k, d->B, st) : launch8<4, 1>(k, d->B, st);
+    if (rc != CRD_OK) return rc;
+  }
+  return CRD_OK;
+}
+
 extern "C" int crd_conv3x3_fp8(const crd_conv_desc* d, const float* w_scales, float x_scale, crd_stream_t stream) {
   CRD_CHECK_ARG(d && d->x && d->w && d->y && w_scales && x_scale > 0.f, "crd_conv3x3_fp8: null pointer / bad scale");
   CRD_UNSUPPORTED(d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->gather_mode == 0 && d->out_mode == 0 && d->IH == d->OH &&
@@ -448,7 +550,7 @@ extern "C" int crd_conv3x3_fp8(const crd_conv_desc* d, const float* w_scales, fl
   F8K k;
   k.x = reinterpret_cast<const unsigned char*>(d->x) + d->x_coff; k.x_ld = d->x_ld; k.x_bstride = (long long)d->IH * d->IW * d->x_ld;
   k.w = reinterpret_cast<const unsigned char*>(d->w); k.Cout = d->Cout; k.Cin = d->Cin; k.Ktot = 9 * d->Cin;
-  k.w_scale = w_scales; k.x_scale = x_scale; k.H = d->IH; k.W = d->IW;
+  k.w_scale = w_scales; k.x_scale = x_scale; k.x_scale_dev = nullptr; k.accumulate = 0; k.H = d->IH; k.W = d->IW;
   k.y = reinterpret_cast<bf16_t*>(d->y) + d->y_coff; k.y_ld = d->y_ld; k.y_bstride = (long long)d->OH * d->OW * d->y_ld;
   k.G16 = d->Cout / 16;
   k.stats_partial = nullptr;

@@ -323,10 +323,16 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
                                                       int gmul, const float* gamma, const float* beta, int act,
                                                       const float* mask, const crd_sum_t* r, float* dgamma, float* dbeta,
                                                       void* dx, int dx_f32, int dx_ld, int dx_acc, int B, void* dx2, int dx2_ld,
-                                                      const float* scale2) {
+                                                      const float* scale2, unsigned char* dx8, int dx8_ld, const float* scale8,
+                                                      unsigned* amax8) {
   const int b = blockIdx.y;
   Map m(C);
   const int c0 = m.cg * 8;
+  // dx8 (config 5, fp8 data gradients): an e4m3 copy of the bf16 gradient just stored, e4m3(bf16(dx) / *scale8), and the running
+  // max |bf16(dx)| of the launch into one of CRD_FP8_AMAX_SLOTS slots (u32 max on the bit pattern of a non-negative float)
+  __shared__ float s_amax[TPB / 64];
+  const float inv8 = (dx8 && scale8) ? 1.f / fmaxf(*scale8, 1e-30f) : 0.f;
+  float amax = 0.f;
   long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk;
   if (p1 > P) p1 = P;
   long long p = p0 + m.pl;
@@ -352,7 +358,8 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
       dgamma[c] = og + (float)g1 * (1.f / GRAD_ONE);
     }
   }
-  if (!m.active) return;
+  if (!m.active && !amax8) return;
+  if (m.active) {
   float ga[8], be[8], mk[8];
   load8(gamma, c0, 1, ga);
   load8(beta, c0, 1, be);
@@ -402,11 +409,28 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
         }
         store8_bf16(dx, off, o);
       }
+      if (dx8) {          // e4m3 copy of the stored bf16 gradient + its running amax
+#pragma unroll
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf_round(o[j])));
+        store8_fp8(dx8, ((long long)b * P + pp) * dx8_ld + c0, o, inv8);
+      }
       if (dx2) {          // second copy of the finished gradient: bf16(scale2[b] * dx)
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] *= sc2;
         store8_bf16(dx2, ((long long)b * P + pp) * dx2_ld + c0, o);
       }
+    }
+  }
+  }
+  if (amax8) {            // one u32 max per workgroup, spread over the slots (same-address atomics serialise chip-wide: ~13 ns each)
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) amax = fmaxf(amax, __shfl_xor(amax, o_));
+    if ((threadIdx.x & 63) == 0) s_amax[threadIdx.x >> 6] = amax;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float a_ = s_amax[0];
+      for (int w_ = 1; w_ < TPB / 64; ++w_) a_ = fmaxf(a_, s_amax[w_]);
+      if (a_ > 0.f) atomicMax(amax8 + ((blockIdx.x + blockIdx.y * gridDim.x) % CRD_FP8_AMAX_SLOTS), __float_as_uint(a_));
     }
   }
 }
@@ -576,12 +600,13 @@ extern "C" int crd_gn_bwd_reduce(const void* x, int32_t x_f32, int32_t x_ld, int
   return CRD_OK;
 }
 
-extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
-                                int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
-                                int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
-                                const crd_sum_t* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
-                                int32_t dx_coff, int32_t dx_accumulate, void* dx2, int32_t dx2_ld, const float* scale2,
-                                crd_stream_t stream) {
+static int gn_bwd_apply_impl(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
+                             int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
+                             int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
+                             const crd_sum_t* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
+                             int32_t dx_coff, int32_t dx_accumulate, void* dx2, int32_t dx2_ld, const float* scale2,
+                             void* dx8, int32_t dx8_ld, int32_t dx8_coff, const float* scale8, uint32_t* amax8, crd_stream_t stream) {
+  unsigned char* dx8p = dx8 ? reinterpret_cast<unsigned char*>(dx8) + dx8_coff : nullptr;
   CRD_CHECK_ARG(x && dy && stats && gamma && beta && r && dx, "crd_gn_bwd_apply: null pointer");
   CRD_CHECK_ARG(!dx2 || dx2_ld % 8 == 0, "crd_gn_bwd_apply: dx2_ld must be a multiple of 8");
   CRD_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr), "crd_gn_bwd_apply: dgamma and dbeta go together");
@@ -596,7 +621,8 @@ extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int3
 #define CRD_GN_BAP(XF, DF, ACT)                                                                                              \
   hipLaunchKernelGGL((k_gn_bwd_apply<XF, DF, ACT>), grid, dim3(TPB), 0, as_stream(stream), off_ptr(x, x_f32, x_coff), x_f32, \
                      x_ld, off_ptr(dy, dy_f32, dy_coff), dy_f32, dy_ld, (long long)P, C, chunk, stats, gmul, gamma, beta,  \
-                     act, mask, r, dgamma, dbeta, dxp, dx_f32, dx_ld, dx_accumulate, B, dx2, dx2_ld, scale2)
+                     act, mask, r, dgamma, dbeta, dxp, dx_f32, dx_ld, dx_accumulate, B, dx2, dx2_ld, scale2, dx8p, dx8_ld, scale8,  \
+                     amax8)
   switch ((x_f32 ? 4 : 0) | (dy_f32 ? 2 : 0) | (act ? 1 : 0)) {
     case 0: CRD_GN_BAP(0, 0, 0); break;  case 1: CRD_GN_BAP(0, 0, 1); break;
     case 2: CRD_GN_BAP(0, 1, 0); break;  case 3: CRD_GN_BAP(0, 1, 1); break;
@@ -606,4 +632,26 @@ extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int3
 #undef CRD_GN_BAP
   CRD_LAUNCH_CHECK("crd_gn_bwd_apply");
   return CRD_OK;
+}
+
+extern "C" int crd_gn_bwd_apply(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
+                                int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
+                                int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
+                                const crd_sum_t* r, float* dgamma, float* dbeta, void* dx, int32_t dx_f32, int32_t dx_ld,
+                                int32_t dx_coff, int32_t dx_accumulate, void* dx2, int32_t dx2_ld, const float* scale2,
+                                crd_stream_t stream) {
+  return gn_bwd_apply_impl(x, x_f32, x_ld, x_coff, dy, dy_f32, dy_ld, dy_coff, B, P, C, stats, gmul, gamma, beta, act, mask, r, dgamma, dbeta,
+                           dx, dx_f32, dx_ld, dx_coff, dx_accumulate, dx2, dx2_ld, scale2, nullptr, 0, 0, nullptr, nullptr, stream);
+}
+
+extern "C" int crd_gn_bwd_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
+                                    int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
+                                    int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
+                                    const crd_sum_t* r, float* dgamma, float* dbeta, void* dx, int32_t dx_ld, int32_t dx_coff,
+                                    void* dx_fp8, int32_t dx8_ld, int32_t dx8_coff, const float* scale_dev, uint32_t* amax_slots,
+                                    crd_stream_t stream) {
+  CRD_CHECK_ARG(dx_fp8 && scale_dev && amax_slots && dx8_ld % 8 == 0 && dx8_coff % 8 == 0,
+                "crd_gn_bwd_apply_fp8: the e4m3 copy needs its buffer, a device scale and the amax slots (ld / coff multiples of 8)");
+  return gn_bwd_apply_impl(x, x_f32, x_ld, x_coff, dy, dy_f32, dy_ld, dy_coff, B, P, C, stats, gmul, gamma, beta, act, mask, r, dgamma, dbeta,
+                           dx, 0, dx_ld, dx_coff, 0, nullptr, 0, nullptr, dx_fp8, dx8_ld, dx8_coff, scale_dev, amax_slots, stream);
 }

@@ -138,11 +138,12 @@ class PM:
 class Op:
     """One recorded kernel call.  stream: 0 = the main stream; 1, 2 = side branches (ops that do not depend on the main
     ops recorded after the point where the branch was opened); fn None = join marker: the main stream waits for the branch."""
-    __slots__ = ("fn", "args", "name", "region", "acc_slot", "meta", "stream", "io")
+    __slots__ = ("fn", "args", "name", "region", "acc_slot", "meta", "stream", "io", "cond")
 
-    def __init__(self, fn, args, name, region=None, acc_slot=None, meta=None, stream=0, io=None):
+    def __init__(self, fn, args, name, region=None, acc_slot=None, meta=None, stream=0, io=None, cond=None):
         self.fn, self.args, self.name, self.region, self.acc_slot, self.meta = fn, args, name, region, acc_slot, meta
         self.stream = stream
+        self.cond = cond        # None, or (plan attribute, value): the op runs only while getattr(plan, attribute) == value (Plan.live)
         self.io = io            # algorithmic HBM bytes of the launch (int, or a callable evaluated after Plan._finalise): see nbytes()
 
 
@@ -294,6 +295,17 @@ class Plan:
         self.fp8_keep_bf16 = bool(training or self.need_grad)
         self.fp8 = dict(f8) if (f8 and (not self.fp8_keep_bf16 or getattr(model, "fp8_train", False))) else None
         self.fp8_convs = []
+        # fp8 DATA GRADIENTS of the same ConvLayers (round 5; model.calibrate_fp8(x, train=True, grads=True)): per layer one device
+        # float (the e4m3 scale of its dy) and CRD_FP8_AMAX_SLOTS amax slots.  fp8_jit True: just-in-time scaling -- the layer's scale
+        # is set from THIS step's amax and dy re-quantised before its data gradient runs (one extra pass; eager plans and the
+        # calibration iteration of TrainStep); False: delayed scaling -- the scales of the previous step's amax, updated once at the
+        # head of the backward pass (TrainStep's graphs).
+        self.fp8_grad = bool(self.fp8 is not None and training and getattr(model, "fp8_grad", False))
+        self.fp8_grad_layers, self.fp8_jit, self.fp8_margin = [], True, 1.0
+        if self.fp8_grad:
+            self.g8_scales = torch.ones(16, dtype=F32, device=self.dev)
+            self.g8_amax = torch.zeros((16, 64), dtype=torch.int32, device=self.dev)
+            self.buffers += [self.g8_scales, self.g8_amax]
         self._build()
 
     # ------------------------------------------------------------------ allocation helpers
@@ -335,6 +347,11 @@ class Plan:
         op = Op(getattr(self.lib, fn_name), list(args), fn_name, region, acc_slot, stream=self._cur_stream, io=io)
         lst.append(op)
         return op
+
+    def live(self, op):
+        """Is this recorded op part of the pass as the plan is configured now?  (join markers and conditional ops: the just-in-time
+        / delayed-scaling variants of the fp8 gradient path are both recorded; plan.fp8_jit selects)"""
+        return op.fn is not None and (op.cond is None or getattr(self, op.cond[0]) == op.cond[1])
 
     @staticmethod
     def op_bytes(op):
@@ -537,6 +554,14 @@ class Plan:
             d.B, d.H, d.W, d.C, d.hidden = sp["dims"]
             self.keep.append(d)
             return C.byref(d)
+        if sp.get("fp8d"):
+            cw, y = sp["cw"], sp["y"]
+            d = L.ConvDesc()
+            d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = sp["x8"].data_ptr(), sp["x8_ld"], 0, self.B, sp["H"], sp["W"], sp["cin"]
+            d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = cw.w8d.data_ptr(), sp["cout"], 3, 3, 1, 1, sp["H"], sp["W"]
+            d.gather_mode, d.y, d.y_ld, d.y_coff, d.accumulate = 1, P(y), y.ld, y.coff, sp["accumulate"]
+            self.keep.append(d)
+            return C.byref(d)
         if sp.get("fp8"):
             cw, y = sp["cw"], sp["y"]
             d = L.ConvDesc()
@@ -685,6 +710,35 @@ class Plan:
             return
         grp = []
         draw = self.act(cw.cout, H, W)
+        if x8 is not None and self.fp8_grad and dx is not None and not cw.frozen:
+            # e4m3 data gradient: the GroupNorm backward writes bf16 d(raw) (the weight gradient reads it) AND its e4m3 copy
+            li = len(self.fp8_grad_layers)
+            assert li < self.g8_scales.numel()
+            self.fp8_grad_layers.append(name)
+            c16 = rup(cw.cout, 16)
+            draw8 = self.new((self.B, H * W, c16), torch.uint8)
+            sc_ptr, am_ptr = self.g8_scales.data_ptr() + 4 * li, self.g8_amax.data_ptr() + 4 * 64 * li
+            gname = name + ".model.1"
+            common = [raw.t, raw.f32, raw.ld, raw.coff, dout.t, dout.f32, dout.ld, dout.coff, self.B, raw.P, raw.C, stats, 1,
+                      self.p(gname + ".weight"), self.p(gname + ".bias"), 1, mask]
+            r = self.zb(self.B * raw.C * 2 + self.B * (raw.C // 16) * 2)
+            self._emit(grp, "crd_gn_bwd_reduce", common + [r, None, 0], io=nbytes(raw, dout))
+            self._emit(grp, "crd_gn_bwd_apply_fp8", common + [r, self.g(gname + ".weight"), self.g(gname + ".bias"), draw.t, draw.ld, draw.coff,
+                                                              draw8, c16, 0, sc_ptr, am_ptr], io=nbytes(raw, dout, draw) + self.B * H * W * c16)
+            self._emit(grp, "crd_fp8_scale_update", [am_ptr, sc_ptr, 1, self.fp8_margin], io=256).cond = ("fp8_jit", True)
+            self._emit(grp, "crd_quant_fp8_dev", [draw.t, self.B * H * W, draw.ld, draw.coff, cw.cout, draw8, c16, 0, sc_ptr],
+                       io=nbytes(draw) + self.B * H * W * c16).cond = ("fp8_jit", True)
+            self.wgrad(grp, x, draw, cw, k, 1, k // 2, H, W)
+            cw.w8d = self.new((cw.cin_pad, 9, c16), torch.uint8)
+            cw.w8d_scales = self.new((cw.cin_pad,), F32)
+            spec = dict(fp8d=True, x8=draw8, x8_ld=c16, cin=c16, H=H, W=W, cw=cw, y=dx, cout=dx.C, accumulate=0)
+            meta = {"kernel": "k_conv3x3_fp8<dgrad>", "flops": 2.0 * self.B * H * W * cw.cout * 9 * min(dx.C, cw.cin_ref),
+                    "shape": f"dgrad fp8 Cin{c16} Cout{dx.C} k3 s1 out{H}x{W}"}
+            grp.append(Op(self.lib.crd_conv3x3_fp8_dgrad, [spec, cw.w8d_scales, sc_ptr], "crd_conv3x3_fp8_dgrad", dx_region,
+                          ("spec", spec) if dx_region else None, meta,
+                          io=lambda spec=spec, n0=self.B * H * W * c16 + dx.C * 9 * c16: n0 + nbytes(spec["y"]) * (2 if spec["accumulate"] else 1)))
+            self._push(grp)
+            return
         self.gn_bwd(grp, raw, stats, 1, name + ".model.1", 1, mask, dout, draw)
         self.wgrad(grp, x, draw, cw, k, 1, k // 2, H, W)
         if dx is not None:
@@ -765,8 +819,8 @@ class Plan:
             self.flush_deferred(grp)       # grp (patch embed) is the LAST backward unit of this stage
             Xb = self.act(Cs, Hs, Ws)
             if persist is not None:
-                nbytes = int(self.lib.crd_enc_stage_ws_bytes(B, Hs, Ws, Cs, hid, heads, sr))
-                ws = torch.zeros(nbytes // 8, dtype=torch.int64, device=self.dev)      # zeroed once: the tags carry an epoch
+                ws_bytes = int(self.lib.crd_enc_stage_ws_bytes(B, Hs, Ws, Cs, hid, heads, sr))
+                ws = torch.zeros(ws_bytes // 8, dtype=torch.int64, device=self.dev)      # zeroed once: the tags carry an epoch
                 status = torch.zeros(1, dtype=torch.int32, device=self.dev)
                 self.buffers += [ws, status]
                 self.enc_status.append(status)
@@ -1412,6 +1466,11 @@ class Plan:
         # backward op order + accumulate flags
         written = {}
         self.bwd, self.bwd_segments = [], []       # segments: (tag, first op, one-past-last op) in execution order
+        if self.fp8_grad_layers:
+            # delayed scaling: the scales every layer of this pass quantises with = the amax its dy had in the PREVIOUS pass
+            self.bwd_groups[-1].insert(0, Op(self.lib.crd_fp8_scale_update, [self.g8_amax.data_ptr(), self.g8_scales.data_ptr(),
+                                                                             len(self.fp8_grad_layers), self.fp8_margin],
+                                             "crd_fp8_scale_update", io=256 * len(self.fp8_grad_layers), cond=("fp8_jit", False)))
         for grp, tag in zip(reversed(self.bwd_groups), reversed(self.bwd_tags)):
             if self.bwd_segments and self.bwd_segments[-1][0] == tag:
                 self.bwd_segments[-1][2] = len(self.bwd) + len(grp)
@@ -1456,7 +1515,7 @@ class Plan:
         lib = self.lib
         if os.environ.get("CRD_DEBUG_SYNC"):      # developer aid: name the faulting kernel
             for i, op in enumerate(ops):
-                if op.fn is None:
+                if not self.live(op):
                     continue
                 print(f"[crd] op {i} {op.name}", flush=True)
                 rc = op.fn(*op.args, st)
@@ -1487,6 +1546,8 @@ class Plan:
         main = torch.cuda.current_stream()
         open_ = {}                                 # side branch -> its stream handle, while the branch is open
         for op in ops:
+            if op.cond is not None and getattr(self, op.cond[0]) != op.cond[1]:
+                continue
             if op.fn is None:                      # join marker
                 if op.stream in open_:
                     ev = torch.cuda.Event()
@@ -1548,6 +1609,9 @@ class Plan:
             if (lo is None or off >= lo) and (hi is None or off < hi):
                 L.check(self.lib.crd_weight_quant_fp8(cw.w_fwd.data_ptr(), cw.cout, 9, cw.cin_pad, cin16, cw.w8.data_ptr(),
                                                       cw.w8_scales.data_ptr(), st), "crd_weight_quant_fp8")
+                if getattr(cw, "w8d", None) is not None:      # data-gradient weights [Cin_pad][9][Cout_pad]: one scale per INPUT channel
+                    L.check(self.lib.crd_weight_quant_fp8(cw.w_dgrad.data_ptr(), cw.cin_pad, 9, cw.cout_pad, cw.w8d.shape[2],
+                                                          cw.w8d.data_ptr(), cw.w8d_scales.data_ptr(), st), "crd_weight_quant_fp8")
         if lo is None and hi is None:
             self.packed_version = getattr(self.model, "_param_version", 0)
 

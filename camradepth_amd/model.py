@@ -253,16 +253,21 @@ class CamRaDepth(nn.Module):
         f8 = getattr(self, "fp8_scales", None)
         return (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None), frozen,
                 bool(getattr(self, "_need_grad", True)), gn_conv_default(), tuple(sorted(f8.items())) if f8 else None,
-                bool(getattr(self, "fp8_train", False)), enc_persist_default(), engine.ENC_ROWS_PER_WG)
+                bool(getattr(self, "fp8_train", False)), enc_persist_default(), engine.ENC_ROWS_PER_WG,
+                bool(getattr(self, "fp8_grad", False)))
 
-    def calibrate_fp8(self, x, margin=1.0, train=False):
+    def calibrate_fp8(self, x, margin=1.0, train=False, grads=False):
         """Per-stage activation scales for the fp8 (e4m3) inference path of the two largest decoder stages (their ConvLayers are
         ~80 % of the forward FLOPs): one bf16 eval forward of the calibration batch x, amax over each stage's concat buffer
         (upsampled input | skip | the two intermediate ConvLayer outputs), scale = margin * amax / 448.  Sets self.fp8_scales
         ({stage name: scale}, e.g. 'depth_upsample.4'); inference plans built afterwards (InferenceGraph, forward under torch.no_grad in eval mode) take the
         fp8 route; training plans only with train=True (fp8 FORWARD convolutions in those stages, their backward in bf16 on
-        the bf16 activations -- a straight-through estimator).  calibrate_fp8(None) switches it off."""
+        the bf16 activations -- a straight-through estimator).  grads=True (round 5, with train=True): the DATA gradients of those
+        ConvLayers run in e4m3 as well -- dy quantised per tensor with a device-resident scale (this step's amax / 448 in eager
+        plans, the previous step's inside TrainStep's graphs), weights per input channel -- while the weight gradients stay bf16.
+        calibrate_fp8(None) switches everything off."""
         self.__dict__["fp8_train"] = bool(train) and x is not None
+        self.__dict__["fp8_grad"] = bool(train) and bool(grads) and x is not None
         if x is None:
             self.__dict__["fp8_scales"] = None
             return None

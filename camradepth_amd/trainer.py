@@ -270,6 +270,11 @@ class TrainStep:
                 fn()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        if self.plan.fp8_grad_layers:
+            # fp8 data gradients: the warm-up iteration above ran with just-in-time scaling and left every layer's scale = its dy's
+            # amax / 448 on THIS batch (the calibration); the captured graphs use delayed scaling from here on -- each backward pass
+            # starts by turning the previous pass's amax into the scales it quantises with (engine: crd_fp8_scale_update)
+            self.plan.fp8_jit = False
         self.graphs = {}
         if self.late_wgrad:
             self.plan.split_late = True

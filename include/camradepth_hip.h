@@ -166,6 +166,34 @@ int crd_bicubic2x_fp8(const void* x, int32_t x_ld, int32_t x_coff, int32_t B, in
 int crd_weight_quant_fp8(const void* w_bf16, int32_t Cout, int32_t taps, int32_t Cin, int32_t Cin_out, void* w_fp8, float* scales,
                          crd_stream_t stream);
 
+/* ---- fp8 DATA GRADIENTS of the same ConvLayers (round 5; config 5 as a training step) ----------------------------------------
+ * dx[b,iy,ix,ci] (+)= bf16( *x_scale_dev * w_scales[ci] * sum_{ky,kx,co} dy8[b, iy+1-ky, ix+1-kx, co] * w8[ci][ky*3+kx][co] ):
+ * the autograd of crd_conv3x3_fp8's convolution w.r.t. its input (utils.py:211 under autograd), with dy = the GroupNorm
+ * backward's output quantised to e4m3 (crd_gn_bwd_apply_fp8) and w8 = the packed data-gradient weights [Cin_pad][9][Cout_pad]
+ * quantised per INPUT channel (crd_weight_quant_fp8 on crd_pack_entry.dst_dgrad).  d: gather_mode 1, x = dy8 (fp8, Cin here =
+ * the layer's output channels rounded up to 16), w = w8, Cout = the channels of dx to produce (multiple of 8; 128-column tiles
+ * + one narrower launch for the rest), accumulate 0 / 1 (dx's read-modify-write in bf16, as crd_conv_igemm), no statistics.
+ * The activation scale is read from DEVICE memory (one float): it is this step's or the previous step's amax / 448
+ * (crd_fp8_scale_update), never a host constant -- gradients shrink by orders of magnitude over a run. */
+int crd_conv3x3_fp8_dgrad(const crd_conv_desc* d, const float* w_scales, const float* x_scale_dev, crd_stream_t stream);
+/* crd_gn_bwd_apply (bf16 dx, no accumulation, no dx2) that ALSO writes dx_fp8 = e4m3(bf16(dx) / *scale_dev) and folds max |bf16(dx)|
+ * into amax_slots[CRD_FP8_AMAX_SLOTS] (u32 max on the float's bits; one slot per workgroup, spread so that the atomics do not
+ * serialise on one address).  The bf16 dx is still written: the weight gradient reads it. */
+#define CRD_FP8_AMAX_SLOTS 64
+int crd_gn_bwd_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_coff, const void* dy, int32_t dy_f32,
+                         int32_t dy_ld, int32_t dy_coff, int32_t B, int32_t P, int32_t C, const crd_sum_t* stats,
+                         int32_t gmul, const float* gamma, const float* beta, int32_t act, const float* mask,
+                         const crd_sum_t* r, float* dgamma, float* dbeta, void* dx, int32_t dx_ld, int32_t dx_coff,
+                         void* dx_fp8, int32_t dx8_ld, int32_t dx8_coff, const float* scale_dev, uint32_t* amax_slots,
+                         crd_stream_t stream);
+/* For each of n tensors: a = max over amax_slots[i][0..CRD_FP8_AMAX_SLOTS); if a > 0: scales[i] = margin * a / 448; the slots are
+ * zeroed.  Delayed scaling: called once per step behind the backward pass; with n = 1 right behind crd_gn_bwd_apply_fp8 it is
+ * just-in-time scaling (the calibration iteration and the eager module path: followed by crd_quant_fp8_dev). */
+int crd_fp8_scale_update(uint32_t* amax_slots, float* scales, int32_t n, float margin, crd_stream_t stream);
+/* crd_quant_fp8 with the scale read from device memory */
+int crd_quant_fp8_dev(const void* x, int64_t rows, int32_t ld, int32_t coff, int32_t C, void* y, int32_t y_ld, int32_t y_coff,
+                      const float* scale_dev, crd_stream_t stream);
+
 /* Weight gradient of the same convolutions: dw[co][tap][ci] += sum_{b,oy,ox} dy[b,oy,ox,co] *
  * x[b, oy*s-p+ky, ox*s-p+kx, ci]  (fixed-point atomics, see crd_sum_t; caller zeroes dw).  Optionally also
  * dbias[co] += sum dy.  (autograd of the conv calls listed above.) */

@@ -139,11 +139,42 @@ def _conv2d_fp8(x, w, x_scale, **kw):
     return _q(F.conv2d(xq, wq, None, **kw) * (x_scale * ws).view(1, -1, 1, 1), "bf16")
 
 
-def conv_layer(sd, name, x, k, quant=None, fp8_scale=None):
-    """ConvLayer.forward: conv(no bias) -> GroupNorm(Cout/16) -> GELU (reference: src/utils/utils.py:210-228)."""
+class _Fp8ConvTrain(torch.autograd.Function):
+    """The e4m3 convolution of config 5 WITH its e4m3 data gradient (camradepth_amd round 5: crd_conv3x3_fp8 /
+    crd_conv3x3_fp8_dgrad; no reference counterpart -- the reference trains under fp16 autocast, runner.py:191).  Forward:
+    _conv2d_fp8.  Backward: dy rounded to bf16 (what the GroupNorm backward stores), quantised per tensor with g_scale, the bf16
+    weights quantised per INPUT channel (scale = max over (cout, taps) / 448, 1 for an all-zero channel), dx = the transposed
+    convolution of the de-quantised pair rounded to bf16; dw = the bf16 weight gradient of the bf16 activations and the bf16 dy."""
+
+    @staticmethod
+    def forward(ctx, x, w, x_scale, g_scale, pad):
+        ctx.save_for_backward(x, w)
+        ctx.g_scale, ctx.pad = g_scale, pad
+        return _conv2d_fp8(x, w, x_scale, padding=pad)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gb = _q(gy, "bf16")
+        gs = torch.tensor(ctx.g_scale, dtype=torch.float32)
+        gq = _e4m3(gb * (1.0 / gs)) * gs
+        wb = _q(w, "bf16")
+        am = wb.abs().amax(dim=(0, 2, 3))
+        ws = torch.where(am > 0, am / E4M3_MAX, torch.ones_like(am))
+        wq = _e4m3(wb * (1.0 / ws).view(1, -1, 1, 1)) * ws.view(1, -1, 1, 1)
+        dx = _q(F.conv_transpose2d(gq, wq, padding=ctx.pad), "bf16") if ctx.needs_input_grad[0] else None
+        dw = torch.nn.grad.conv2d_weight(_q(x, "bf16"), w.shape, gb, padding=ctx.pad) if ctx.needs_input_grad[1] else None
+        return dx, dw, None, None, None
+
+
+def conv_layer(sd, name, x, k, quant=None, fp8_scale=None, fp8_gscales=None):
+    """ConvLayer.forward: conv(no bias) -> GroupNorm(Cout/16) -> GELU (reference: src/utils/utils.py:210-228).
+    fp8_gscales: {layer name: e4m3 scale of its dy} -- the layers listed there also take their DATA gradient in e4m3."""
     w = sd[name + ".model.0.weight"]
     if fp8_scale is None:
         y = _conv2d(x, w, None, quant, padding=k // 2)
+    elif torch.is_grad_enabled() and (x.requires_grad or w.requires_grad) and fp8_gscales and name in fp8_gscales:
+        y = _Fp8ConvTrain.apply(x, w, fp8_scale, float(fp8_gscales[name]), k // 2)
     elif torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
         # fp8 forward inside a training step: the value of the fp8 convolution, the gradient of the bf16 one (what the HIP
         # path does: data and weight gradients are the bf16 kernels on the bf16 activations / weights)
@@ -156,12 +187,12 @@ def conv_layer(sd, name, x, k, quant=None, fp8_scale=None):
     return F.gelu(_gn(y, sd, name + ".model.1", w.shape[0] // GN_DIV))
 
 
-def short_res_block(sd, name, x, quant=None, fp8_scale=None):
+def short_res_block(sd, name, x, quant=None, fp8_scale=None, fp8_gscales=None):
     """ShortResBlock.forward (reference: src/utils/utils.py:127-135)."""
     for li in range(2):
-        out = conv_layer(sd, f"{name}.layers.{li}", x, 3, quant, fp8_scale)
+        out = conv_layer(sd, f"{name}.layers.{li}", x, 3, quant, fp8_scale, fp8_gscales)
         x = torch.cat((x, out), dim=1)
-    return conv_layer(sd, f"{name}.layers.2", x, 3, quant, fp8_scale)
+    return conv_layer(sd, f"{name}.layers.2", x, 3, quant, fp8_scale, fp8_gscales)
 
 
 def bicubic2x(x):
@@ -169,12 +200,12 @@ def bicubic2x(x):
     return F.interpolate(x, scale_factor=2, mode="bicubic")
 
 
-def decoder_stage(sd, name, x, skip=None, quant=None, fp8_scale=None):
+def decoder_stage(sd, name, x, skip=None, quant=None, fp8_scale=None, fp8_gscales=None):
     """Decoder.forward (reference: src/utils/utils.py:249-257)."""
     x = bicubic2x(x)
     if skip is not None:
         x = torch.cat((x, skip), dim=1)
-    return short_res_block(sd, name + ".conv", x, quant, fp8_scale)
+    return short_res_block(sd, name + ".conv", x, quant, fp8_scale, fp8_gscales)
 
 
 def depth_activation(sd, name, x, quant=None):
@@ -189,7 +220,7 @@ def seg_block(logits, num_classes):
     return torch.argmax(logits, dim=1, keepdim=True) / num_classes
 
 
-def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
+def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None, fp8_grad_scales=None):
     """CamRaDepth.forward (reference: src/models/CamRaDepth.py:99-176).
 
     masks: None (eval) or the dict of synth.make_masks (train mode with injected Dropout2d /
@@ -197,8 +228,11 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
     fp8_scales: {"depth_upsample.3": s, "depth_upsample.4": s, "seg_upsample.0": s, ...} -- the ConvLayers of those decoder
     stages as fp8 convolutions (_conv2d_fp8) with these per-stage activation scales (what camradepth_amd's calibrate_fp8
     returns; a stage that is not listed stays as `quant` says).
+    fp8_grad_scales: {"depth_upsample.4.conv.layers.2": s, ...} -- ConvLayers of fp8 stages whose data gradient is e4m3 as well
+    (_Fp8ConvTrain), with the per-tensor scale of their dy (what the HIP plan's device-resident scales held for that step).
     """
     f8 = fp8_scales or {}
+    g8 = fp8_grad_scales
     d2 = iter(masks["dropout2d"]) if masks is not None else None
     drop = (lambda t: t) if masks is None else (lambda t: t * next(d2).view(t.shape[0], t.shape[1], 1, 1))
     outs = encoder(sd, x, cfg, quant, masks, taps)
@@ -214,10 +248,10 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
     s3 = drop(decoder_stage(sd, "depth_upsample.2", s2, e4, quant))
     d3 = depth_activation(sd, "depth_activation_3", s3, quant)
     s3 = torch.cat([s3, d3], 1)
-    s4 = drop(decoder_stage(sd, "depth_upsample.3", s3, None, quant, f8.get("depth_upsample.3")))
+    s4 = drop(decoder_stage(sd, "depth_upsample.3", s3, None, quant, f8.get("depth_upsample.3"), g8))
     sup_map = unsup_map = seg_map = seg_feat = seg_final = None
     if cfg.supervised_seg or cfg.unsupervised_seg:
-        seg_feat = drop(decoder_stage(sd, "seg_upsample.0", s3, None, quant, f8.get("seg_upsample.0")))
+        seg_feat = drop(decoder_stage(sd, "seg_upsample.0", s3, None, quant, f8.get("seg_upsample.0"), g8))
     if cfg.supervised_seg:
         sup_map = seg_block(_conv2d(seg_feat, sd["seg_conv_stage_4.weight"], sd["seg_conv_stage_4.bias"], quant,
                                     padding=1), cfg.num_classes)
@@ -233,9 +267,9 @@ def forward(sd, x, cfg, quant=None, masks=None, taps=None, fp8_scales=None):
     tmp = torch.cat((s4, seg_map), dim=1) if seg_map is not None else s4
     d4 = depth_activation(sd, "depth_activation_4", tmp, quant)
     s4 = torch.cat([s4, d4], 1)
-    s5 = drop(decoder_stage(sd, "depth_upsample.4", s4, x, quant, f8.get("depth_upsample.4")))
+    s5 = drop(decoder_stage(sd, "depth_upsample.4", s4, x, quant, f8.get("depth_upsample.4"), g8))
     if cfg.supervised_seg or cfg.unsupervised_seg:
-        seg_feat = drop(decoder_stage(sd, "seg_upsample.1", seg_feat, x, quant, f8.get("seg_upsample.1")))
+        seg_feat = drop(decoder_stage(sd, "seg_upsample.1", seg_feat, x, quant, f8.get("seg_upsample.1"), g8))
     if cfg.supervised_seg:
         seg_final = _conv2d(seg_feat, sd["seg_conv_final.weight"], sd["seg_conv_final.bias"], quant, padding=1)
         sup_map = seg_block(seg_final, cfg.num_classes)

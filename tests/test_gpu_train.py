@@ -411,7 +411,7 @@ def test_per_rank_dropout_streams_differ_and_rank0_is_unchanged():
 # The streaming 3x3 weight gradients split the pixels S ways and add their fp32 partial copies in index order; the graph step caps their
 # workgroups (late stream: 160) and so uses another S than the eager step: a different summation TREE of the same fp32 products, not a
 # different sum order of integers.  Measured round 5: see the print below (bound = 2 x measured).
-B16_GRAPH_VS_EAGER = 2e-2
+B16_GRAPH_VS_EAGER = 2e-7        # measured 4.2e-8
 
 
 def test_graph_step_matches_eager_step_at_batch16():
@@ -444,7 +444,10 @@ def test_graph_step_matches_eager_step_at_batch16():
     assert r16 < B16_GRAPH_VS_EAGER and float(ge.abs().sum()) > 0
 
 
-C2_GRAPH_VS_EAGER_GRAD, C2_GRAPH_VS_EAGER_UPDATE = 2e-2, 0.2      # TIGHTEN: set from the round-5 measurement (printed below)
+# Round 5 measurement (printed below): NOT bit-equal -- gradient rel-L2 3.5e-8, update 2.6e-5.  Every integer sum is order-independent, but
+# the streaming 3x3 weight gradients add per-split fp32 partial copies, and the graph step (late stream: 160 workgroups) splits the pixels
+# differently from the eager module path: another summation TREE of the same fp32 products.  Round 4's "0.0000" was a four-decimal print.
+C2_GRAPH_VS_EAGER_GRAD, C2_GRAPH_VS_EAGER_UPDATE = 2e-7, 1e-4
 
 
 def test_train_step_at_benchmark_size_graph_vs_eager_and_oracle():
@@ -518,7 +521,7 @@ def test_train_step_at_benchmark_size_graph_vs_eager_and_oracle():
         den += float((ref_delta ** 2).sum())
     upd = (num / den) ** 0.5
     print(f"C2-size first-step update vs oracle (batch 2): rel-L2 {upd:.4f}")
-    assert upd < 0.25, upd      # measured 0.10; sign-like first step of diffGradNorm on a bf16-chaotic full-depth gradient (see module docstring)
+    assert upd < 0.19, upd      # measured 0.094 (rounds 4, 5): 2x; sign-like first step of diffGradNorm on a bf16-chaotic full-depth gradient (see module docstring)
 
 
 def _free_port():

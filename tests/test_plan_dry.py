@@ -1,0 +1,59 @@
+"""CPU: the execution plan (camradepth_amd.engine.Plan) is pure recording -- buffers, descriptors, op lists -- so it can be BUILT
+without a GPU (nothing is launched).  This catches host-logic errors before a GPU box is spent on them, and pins the host-side
+bookkeeping the measurement rests on: every recorded launch carries its algorithmic HBM bytes (bench.floor_budget, tools/floor_table.py),
+the phase marks partition the forward list, the weight-gradient launches are all on the late stream."""
+import pytest
+import torch
+
+import bench
+from camradepth_amd.engine import LATE, Plan
+from camradepth_amd.model import CamRaDepth
+
+
+def _plan(train=True, **variant):
+    m = CamRaDepth(input_channels=7, depths=(1, 1, 1, 1), **variant)
+    m.train(train)
+    if train:
+        m._ensure_grad_views()
+    return m, Plan(m, 2, 64, 96, train)
+
+
+@pytest.mark.parametrize("variant", [{}, {"supervised_seg": True}, {"supervised_seg": True, "unsupervised_seg": True}])
+def test_plan_builds_without_a_gpu_and_every_launch_has_bytes(variant):
+    m, p = _plan(True, **variant)
+    ops = [op for op in p.fwd + p.bwd if p.live(op)]
+    assert len(p.fwd) > 90 and len(p.bwd) > 150
+    zero = sorted({op.name for op in ops if p.op_bytes(op) <= 0})
+    assert not zero, f"launches without algorithmic bytes: {zero}"
+    # weight gradients never sit on the dependency chain
+    for op in p.bwd:
+        if op.fn is not None and op.name in ("crd_conv_wgrad", "crd_conv_wgrad_grouped", "crd_dwconv3x3_wgrad", "crd_head_conv2_wgrad"):
+            assert op.stream == LATE, op.name
+    # the first op of every phase mark is what the builder recorded there (marks survive the slice-copy inserts)
+    names = [n for n, _ in p.fwd_marks]
+    assert names == ["enc0", "enc1", "enc2", "enc3", "dec"]
+    for n, i in p.fwd_marks[1:4]:
+        assert p.fwd[i].name == "crd_conv_igemm" and "k3 s2" in p.fwd[i].meta["shape"], (n, p.fwd[i].name)     # the stage's patch embed
+
+
+def test_floor_budget_adds_up():
+    m, p = _plan(True)
+    fb = bench.floor_budget(p)
+    ph = fb["phases"]
+    assert set(ph) == {"fwd:enc0", "fwd:enc1", "fwd:enc2", "fwd:enc3", "fwd:dec", "bwd:dec", "bwd:enc3", "bwd:enc2", "bwd:enc1", "bwd:enc0",
+                       "late:dec", "late:enc3", "late:enc2", "late:enc1", "late:enc0"}
+    chain = sum(v["floor_ms"] for k, v in ph.items() if not k.startswith("late:"))
+    assert abs(chain - fb["floor_ms"]) < 1e-2
+    n_ops = sum(1 + (op.meta or {}).get("kernel", "").count("+") for op in p.fwd + p.bwd if p.live(op))
+    assert sum(v["launches"] for v in ph.values()) == n_ops
+    for k, v in ph.items():
+        assert v["floor_ms"] >= max(v["mfma_ms"], v["byte_ms"], v["dep_ms"]) - 1e-3 and v["floor_ms"] <= v["mfma_ms"] + v["byte_ms"] + v["dep_ms"] + 1e-3, k
+    # the decoder carries the FLOPs, the encoder the launches
+    assert ph["fwd:dec"]["gflop"] > 5 * sum(ph[f"fwd:enc{s}"]["gflop"] for s in range(4))
+
+
+def test_eval_plan_records_no_backward_only_tensors():
+    _, pt = _plan(True)
+    m, pe = _plan(False)
+    assert len(pe.fwd) <= len(pt.fwd)
+    assert pe.training is False

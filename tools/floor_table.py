@@ -68,13 +68,13 @@ marks = plan.fwd_marks + [("end", len(plan.fwd))]
 rows = []          # (phase, kernel label, ms, mfma, byte, dep, floor, bytes)
 for (name, lo), (_, hi) in zip(marks[:-1], marks[1:]):
     for i, op in enumerate(plan.fwd[:hi] if name == marks[0][0] else plan.fwd[lo:hi]):
-        if op.fn is not None:
+        if plan.live(op):
             rows.append(("fwd:" + name, op, time_op(op)) + floor_of(op))
 saved_split = plan.split_late
 plan.split_late = False
 for tag, lo, hi in plan.bwd_segments:
     for op in plan.bwd[lo:hi]:
-        if op.fn is not None:
+        if plan.live(op):
             rows.append((("late:" if op.stream == LATE else "bwd:") + tag, op, time_op(op)) + floor_of(op))
 plan.split_late = saved_split
 

@@ -351,8 +351,19 @@ __device__ __forceinline__ void conv_epilogue_idle(const ConvK& a) {
   if (a.stats) __syncthreads();
 }
 
+// The narrow pointwise layers (pw_narrow.hip: Mlp.fc2 / fc1's data gradient at encoder stages 1-2).  NarrowGn: an optional
+// GroupNorm + exact GELU applied to the bf16 input rows on their way in (Mlp.norm2 in front of fc2); xn: optional bf16 copy of the
+// activated rows (what fc2's weight gradient reads).
+struct NarrowGn {
+  const crd_sum_t* stats; int gmul; const float* gamma; const float* beta; float count;
+  bf16_t* xn; int xn_ld; long long xn_bstride;
+};
+
 // stats[b][g][which] += sum over tiles of the per-tile partials written by conv_epilogue
 __global__ __launch_bounds__(256) void k_stats_finalize(const float* partial, int n_tiles, int G16, crd_sum_t* stats);
 
 
 }  // namespace crdk
+
+bool crd_pw_narrow_applicable(const crdk::ConvK& k, const crdk::NarrowGn* gn);      // pw_narrow.hip
+int crd_pw_narrow(const crdk::ConvK& k, const crdk::NarrowGn* gn, int B, hipStream_t st);

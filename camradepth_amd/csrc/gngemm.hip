@@ -615,6 +615,14 @@ extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_st
   gi.count = (float)d->IH * (float)d->IW * 16.f * (float)n->gmul;
   gi.xn = reinterpret_cast<bf16_t*>(n->xn); gi.xn_ld = n->xn_ld; gi.xn_bstride = (long long)d->IH * d->IW * n->xn_ld;
   hipStream_t st = as_stream(stream);
+  if (n->act == 1 && !n->x_f32 && d->KH == 1) {        // Mlp.norm2 + GELU in front of fc2 at stages 1-2: the narrow streaming kernel
+    ConvK kn = k;
+    kn.x = reinterpret_cast<const bf16_t*>(gi.x);
+    NarrowGn ng;
+    ng.stats = gi.stats; ng.gmul = gi.gmul; ng.gamma = gi.gamma; ng.beta = gi.beta; ng.count = gi.count;
+    ng.xn = gi.xn; ng.xn_ld = gi.xn_ld; ng.xn_bstride = gi.xn_bstride;
+    if (crd_pw_narrow_applicable(kn, &ng)) return crd_pw_narrow(kn, &ng, d->B, st);
+  }
   if (pw_wide_applies(k, gi, n->act)) return dispatch_pw_wide<1>(k, gi, d->B, st);
   if (n->x_f32) return n->act ? dispatch<1, 1>(k, gi, d->B, st) : dispatch<1, 0>(k, gi, d->B, st);
   return n->act ? dispatch<0, 1>(k, gi, d->B, st) : dispatch<0, 0>(k, gi, d->B, st);

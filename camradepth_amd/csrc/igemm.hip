@@ -315,6 +315,8 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   if (d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->out_mode == 0 && d->IH == d->OH && d->IW == d->OW &&
       d->IW >= 32 && d->IH >= 8)
     return crd_conv3x3_halo(k, d->B, st, pcap);
+  // pointwise layers that are all INPUT (Mlp.fc2 and fc1's data gradient at encoder stages 1-2): weights in registers, rows streamed once
+  if (d->KH == 1 && d->KW == 1 && crd_pw_narrow_applicable(k, nullptr)) return crd_pw_narrow(k, nullptr, d->B, st);
   // pointwise layers that are all output (fc2's data gradient at encoder stages 1-2): the register-resident-weight kernel
   if (d->KH == 1 && d->KW == 1 && crd_pw_wide_plain_applicable(k)) return crd_pw_wide_plain(k, d->B, st);
   {   // developer override of the tile choice below (tools/bench_small_gemm.py sweeps it)

@@ -796,6 +796,9 @@ class Plan:
             grp = []
             draw = self.act(Cs, Hs, Ws)
             self.gn_bwd(grp, raw, st, 1, pe + ".norm", 0, None, DX, draw)
+            # (round 5: the patch embed's own weight gradient rides in the stage's grouped launch as well -- alone it was 25-39 us
+            # of split-K atomics on the late stream; its operands, the previous stage's output and `draw`, outlive the stage)
+            self._defer = [] if GROUP_WGRAD else None
             self.wgrad(grp, src, draw, cw, k, stride, k // 2, Hs, Ws, dbias=pe + ".proj.bias")
             if s > 0:
                 self.conv(grp, self.conv_desc(draw, ("dgrad", cw), src.C, k, stride, k // 2, src.H, src.W, d_enc_out[s - 1],
@@ -805,7 +808,6 @@ class Plan:
             hid = Cs * ratio
             sc = {"DH": self.act(Cs, Hs, Ws), "DHID": self.act(hid, Hs, Ws), "DHID2": self.act(hid, Hs, Ws),
                   "DXN": self.act(Cs, Hs, Ws), "DQ": self.act(Cs, Hs, Ws), "hid": hid}
-            self._defer = [] if GROUP_WGRAD else None
             pre = dh = None
             persist = None
             want = self.enc_persist == "1" or (self.enc_persist == "auto" and not tr and sr == 2 and 64 <= B * Hs <= 256)
@@ -853,6 +855,11 @@ class Plan:
             dCB.append(self.act(ld, Hj, Wj))
             lay.append((up_p, sk_p))
         self._cmap = None
+        # the decoder's SMALL weight gradients (the four 1x1 skip adapters, the three 3x3 layers of the 16 x 26 level: 16-49 us each as
+        # individual split-K launches, 90 TFLOP/s) go into one grouped launch at the end of the decoder's backward segment; the
+        # streaming 3x3 kernel keeps the large ones.  Operands: forward activations and per-layer `draw` buffers (never reused).
+        self._defer = [] if GROUP_WGRAD else None
+        dec_first_group = len(self.bwd_groups)
         self.stage_buffers = {}                           # decoder stage name -> its concat buffer
         E1, dE1 = self.act(d[3], *hs[0]), self.act(d[3], *hs[0])
         # gradient regions of encoder outputs: from_encoder dgrad stores (fp32), patch-embed dgrad accumulates
@@ -1040,15 +1047,20 @@ class Plan:
                 self.unsup_map = torch.zeros((B, 1, H, W), dtype=F32, device=self.dev)
                 seg_head("unsup_final", SF1, UNSUP_CLASSES, [(S[4], ch), (self.unsup_map, None)], False)
         head(5, "depth_activation_5", S[4], dS[4], 128 + n_extra, hmap)
+        if self._defer is not None:
+            self.flush_deferred(self.bwd_groups[dec_first_group])       # the first decoder group recorded = the last one executed
         self._finalise()
 
     def _stage_fwd_only(self, stage):
         """Run a decoder stage builder but drop its backward groups (branches without any loss)."""
         def run(*a, **k):
             n = len(self.bwd_groups)
+            nd = len(self._defer) if self._defer is not None else 0
             stage(*a, **k)
             del self.bwd_groups[n:]
             del self.bwd_tags[n:]
+            if self._defer is not None:
+                del self._defer[nd:]               # (their deferred weight gradients as well: no dy is ever produced for them)
         return run
 
     # ------------------------------------------------------------------ encoder block
@@ -1179,7 +1191,10 @@ class Plan:
             # Mlp.norm2 + GELU applied while fc2 loads H2 (H3 is kept for fc2's weight gradient only).  Inference plans
             # (nothing saved) take it from FC2_FOLD_MINROWS pixels x batch on: on small grids fc2 is a long-K GEMM on few
             # workgroups, which k_igemm's intra-workgroup split-K handles better than the register-path kernel
-            if fused and (self.gn_conv_on == 1 or (not tr and B * Hs * Ws >= FC2_FOLD_MINROWS)):
+            # Round 5: at stages 1-2 the narrow streaming kernel (csrc/pw_narrow.hip) takes the folded form in training plans too --
+            # it activates the rows in registers on their way into LDS and writes H3 from there: crd_gn_apply's pass disappears
+            narrow = fused and not c2.frozen and int(self.lib.crd_pw_narrow_supported(hid, Cs, N)) > 0
+            if fused and (narrow or self.gn_conv_on == 1 or (not tr and B * Hs * Ws >= FC2_FOLD_MINROWS)):
                 fc2_spec["x"] = H2
                 self.gn_conv(F_, fc2_spec, sth2, ratio, ml + ".norm2", 1, H3 if tr else None)
             else:

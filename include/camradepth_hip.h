@@ -133,6 +133,18 @@ typedef struct {
   void* xn;                 /* optional bf16 output */
 } crd_gn_input;
 int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stream);
+/* 1 when crd_conv_igemm / crd_gn_conv send a 1x1 layer of this shape (input channels, output channels, pixels per sample) to the
+ * narrow streaming kernel (round 5, csrc/pw_narrow.hip: Mlp.fc2 and the data gradient of Mlp.fc1 at encoder stages 1-2,
+ * simplified_attention.py:17,20,35,41 -- hidden 512 / 1024 -> 64 / 128 channels): the weights of a workgroup's 16-column
+ * slices live in registers, the hidden tensor streams through LDS once.  With crd_gn_conv (act = 1) Mlp.norm2 + the exact GELU
+ * are applied to the rows on their way in and crd_gn_input.xn receives the activated tensor: callers use this to decide whether
+ * the separate crd_gn_apply pass over the hidden tensor can be dropped. */
+int crd_pw_narrow_supported(int32_t Cin, int32_t Cout, int32_t pixels);
+/* Tuning / test knob of that kernel: on = 0 / 1 switches it off / on (2: on, and also for the K = 1024 launches without a GroupNorm
+ * in front, which the generic tiles serve faster -- benchmarks only) for launches recorded from now on (returns the previous
+ * setting; plans built before keep what they chose); on < 0: returns the number of launches that took the narrow kernel so far
+ * (modulo 2^31) -- the tests use it to assert that the native kernel ran and not the generic tiles behind it. */
+int crd_tune_pw_narrow(int32_t on);
 /* Tuning knob of the 3x3 halo kernel: launches whose 128-column tiling would give fewer than `workgroups` workgroups use
  * 64- or 32-column tiles instead (default 512; 0 disables; < 0 restores the default).  Returns the previous value.
  * Not needed for correctness -- the tests use it to reach every tile configuration with small inputs. */

@@ -48,6 +48,9 @@ CASES = [
     (3, 128, 9, 11, 1024, 1, 1, 0, 1, "plain"),           # wide kernel: ragged rows (99 pixels: two tiles, the second 35 rows), no sums
     (2, 160, 16, 26, 640, 1, 1, 0, 1, "stats"),           # fc1 stage 3 at the benchmark size: 128-column workgroups, 6.5 tiles
     (5, 64, 20, 30, 256, 1, 1, 0, 1, "stats"),            # wide kernel: one column block, odd batch, 600 pixels
+    (8, 1024, 32, 52, 128, 1, 8, 1, 0, "res"),            # fc2 stage 2 at the benchmark size: the narrow streaming kernel (round 5), 2 tiles per workgroup
+    (3, 1024, 8, 12, 128, 1, 8, 1, 0, "res"),             # ... three tiles per sample, odd batch
+    (2, 512, 16, 24, 64, 1, 8, 1, 0, "plain"),            # ... its bf16-output form behind GroupNorm + GELU
 ]
 
 
@@ -101,8 +104,12 @@ def test_gn_conv_matches_groupnorm_then_conv(case):
         if epi == "stats":
             d.stats = ostats.data_ptr()
         ref_y = ref.permute(0, 2, 3, 1).reshape(B, OH * OW, Cout)
+    n_narrow = L.crd_tune_pw_narrow(-1)
     lib.check(L.crd_gn_conv(C.byref(d), C.byref(n), lib.stream()), "crd_gn_conv")
     torch.cuda.synchronize()
+    # fc2 of encoder stages 1-2 behind Mlp.norm2 + GELU is the narrow streaming kernel's (csrc/pw_narrow.hip), not the generic tiles'
+    narrow = (Cin, Cout) in ((512, 64), (1024, 128)) and act == 1 and k == 1 and (H * W) % 32 == 0 and epi in ("res", "plain")
+    assert L.crd_tune_pw_narrow(-1) - n_narrow == (1 if narrow else 0), "kernel selection"
     assert_close(y.float().cpu(), ref_y, "gn_conv output")
     # the normalised operand is stored for the weight gradient: bf16 of the torch value, up to one ulp where the fp32
     # statistics (sum / sum of squares here, two-pass in torch) move a value across a rounding boundary

@@ -191,7 +191,10 @@ def test_epilogues_sigmoid_residual_accumulate():
     assert_close(y.float().cpu(), y0 + F.conv2d(x, w).permute(0, 2, 3, 1), "accumulate")
 
 
-@pytest.mark.parametrize("Ci,Co,H,W,acc", [(640, 160, 16, 26, 0), (1024, 256, 8, 13, 0), (160, 160, 9, 7, 1), (128, 96, 12, 20, 0)])
+@pytest.mark.parametrize("Ci,Co,H,W,acc", [(640, 160, 16, 26, 0), (1024, 256, 8, 13, 0), (160, 160, 9, 7, 1), (128, 96, 12, 20, 0),
+                                           # round 5: Mlp.fc2 of stages 1-2 on rows that are already activated -- the narrow streaming
+                                           # kernel (csrc/pw_narrow.hip), 12 / 52 / 3 tiles of 32 rows per sample
+                                           (512, 64, 16, 24, 0), (1024, 128, 32, 52, 0), (1024, 128, 8, 12, 0)])
 def test_fp32_residual_epilogue_with_sums(Ci, Co, H, W, acc):
     """LDS-staged float4 epilogue: fp32 output = res + scale[b] * bf16(conv) (+ previous contents), GroupNorm sums of the
     stored values per 16-channel slab and per channel -- on the split-K (deep K, small grid) and plain small-tile kernels,
@@ -232,6 +235,8 @@ DGRAD_CASES = [
     (2, 512, 20, 26, 64, 1, 1, 0),       # Mlp.fc2's data gradient (64 -> 512 columns): the wide pointwise kernel
     (2, 1024, 9, 11, 128, 1, 1, 0),
     (1, 640, 16, 26, 160, 1, 1, 0),
+    (2, 64, 16, 24, 512, 1, 1, 0),       # Mlp.fc1's data gradient (512 -> 64 columns): the narrow streaming kernel, plain bf16 output
+    (3, 128, 8, 12, 1024, 1, 1, 0),
 ]
 
 

@@ -406,6 +406,8 @@ def main():
     ap.add_argument("--fp8-grad", action="store_true",
                     help="with --fp8 in a training step: the data gradients of the same ConvLayers in e4m3 too (delayed per-tensor scaling); "
                          "weight gradients stay bf16")
+    ap.add_argument("--tune-narrow", type=int, default=None, choices=[0, 1, 2],
+                    help="A/B aid: crd_tune_pw_narrow(n) before the plans are built (0: the narrow streaming pointwise kernel off)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # tests: launcher contract on CPU (gloo)
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:       # no launcher: be the launcher (before any HIP call in this process)
@@ -434,6 +436,9 @@ def main():
     from camradepth_amd.model import CamRaDepth
     from camradepth_amd.trainer import TrainStep, one_cycle
 
+    if a.tune_narrow is not None:
+        import camradepth_amd.lib as _L
+        _L.load().crd_tune_pw_narrow(a.tune_narrow)
     sup = a.variant == "supervised_seg"
     model = CamRaDepth(input_channels=7, supervised_seg=sup, seed=0).cuda()      # same init on every rank
     if a.inference:       # the reference's own "runtime" figure (Trainer.test(), runner.py:417-420), without its missing device sync

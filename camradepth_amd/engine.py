@@ -710,7 +710,12 @@ class Plan:
             return
         grp = []
         draw = self.act(cw.cout, H, W)
-        if x8 is not None and self.fp8_grad and dx is not None and not cw.frozen:
+        # e4m3 data gradient where it pays -- measured per kernel at B = 16 (profiles/r05_c5_decoder_backward_chain_*.txt): the 128 -> 304 /
+        # 296 layers, whose data gradient is the first writer of the concat gradient and MFMA-bound (1092 -> 859 us, 308 -> 238 us); the
+        # 64- and 96-channel layers ACCUMULATE into it and are bound by that read-modify-write (652 -> 679, 644 -> 684 us in e4m3, plus
+        # 28-44 us per layer for the e4m3 copy of dy): they keep the bf16 kernel.  (developer switch CRD_FP8_GRAD_ALL: all six, as measured)
+        if (x8 is not None and self.fp8_grad and dx is not None and not cw.frozen
+                and (cw.cout >= 128 or _dev_flag("CRD_FP8_GRAD_ALL"))):
             # e4m3 data gradient: the GroupNorm backward writes bf16 d(raw) (the weight gradient reads it) AND its e4m3 copy
             li = len(self.fp8_grad_layers)
             assert li < self.g8_scales.numel()
@@ -1555,9 +1560,6 @@ class Plan:
                         if isinstance(k, tuple) and k[0] == "idx" and (int(k[2].min()) < 0 or int(k[2].max()) >= k[3]):
                             raise L.CrdError(f"argmax table of {k[1]} corrupted after op {i} {op.name}")
             return
-        pad = _dev_int("CRD_EXP_PAD", 0)       # experiment: cost of an extra tiny dispatch after every op
-        if pad and not hasattr(self, "_pad_buf"):
-            self._pad_buf = torch.zeros(64, device=self.dev)
         main = torch.cuda.current_stream()
         open_ = {}                                 # side branch -> its stream handle, while the branch is open
         for op in ops:
@@ -1586,8 +1588,6 @@ class Plan:
             rc = op.fn(*op.args, sh)
             if rc != 0:
                 raise L.CrdError(f"{op.name} failed ({rc}): {lib.crd_last_error().decode()}")
-            for _ in range(pad):
-                lib.crd_scale_f32(self._pad_buf.data_ptr(), self._pad_buf.data_ptr(), 64, 1.0, st)
         for sid in list(open_):                    # never leave a branch open past the end of the list
             ev = torch.cuda.Event()
             ev.record(self._side_streams[sid - 1])

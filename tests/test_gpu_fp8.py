@@ -3,6 +3,7 @@ kernels bit-exact against torch's float8_e4m3fn conversion, the block-scaled-MFM
 de-quantised operands (so the only difference is fp32 accumulation order + the bf16 output rounding: rel-L2 < 4e-3, as for
 the bf16 kernels), and the end-to-end model against the oracle's quant="fp8" mode."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -423,7 +424,10 @@ def _fp8_grad_step_vs_oracle(depths, B, H, W, seed=77, reference_init=False):
     out = model(x, masks=masks)
     plan = model._plans[model._plan_key(x)]
     n8 = sum(op.name == "crd_conv3x3_fp8_dgrad" for op in plan.bwd)
-    want = 6 if B * (H // 32) * (W // 64) >= 192 else 3          # stages with >= 192 tiles of 16 x 32 pixels take the fp8 route (B = 2: the full-resolution stage only)
+    # stages with >= 192 tiles of 16 x 32 pixels take the fp8 route (B = 2: the full-resolution stage only); per stage the e4m3 DATA
+    # gradient runs for the 128-channel layer (the MFMA-bound first writer of the concat gradient; all three with CRD_FP8_GRAD_ALL)
+    per_stage = 3 if (os.environ.get("CRD_DEV_SWITCHES") == "1" and os.environ.get("CRD_FP8_GRAD_ALL") is not None) else 1
+    want = per_stage * (2 if B * (H // 32) * (W // 64) >= 192 else 1)
     assert plan.training and plan.fp8_jit and n8 == len(plan.fp8_grad_layers) == want                   # the native e4m3 data gradients ran
     loss, _ = hl.total_loss(out, {k: v.cuda() for k, v in batch.items()}, False)
     loss.backward()
@@ -507,18 +511,18 @@ def test_fp8_graph_step_with_delayed_scaling_equals_the_just_in_time_step_on_the
         ts.set_batch(batch)
         ts.step()
         torch.cuda.synchronize()
-        assert len(ts.plan.fp8_grad_layers) == 6 and ts.plan.fp8_jit == (not use_graph)
+        assert len(ts.plan.fp8_grad_layers) == 2 and ts.plan.fp8_jit == (not use_graph)
         res[use_graph] = (ts.losses(), m.flat_grad.clone(), ts.plan.g8_scales.clone())
         if use_graph:
             ts.step()
             torch.cuda.synchronize()
-            assert float(ts.plan.g8_scales[:6].min()) > 0                     # delayed update at the head of the second backward
+            assert float(ts.plan.g8_scales[:2].min()) > 0                     # delayed update at the head of the second backward
         del ts, m
         torch.cuda.empty_cache()
     (lg, gg, sg), (le, ge, se) = res[True], res[False]
     r = rel(gg, ge)
     print(f"fp8 graph step (delayed scaling, calibrated on this batch) vs eager just-in-time step: loss {lg['loss']:.6f} / {le['loss']:.6f}, "
-          f"gradient rel-L2 {r:.3e}, scales {sg[:6].tolist()} / {se[:6].tolist()}")
+          f"gradient rel-L2 {r:.3e}, scales {sg[:2].tolist()} / {se[:2].tolist()}")
     assert lg == le
-    assert torch.equal(sg[:6], se[:6])
+    assert torch.equal(sg[:2], se[:2])
     assert r < 2e-7          # measured 3.5e-8: the same difference as the bf16 graph-vs-eager step (weight-gradient split counts), nothing from the scaling mode

@@ -2,6 +2,7 @@
 workgroups ran (XCC id per workgroup) -- run it several times: the launch has a fast and a slow mode between processes."""
 import ctypes
 import os
+os.environ.setdefault("CRD_DEV_SWITCHES", "1")      # the persistent stage is a developer path since round 5
 import torch
 from camradepth_amd import synth, engine, lib as L
 from camradepth_amd.config import ModelConfig

@@ -48,5 +48,5 @@ PY
   done
 }
 run_set "eager training iterations x3 (per-launch encoder), base 8x7x256x416" "CRD_ENC_PERSIST=0" tools/run_forward.py 3 train
-run_set "eval forwards x3, persistent stages 3-4 (CRD_ENC_PERSIST=1)" "CRD_ENC_PERSIST=1" tools/run_forward.py 3
+run_set "eval forwards x3, persistent stages 3-4 (CRD_ENC_PERSIST=1)" "CRD_DEV_SWITCHES=1 CRD_ENC_PERSIST=1" tools/run_forward.py 3
 cat $O/summary.txt

@@ -2,6 +2,7 @@
 (CRD_ENC_PERSIST=1, stages 3-4) against the per-launch path (=0), eval and train plans.
 Usage: python tools/prof_enc_stage.py [B]"""
 import os
+os.environ.setdefault("CRD_DEV_SWITCHES", "1")      # the persistent stage is a developer path since round 5
 import sys
 
 import torch

@@ -416,6 +416,8 @@ class Plan:
             return None
         flops = spec.get("flops_override", flops)
         kname = halo_tile(spec["cout"], spec["OH"], spec["OW"], self.B) if halo else igemm_tile(spec["cout"], spec["OH"] * spec["OW"], self.B)
+        if self._narrow_takes(spec, False):
+            kname = "k_pw_narrow"
         if halo and persistent_conv3(spec, self.B):
             c = spec["cout"]
             rest = c % 128
@@ -438,6 +440,19 @@ class Plan:
         lst.append(op)
         return op
 
+    def _narrow_takes(self, spec, with_gn):
+        """Label only (bench.py / tools): does the library send this 1x1 launch to the narrow streaming kernel (csrc/pw_narrow.hip:
+        crd_pw_narrow_applicable)?  K = 1024 only behind a GroupNorm (the generic tiles are faster on rows that are already activated)."""
+        y = spec["y"]
+        if not (spec["k"] == 1 and spec["stride"] == 1 and spec["out_mode"] == 0 and not spec["act"] and not spec["accumulate"]
+                and (with_gn or spec["cin"] == 512)
+                and int(self.lib.crd_pw_narrow_supported(spec["cin"], spec["cout"], spec["OH"] * spec["OW"])) > 0):
+            return False
+        if y.f32:
+            return spec.get("red") is None
+        red = spec.get("red")
+        return spec["res"] is None and spec["stats"] is None and spec.get("chan") is None and (red is None or red[5] == 0)
+
     def gn_conv(self, lst, spec, stats, gmul, gname, act, xn):
         """spec as for conv() with x the RAW (un-normalised) tensor: the GroupNorm `gname` (+ GELU when act) is applied while
         the GEMM loads its A operand (crd_gn_conv); xn: PM that also receives the normalised bf16 tensor, or None."""
@@ -446,6 +461,8 @@ class Plan:
         flops = 2.0 * self.B * spec["OH"] * spec["OW"] * spec["cout"] * w.cin_ref * w.taps
         small = spec["cout"] <= 64 or -(-spec["OH"] * spec["OW"] // 64) * -(-spec["cout"] // 128) * self.B < 256
         kname = "k_gngemm_reg" + ("<2,2,1,1>" if small else "<2,2,1,2>")
+        if act and not x.f32 and self._narrow_takes(spec, True):
+            kname = "k_pw_narrow<gn+gelu>"
         meta = {"kernel": kname, "flops": flops,
                 "shape": f"gn+fwd Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} out{spec['OH']}x{spec['OW']}"}
         gn = dict(gn_in=True, x_f32=x.f32, gmul=gmul, stats=stats, gamma=self.p(gname + ".weight"), beta=self.p(gname + ".bias"),

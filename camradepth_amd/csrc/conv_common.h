@@ -336,6 +336,168 @@ __device__ __forceinline__ void conv_epilogue(const ConvK& a, f32x16 (&acc)[TM][
   }
 }
 
+// ---- register epilogue of the 64 x 64 tile kernels (round 5) --------------------------------------------------------------------
+// The small encoder GEMMs (k_igemm<2,2,1,1>: 210 launches per step) spend more time in the LDS-staged epilogue above than in their K
+// loop (160 -> 160 at 16 x 26: launch 1.7 us, K loop 2.2, store path 1.6, statistics 0.9; with the fused reduce three more barriers --
+// tools/sweep_igemm.sh).  With the MFMA operands SWAPPED (A = weight rows, B = pixels) a lane holds ONE pixel (l & 31) and, of its
+// wave's 32 columns, the channels (r & 3) + 8 (r >> 2) + 4 (l >> 5): v_permlane32_swap between the half-waves turns them into two runs
+// of 8 consecutive channels -- two 16-byte stores per lane straight from the accumulators (k_conv3x3p's epilogue).  Everything the
+// epilogue READS (the old values of an accumulating store, the GroupNorm input and moments of the fused backward reduce, gamma / beta)
+// does not depend on the GEMM: it is requested at kernel start and arrives under the K loop.  The fused reduce's 32 per-lane sums
+// (2 pieces x 8 channels x 2 moments) are folded over the 32 pixels of a half-wave with a halving butterfly (31 shuffles: after
+// the step with mask m a lane keeps the half of its values selected by its bit m), then over the WM waves through 1.5 KB of LDS.
+// Arithmetic identical to conv_epilogue's vector path: bf16(v) stored, accumulate = bf16(bf16(v) + old), GroupNorm sums of the rounded
+// values before accumulation, the reduce on what was stored.
+typedef __attribute__((ext_vector_type(4))) unsigned crd_u32x4;
+struct RegEpiState {
+  int row, col[2];
+  bool ok[2];
+  crd_u32x4 old[2];
+  float xq[2][8], rmean[2], rrstd[2], rga[2][8], rbe[2][8];
+};
+
+template <int WM, int WN>
+__device__ __forceinline__ void reg_epi_prefetch(const ConvK& a, int b, int l, int wm, int wn, int m0, int n0, RegEpiState& st) {
+  st.row = m0 + wm * 32 + (l & 31);
+  const bool rowok = st.row < a.OHW;
+  const int rowc = rowok ? st.row : a.OHW - 1;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    st.col[k] = n0 + wn * 32 + 16 * k + 8 * (l >> 5);
+    st.ok[k] = rowok && st.col[k] < a.Cout;
+    const int colc = st.col[k] < a.Cout ? st.col[k] : 0;                 // (unconditional loads from a clamped address)
+    st.old[k] = crd_u32x4{0u, 0u, 0u, 0u};
+    if (a.accumulate)
+      st.old[k] = *reinterpret_cast<const crd_u32x4*>(reinterpret_cast<const bf16_t*>(a.y) + (long long)b * a.y_bstride + (long long)rowc * a.y_ld + colc);
+    if (a.red_x) {
+      load8(a.red_x, (long long)b * a.red_x_bstride + (long long)rowc * a.red_x_ld + colc, a.red_x_f32, st.xq[k]);
+      const int cpg = 16 * a.red_gmul;
+      gn_mean_rstd(a.red_stats + (long long)b * (a.Cout >> 4) * 2, (colc / cpg) * a.red_gmul, a.red_gmul, (float)a.OHW * cpg, st.rmean[k], st.rrstd[k]);
+      if (a.red_act == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { st.rga[k][j] = a.red_gamma[colc + j]; st.rbe[k][j] = a.red_beta[colc + j]; }
+      }
+    }
+  }
+}
+
+// acc: the wave's 32 x 32 tile in the SWAPPED layout (lane = pixel, registers = channels).  smem: the kernel's LDS, free after the K loop.
+template <int WM, int WN>
+__device__ __forceinline__ void conv_epilogue_reg(const ConvK& a, f32x16& acc, int b, int l, int wm, int wn, int n0, int tile, void* smem,
+                                                  const RegEpiState& st) {
+  constexpr int BN = WN * 32, NT = WM * WN * 64;
+  float* fr = reinterpret_cast<float*>(smem);              // [WM][BN * 2]  per-channel (sum g, sum g xhat) of each wave row
+  float* fw = fr + WM * BN * 2;                            // [BN * 2]      gamma-weighted, for the group sums
+  float* sred = fw + BN * 2;                               // [WM][WN][2 slabs][2]
+  uint32_t d[4][2];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    float v0 = acc[4 * g], v1 = acc[4 * g + 1], v2 = acc[4 * g + 2], v3 = acc[4 * g + 3];
+    if (a.act == 1) { v0 = sigmoidf_(v0); v1 = sigmoidf_(v1); v2 = sigmoidf_(v2); v3 = sigmoidf_(v3); }
+    d[g][0] = pack_bf2(v0, v1);
+    d[g][1] = pack_bf2(v2, v3);
+  }
+  bf16_t* yb = reinterpret_cast<bf16_t*>(a.y) + (long long)b * a.y_bstride;
+  float rv[32];
+  float s[2], ss[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    // runs 2k (channels 16k + 4 half ..) and 2k + 1 (16k + 8 + 4 half ..): after the swaps the lower half-wave holds channels
+    // 16k .. 16k + 7 of its pixel, the upper one 16k + 8 .. 16k + 15
+    auto r0 = __builtin_amdgcn_permlane32_swap(d[2 * k][0], d[2 * k + 1][0], false, false);
+    auto r1 = __builtin_amdgcn_permlane32_swap(d[2 * k][1], d[2 * k + 1][1], false, false);
+    crd_u32x4 u = {r0[0], r1[0], r0[1], r1[1]};
+    {
+      const float q[8] = {bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1]), bf_lo(u[2]), bf_hi(u[2]), bf_lo(u[3]), bf_hi(u[3])};
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { a0 += q[j]; a1 += q[j] * q[j]; }
+      s[k] = st.ok[k] ? a0 : 0.f;
+      ss[k] = st.ok[k] ? a1 : 0.f;
+    }
+    if (a.accumulate) {
+      const crd_u32x4 o = st.old[k];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) u[w] = pack_bf2(bf_lo(u[w]) + bf_lo(o[w]), bf_hi(u[w]) + bf_hi(o[w]));
+    }
+    if (st.ok[k]) *reinterpret_cast<crd_u32x4*>(yb + (long long)st.row * a.y_ld + st.col[k]) = u;
+    if (a.red_x) {
+      const float dq[8] = {bf_lo(u[0]), bf_hi(u[0]), bf_lo(u[1]), bf_hi(u[1]), bf_lo(u[2]), bf_hi(u[2]), bf_lo(u[3]), bf_hi(u[3])};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (st.xq[k][j] - st.rmean[k]) * st.rrstd[k];
+        float gg = st.ok[k] ? dq[j] : 0.f;
+        if (a.red_act == 1) gg *= gelu_grad(xh * st.rga[k][j] + st.rbe[k][j]);
+        rv[(k * 8 + j) * 2] = gg;
+        rv[(k * 8 + j) * 2 + 1] = gg * xh;
+      }
+    }
+  }
+  if (!a.stats && !a.red_x) return;
+  if (a.red_x) {
+    // halving butterfly over the 32 pixels of the half-wave: lane x (0..31) ends up with the total of value x
+#pragma unroll
+    for (int m = 16, n = 32; m >= 1; m >>= 1, n >>= 1) {
+      const bool up = (l & m) != 0;
+#pragma unroll
+      for (int i = 0; i < n / 2; ++i) {
+        const float send = up ? rv[i] : rv[i + n / 2];
+        const float keep = up ? rv[i + n / 2] : rv[i];
+        rv[i] = keep + __shfl_xor(send, m);
+      }
+    }
+    const int x = l & 31;                                   // value index: piece x >> 4, channel (x >> 1) & 7, moment x & 1
+    const int cl = wn * 32 + 16 * (x >> 4) + 8 * (l >> 5) + ((x >> 1) & 7);
+    fr[wm * BN * 2 + cl * 2 + (x & 1)] = rv[0];
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float sv = wave_sum(s[k]), sq = wave_sum(ss[k]);
+      if (l == 0) { sred[(((wm * WN + wn) * 2 + k) * 2)] = sv; sred[(((wm * WN + wn) * 2 + k) * 2) + 1] = sq; }
+    }
+  }
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (a.stats && t < WN * 2 * 2) {
+    const int which = t & 1, slab = (t >> 1) & 1, wn_ = t >> 2;
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) v += sred[(((w * WN + wn_) * 2 + slab) * 2) + which];
+    const int g = (n0 >> 4) + wn_ * 2 + slab;
+    if (g < a.G16) {
+      if (a.stats_partial) a.stats_partial[(((long long)b * a.n_tiles + tile) * a.G16 + g) * 2 + which] = v;
+      else stat_add(a.stats + ((long long)b * a.G16 + g) * 2 + which, v);
+    }
+  }
+  if (!a.red_x) return;
+  if (t < BN * 2) {
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) v += fr[w * BN * 2 + t];
+    const int c = n0 + (t >> 1);
+    float wv = 0.f;
+    if (c < a.Cout) {
+      grad_add(&a.red_r[((long long)b * a.Cout + c) * 2 + (t & 1)], v);
+      wv = v * a.red_gamma[c];
+    }
+    fw[t] = wv;
+  }
+  __syncthreads();
+  if (t < (BN / 16) * 2) {
+    const int slab = t >> 1, which = t & 1;
+    const int c0s = n0 + slab * 16;
+    if (c0s < a.Cout) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) s2 += fw[(slab * 16 + j) * 2 + which];
+      const int cpg = 16 * a.red_gmul;
+      grad_add(&a.red_r[(long long)gridDim.z * a.Cout * 2 + ((long long)b * (a.Cout / cpg) + c0s / cpg) * 2 + which], s2);
+    }
+  }
+  (void)NT;
+}
+
 // Waves of a workgroup that hold no output tile (split-K groups 1.. of k_igemm) must still meet the barriers of
 // conv_epilogue: one in the LDS-staged vector path, one before the statistics fold.  Keep in step with conv_epilogue.
 template <int BM, int BN, int NT>

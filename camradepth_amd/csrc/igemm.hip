@@ -58,9 +58,12 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // to cover the CUs (the k = sr patch convs: 32 workgroups x 32..64 slabs, fc2 of the small stages) the K loop is bound
 // by the issue cost of the LDS-DMA pieces (~0.45 us per slab whatever the stage count): more waves issue them in
 // parallel.
-template <int WM, int WN, int TM, int TN, int MODE, int NST, int KG = 1>
+// REGE: the register epilogue (conv_common.h: conv_epilogue_reg) -- MFMA operands swapped, stores straight from the accumulators, the
+// epilogue's own inputs prefetched at kernel start.  64 x 64 tiles without split-K only; chosen per launch (launch_mode).
+template <int WM, int WN, int TM, int TN, int MODE, int NST, int KG = 1, bool REGE = false>
 __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
   static_assert(WM * WN == 4, "4 waves per group");
+  static_assert(!REGE || (TM == 1 && TN == 1 && KG == 1), "register epilogue: one 32 x 32 tile per wave, no split-K");
   static_assert(KG == 1 || (TM == 1 && TN == 1), "split-K groups exchange a single 32x32 tile per wave");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_IT = BM / 32, B_IT = BN / 32;   // each wave DMAs 8 rows per instruction, 4 waves -> 32 rows per pass
@@ -75,6 +78,8 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
   const int wm = wave / WN, wn = wave % WN;
   const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   if (a.dbg & 8) return;
+  RegEpiState est;
+  if constexpr (REGE) reg_epi_prefetch<WM, WN>(a, b, l, wm, wn, m0, n0, est);
   // hardware-bounds-checked buffer loads: an out-of-range offset returns zeros, which implements the conv padding,
   // the K tail and the partial M/N tiles without a single branch in the load path
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
@@ -148,6 +153,13 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
   // accumulators start at the bias of their column (lane l holds column l&31 of every 32x32 tile): the load overlaps the
   // first DMA instead of adding a dependent memory latency to the epilogue
   f32x16 acc[TM][TN];
+  if constexpr (REGE) {        // swapped layout: register r of a lane is channel (r & 3) + 8 (r >> 2) + 4 (l >> 5) of the wave's 32 columns
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int col = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      acc[0][0][r] = (a.bias && col < a.Cout) ? a.bias[(long long)b * a.bias_bstride + col] : 0.f;
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + (wn * TN + j) * 32 + (l & 31);
@@ -156,6 +168,7 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = bias_v;
+  }
   }
 
   const int nK = ((a.dbg & 16) ? 0 : (a.Ktot + BK - 1) / BK + KG - 1) / KG;     // slabs per group (uniform: the tail is zero fill)
@@ -185,8 +198,10 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TN; ++j) {
+          if constexpr (REGE) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);   // C[channel][pixel]
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
     }
     cur = cur + 1 == NST ? 0 : cur + 1;
     nxt = nxt + 1 == NST ? 0 : nxt + 1;
@@ -215,6 +230,10 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
   }
 
   // ---- epilogue (conv_common.h) ----
+  if constexpr (REGE) {
+    conv_epilogue_reg<WM, WN>(a, acc[0][0], b, l, wm, wn, n0, blockIdx.x, lds, est);
+    return;
+  }
   conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
                                 [&](int i, int rr, bool& valid, int& row) {
     row = m0 + (wm * TM + i) * 32 + rr;
@@ -223,6 +242,17 @@ __global__ __launch_bounds__(256 * KG) void k_igemm(ConvK a) {
     row = m0 + rl;
     valid = row < a.OHW;
   });
+}
+
+int g_rege_on = 1;
+long long g_rege_launches = 0;
+// bf16 output in the plain layout (what conv_epilogue's vector path covers, minus the patch scatter), no per-tile partial statistics,
+// no per-channel sums; the fused reduce needs whole 16-channel slabs
+bool crd_igemm_reg_epilogue_applies(const ConvK& k) {
+  const bool ok = g_rege_on && k.out_mode == 0 && !k.y_f32 && !k.res && (k.Cout & 7) == 0 && (k.y_ld & 7) == 0 && k.vec_ok && !k.chan &&
+                  (!k.red_x || ((k.Cout & 15) == 0 && (k.red_x_ld & 7) == 0 && (reinterpret_cast<uintptr_t>(k.red_x) & 15) == 0));
+  if (ok) ++g_rege_launches;
+  return ok;
 }
 
 template <int WM, int WN, int TM, int TN, int MODE, int NST, int KG = 1>
@@ -236,6 +266,12 @@ void launch_mode(const ConvK& k, dim3 grid, hipStream_t st) {
   }
   ConvK kk = k;
   kk.lds_bytes = (int)lds;
+  if constexpr (TM == 1 && TN == 1 && KG == 1 && WM == 2 && WN == 2) {
+    if (crd_igemm_reg_epilogue_applies(k)) {
+      hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, MODE, NST, KG, true>), grid, dim3(256), lds, st, kk);
+      return;
+    }
+  }
   hipLaunchKernelGGL((k_igemm<WM, WN, TM, TN, MODE, NST, KG>), grid, dim3(256 * KG), lds, st, kk);
 }
 
@@ -352,4 +388,11 @@ extern "C" int crd_conv_igemm(const crd_conv_desc* d, crd_stream_t stream) {
   if (d->Cout <= 96) return launch<4, 1, 1, 3, 2>(k, d->B, st, pcap);
   if (d->Cout > 128 && d->Cout <= 160) return launch<4, 1, 1, 5, 2>(k, d->B, st, pcap);
   return launch<2, 2, 2, 2, 2>(k, d->B, st, pcap);
+}
+
+extern "C" int crd_tune_igemm_reg_epilogue(int32_t on) {
+  if (on < 0) return (int)(g_rege_launches & 0x7fffffff);
+  const int prev = g_rege_on;
+  g_rege_on = on ? 1 : 0;
+  return prev;
 }

@@ -149,6 +149,12 @@ int crd_tune_pw_narrow(int32_t on);
  * 64- or 32-column tiles instead (default 512; 0 disables; < 0 restores the default).  Returns the previous value.
  * Not needed for correctness -- the tests use it to reach every tile configuration with small inputs. */
 int crd_tune_conv3x3_small_grid(int workgroups);
+/* Round 5: the 64 x 64-tile launches of crd_conv_igemm with a bf16 output in the plain layout (+ bias, sigmoid, accumulate, GroupNorm
+ * sums, the fused GroupNorm-backward reduce) use a REGISTER epilogue (csrc/conv_common.h: conv_epilogue_reg -- swapped MFMA operands,
+ * 16-byte stores straight from the accumulators, the epilogue's inputs prefetched at kernel start) instead of the LDS-staged one.
+ * on = 0 / 1 switches it off / on for the following launches (returns the previous setting); on < 0 returns the number of launches
+ * that took it so far (modulo 2^31).  Same results up to the summation order of the fused reduce's fp32 partials. */
+int crd_tune_igemm_reg_epilogue(int32_t on);
 
 /* ---- fp8 (OCP e4m3) inference path of the decoder's 3x3 ConvLayers (BASELINE.json config 5) ------------------------------
  * y = bf16( x_scale * w_scales[co] * sum_k x8[k] * w8[co][k] ) on the block-scaled MFMA (all block scales 2^0) at twice the

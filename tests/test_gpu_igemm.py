@@ -378,3 +378,78 @@ def test_conv3x3_persistent_dgrad(B, Ci, H, W, Co, acc):
     dx = base.to(torch.bfloat16).cuda()
     run_conv(dypm, Co, 0, B, H, W, Co, wd, Ci, 3, 3, 1, 1, H, W, dx, Ci, 0, gather_mode=1, accumulate=acc)
     assert_close(dx.float().cpu(), base + ref.permute(0, 2, 3, 1), f"persistent dgrad {Ci}<-{Co}", rel=5e-3, elem=1.5e-2)
+
+
+REGE_CASES = [
+    # what, Cin, Cout, H, W  (B = 2; 64 x 64 tiles: the small-grid path of crd_conv_igemm)
+    ("fwd_bias_stats", 160, 160, 16, 26), ("fwd_bias_stats", 128, 128, 9, 13), ("fwd_sigmoid", 64, 72, 10, 11),
+    ("dgrad_acc", 160, 160, 16, 26), ("dgrad_acc_bias", 128, 128, 32, 52),
+    ("dgrad_red_act", 160, 640, 16, 26), ("dgrad_red_f32", 640, 160, 16, 26), ("dgrad_red_f32_acc_bias", 160, 160, 16, 26),
+    ("dgrad_red_f32", 128, 128, 8, 13),
+]
+
+
+@pytest.mark.parametrize("case", REGE_CASES, ids=[f"{c[0]}_{c[1]}to{c[2]}_{c[3]}x{c[4]}" for c in REGE_CASES])
+def test_register_epilogue_matches_the_staged_epilogue(case):
+    """Round 5: the 64 x 64 tiles' register epilogue (conv_common.h: conv_epilogue_reg) against the LDS-staged one it replaces, toggled with
+    crd_tune_igemm_reg_epilogue: identical stored bf16 values (plain, sigmoid, accumulate, per-image bias), GroupNorm sums and the fused
+    GroupNorm-backward reduce equal up to the summation order of fp32 partials -- and the register path really ran."""
+    what, Ci, Co, H, W = case
+    lib = _lib()
+    L = lib.load()
+    g = torch.Generator().manual_seed(sum(map(ord, what)) + Ci + Co)
+    B = 2
+    dgrad = what.startswith("dgrad")
+    w = bf(torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5)
+    x = bf(torch.randn(B, Co if dgrad else Ci, H, W, generator=g))
+    xpm = to_pm(x)
+    wp = w.permute(1, 2, 3, 0).contiguous().reshape(Ci, 1, Co).to(torch.bfloat16).cuda() if dgrad else pack_w(w)
+    N = Ci if dgrad else Co                   # output channels of the launch
+    K = Co if dgrad else Ci
+    bias = (torch.randn(B, N, generator=g) * 0.1).cuda() if "bias" in what else None
+    y0 = bf(torch.randn(B, H, W, N, generator=g)).to(torch.bfloat16).cuda()
+    red_in = None
+    if "red" in what:
+        xf32 = "f32" in what
+        gmul, act = (1, 0) if xf32 else (4, 1)
+        xg = to_pm(bf(torch.randn(B, N, H, W, generator=g) * 1.3 + 0.2))
+        if xf32:
+            xg = (xg.float() + 0.001 * torch.randn(xg.shape, generator=g).cuda()).contiguous()
+        gam, bet = (1 + 0.1 * torch.randn(N, generator=g)).cuda(), (0.1 * torch.randn(N, generator=g)).cuda()
+        gst = zsum(B, N // 16, 2)
+        lib.check(L.crd_gn_stats(xg.data_ptr(), 1 if xf32 else 0, N, 0, B, H * W, N, gst.data_ptr(), None, lib.stream()), "gn_stats")
+        red_in = (xg, gst, gam, bet, gmul, act)
+    outs = {}
+    for on in (0, 1):
+        prev = L.crd_tune_igemm_reg_epilogue(on)
+        n0 = L.crd_tune_igemm_reg_epilogue(-1)
+        y = y0.clone()
+        st = zsum(B, N // 16, 2) if "stats" in what else None
+        r = zsum(B * N * 2 + B * (N // (16 * red_in[4])) * 2) if red_in else None
+        d = lib.ConvDesc()
+        d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = xpm.data_ptr(), K, 0, B, H, W, K
+        d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = wp.data_ptr(), N, 1, 1, 1, 0, H, W
+        d.gather_mode = 1 if dgrad else 0
+        d.y, d.y_ld, d.y_coff = y.data_ptr(), N, 0
+        d.accumulate = 1 if "acc" in what else 0
+        d.act = 1 if "sigmoid" in what else 0
+        if bias is not None:
+            d.bias, d.bias_bstride = bias.data_ptr(), N
+        if st is not None:
+            d.stats = st.data_ptr()
+        if red_in:
+            xg, gst, gam, bet, gmul, act = red_in
+            d.red_x, d.red_x_ld, d.red_gmul, d.red_act, d.red_x_f32 = xg.data_ptr(), N, gmul, act, 1 if xg.dtype == torch.float32 else 0
+            d.red_stats, d.red_gamma, d.red_beta, d.red_r = gst.data_ptr(), gam.data_ptr(), bet.data_ptr(), r.data_ptr()
+        lib.check(L.crd_conv_igemm(C.byref(d), lib.stream()), "crd_conv_igemm")
+        torch.cuda.synchronize()
+        took = L.crd_tune_igemm_reg_epilogue(-1) - n0
+        L.crd_tune_igemm_reg_epilogue(prev)
+        assert took == on, f"register epilogue launches: {took} with the switch at {on}"
+        outs[on] = (y, st, r)
+    (ya, sa, ra), (yb, sb, rb) = outs[0], outs[1]
+    assert torch.equal(ya, yb), f"stored values differ: max {float((ya.float() - yb.float()).abs().max()):.3e}"
+    if sa is not None:
+        assert_close(sval(sb), sval(sa), "GroupNorm sums", rel=1e-5, elem=1e-5)
+    if ra is not None:
+        assert_close(gval(rb), gval(ra), "fused gn-bwd reduce", rel=3e-4, elem=3e-4)

@@ -4,7 +4,12 @@ import sys, ctypes as C
 sys.path.insert(0, ".")
 import torch
 from camradepth_amd import lib
+import os
 L = lib.load()
+if os.environ.get("CRD_REGE") is not None:            # round 5: register epilogue of the 64 x 64 tiles off (0) / on (1)
+    L.crd_tune_igemm_reg_epilogue(int(os.environ["CRD_REGE"]))
+if os.environ.get("CRD_NARROW") is not None:
+    L.crd_tune_pw_narrow(int(os.environ["CRD_NARROW"]))
 B = 8
 SHAPES = [  # Cin, Cout, H, W, k, stride, gather_mode   (the encoder's Mlp.fc1 / fc2 and their data gradients, base model)
     (64, 512, 64, 104, 1, 1, 0), (512, 64, 64, 104, 1, 1, 0), (512, 64, 64, 104, 1, 1, 1), (64, 512, 64, 104, 1, 1, 1),
@@ -44,4 +49,6 @@ for Cin, Cout, H, W, k, s, mode in SHAPES:
         e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / REPS
     byts = B * (H * W * Cin + OH * OW * Cout) * 2 + Cout * k * k * Cin * 2
+    if os.environ.get("CRD_REGE_COUNT"):
+        print("  register-epilogue launches so far:", L.crd_tune_igemm_reg_epilogue(-1))
     print(f"Cin{Cin:5d} Cout{Cout:5d} {H}x{W} k{k} s{s} mode{mode}: {us:7.2f} us  {2.0 * B * OH * OW * Cout * Cin * k * k / us / 1e6:6.1f} TF/s  {byts / us / 1e6:5.2f} TB/s")

@@ -408,6 +408,8 @@ def main():
                          "weight gradients stay bf16")
     ap.add_argument("--tune-narrow", type=int, default=None, choices=[0, 1, 2],
                     help="A/B aid: crd_tune_pw_narrow(n) before the plans are built (0: the narrow streaming pointwise kernel off)")
+    ap.add_argument("--tune-rege", type=int, default=None, choices=[0, 1],
+                    help="A/B aid: crd_tune_igemm_reg_epilogue(n) (0: the LDS-staged epilogue for the 64 x 64 igemm tiles)")
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)      # tests: launcher contract on CPU (gloo)
     a = ap.parse_args()
     if a.gpus > 1 and "RANK" not in os.environ:       # no launcher: be the launcher (before any HIP call in this process)
@@ -439,6 +441,9 @@ def main():
     if a.tune_narrow is not None:
         import camradepth_amd.lib as _L
         _L.load().crd_tune_pw_narrow(a.tune_narrow)
+    if a.tune_rege is not None:
+        import camradepth_amd.lib as _L
+        _L.load().crd_tune_igemm_reg_epilogue(a.tune_rege)
     sup = a.variant == "supervised_seg"
     model = CamRaDepth(input_channels=7, supervised_seg=sup, seed=0).cuda()      # same init on every rank
     if a.inference:       # the reference's own "runtime" figure (Trainer.test(), runner.py:417-420), without its missing device sync

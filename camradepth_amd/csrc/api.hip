@@ -17,19 +17,47 @@ extern "C" int crd_version(void) { return 1; }
 extern "C" const char* crd_arch(void) { return "gfx950"; }
 
 // ---- sticky non-finite indicator of the fixed-point sums (common.h: to_fx) ----
-static int (*g_nf_readers[64])(int);
+// One flag per translation unit (a static __device__ word: no relocatable device code needed); their device addresses are gathered
+// once, and a status query is ONE 64-thread launch on the null stream + ONE 4-byte copy, whatever the number of translation units.
+constexpr int NF_MAX = 64;
+static void* (*g_nf_addr_fns[NF_MAX])();
 static int g_nf_count = 0;
-void crd_register_nonfinite_reader(int (*reader)(int)) {
-  if (g_nf_count < 64) g_nf_readers[g_nf_count++] = reader;
+static bool g_nf_overflow = false;
+void crd_register_nonfinite_flag(void* (*addr_of_flag)()) {
+  if (g_nf_count < NF_MAX) g_nf_addr_fns[g_nf_count++] = addr_of_flag;
+  else g_nf_overflow = true;                       // reported by crd_nonfinite_status: never silently dropped
+}
+struct NfPtrs { int* p[NF_MAX]; };
+static __device__ int g_nf_any;
+__global__ __launch_bounds__(64) void k_nf_gather(NfPtrs ptrs, int n, int reset) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  if ((int)threadIdx.x < n && *ptrs.p[threadIdx.x]) {
+    any = 1;
+    if (reset) *ptrs.p[threadIdx.x] = 0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) g_nf_any = any;
 }
 extern "C" int crd_nonfinite_status(int32_t reset) {
-  int any = 0;
-  for (int i = 0; i < g_nf_count; ++i) {
-    const int v = g_nf_readers[i](reset);
-    if (v < 0) { crd_set_error("crd_nonfinite_status: cannot read the device flag"); return CRD_E_LAUNCH; }
-    any |= v;
+  static NfPtrs ptrs;
+  static bool resolved = false;
+  if (g_nf_overflow) { crd_set_error("crd_nonfinite_status: more than %d translation units registered a flag", NF_MAX); return CRD_E_LAUNCH; }
+  if (!resolved) {
+    for (int i = 0; i < g_nf_count; ++i) {
+      ptrs.p[i] = reinterpret_cast<int*>(g_nf_addr_fns[i]());
+      if (!ptrs.p[i]) { crd_set_error("crd_nonfinite_status: cannot resolve the device flag of translation unit %d", i); return CRD_E_LAUNCH; }
+    }
+    resolved = true;
   }
-  return any ? 1 : 0;
+  hipLaunchKernelGGL(k_nf_gather, dim3(1), dim3(64), 0, 0, ptrs, g_nf_count, reset ? 1 : 0);
+  int v = 0;
+  if (hipGetLastError() != hipSuccess || hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_nf_any), sizeof(int)) != hipSuccess) {
+    crd_set_error("crd_nonfinite_status: cannot read the device flag");
+    return CRD_E_LAUNCH;
+  }
+  return v ? 1 : 0;
 }
 
 // ---- refused dynamic-LDS reservations (common.h: crd_reserve_lds) ----

@@ -288,15 +288,15 @@ __device__ __forceinline__ void sum_samples(const crd_sum_t* r, int B, int C, in
   }
 }
 
-// every translation unit registers a reader of its sticky flag with api.hip (crd_nonfinite_status)
-void crd_register_nonfinite_reader(int (*reader)(int reset));
-static int crd_tu_read_nonfinite(int reset) {
-  int v = 0;
-  if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(crd_tu_nonfinite), sizeof(int)) != hipSuccess) return -1;
-  if (reset && v) { const int z = 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(crd_tu_nonfinite), &z, sizeof(int)); }
-  return v;
+// every translation unit registers the DEVICE ADDRESS of its sticky flag with api.hip: crd_nonfinite_status() gathers all of them with
+// one 64-thread launch and one copy (round 5, ADVICE r4: it used to be one blocking hipMemcpyFromSymbol per translation unit and call)
+void crd_register_nonfinite_flag(void* (*addr_of_flag)());
+static void* crd_tu_nonfinite_addr() {
+  void* p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(crd_tu_nonfinite)) != hipSuccess) return nullptr;
+  return p;
 }
-namespace { struct CrdNonfiniteRegistrar { CrdNonfiniteRegistrar() { crd_register_nonfinite_reader(&crd_tu_read_nonfinite); } }; static CrdNonfiniteRegistrar crd_nonfinite_registrar; }
+namespace { struct CrdNonfiniteRegistrar { CrdNonfiniteRegistrar() { crd_register_nonfinite_flag(&crd_tu_nonfinite_addr); } }; static CrdNonfiniteRegistrar crd_nonfinite_registrar; }
 
 static inline hipStream_t as_stream(crd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

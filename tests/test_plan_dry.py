@@ -57,3 +57,28 @@ def test_eval_plan_records_no_backward_only_tensors():
     m, pe = _plan(False)
     assert len(pe.fwd) <= len(pt.fwd)
     assert pe.training is False
+
+
+def test_fp8_gradient_plan_records_both_scaling_variants():
+    """Config 5 as a training plan (e4m3 forward + data gradients): the just-in-time variant (scale update + re-quantisation behind the
+    GroupNorm backward of every e4m3 layer) and the delayed variant (one update at the head of the backward pass) are both recorded;
+    plan.fp8_jit selects -- what TrainStep flips after its calibration iteration."""
+    m = CamRaDepth(input_channels=7, depths=(1, 1, 1, 1))
+    m.train(True)
+    m._ensure_grad_views()
+    m.__dict__["fp8_scales"] = {"depth_upsample.3": 0.01, "depth_upsample.4": 0.01}
+    m.__dict__["fp8_train"] = True
+    m.__dict__["fp8_grad"] = True
+    p = Plan(m, 8, 128, 192, True)                  # 8 x 6 x 8 = 384 tiles at full resolution: that stage takes the fp8 route, 96 at half do not
+    assert p.fp8_grad_layers == ["depth_upsample.4.conv.layers.2"]          # the MFMA-bound first writer of the concat gradient
+    assert sum(op.name == "crd_conv3x3_fp8" for op in p.fwd) == 3
+    jit = [op.name for op in p.bwd if p.live(op)]
+    p.fp8_jit = False
+    delayed = [op.name for op in p.bwd if p.live(op)]
+    assert jit.count("crd_conv3x3_fp8_dgrad") == delayed.count("crd_conv3x3_fp8_dgrad") == 1
+    assert jit.count("crd_quant_fp8_dev") == 1 and delayed.count("crd_quant_fp8_dev") == 0
+    assert jit.count("crd_fp8_scale_update") == 1 and delayed.count("crd_fp8_scale_update") == 1
+    assert delayed[0] == "crd_fp8_scale_update" and jit[0] != "crd_fp8_scale_update"      # delayed: at the head of the backward pass
+    i = jit.index("crd_gn_bwd_apply_fp8")
+    assert jit[i + 1:i + 3] == ["crd_fp8_scale_update", "crd_quant_fp8_dev"]              # just-in-time: right behind the layer's GroupNorm backward
+    assert bench.floor_budget(p)["floor_ms"] > 0

@@ -120,6 +120,11 @@ def load():
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [_CT[ch] for ch in sig]
+    # developer aids (A/B of a whole test or bench run): kernel-selection knobs of the C ABI set once at load time
+    if os.environ.get("CRD_TUNE_REGE") is not None:
+        lib.crd_tune_igemm_reg_epilogue(int(os.environ["CRD_TUNE_REGE"]))
+    if os.environ.get("CRD_TUNE_NARROW") is not None:
+        lib.crd_tune_pw_narrow(int(os.environ["CRD_TUNE_NARROW"]))
     _lib = lib
     return lib
 

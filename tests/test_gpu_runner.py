@@ -107,40 +107,56 @@ def test_ragged_last_batch_continues_the_optimizer_state():
     # per epoch: optimizer after batch 2 and (flush) after batch 3
     assert st.step_count == 2 * epochs and st.iter_count == 3 * epochs
 
-    # -- the same iterations written out eagerly with ONE optimizer
-    m2 = fresh()
-    opt = diffGradNorm(m2.parameters(), lr=lr)
+    # -- the same iterations written out eagerly with ONE optimizer; and, as the negative control, with an optimizer that RESTARTS whenever
+    # the batch shape changes (the round-3 bug this test exists for)
     sched = one_cycle(max(len(batches) * epochs, 2), lr, div_factor=2.0)
-    cfgm = m2.cfg
-    sched_steps = 0
-    for e in range(epochs):
-        window = 0
-        for i, b in enumerate(batches):
-            B = b["image"].shape[0]
-            masks = {"drop_path": [torch.ones(B) for _ in cfgm.drop_path_rates], "dropout2d": [torch.ones(B, 128) for _ in range(5)]}
-            if window == 0:
-                opt.zero_grad(set_to_none=False)
-            out = m2(b["image"].cuda(), masks=masks)
-            loss, _ = hl.total_loss(out, {kk: v.cuda() for kk, v in b.items()}, False)
-            (loss / k).backward()
-            window += 1
-            if window == k or i + 1 == len(batches):
-                lr_i, b1 = sched[min(sched_steps, len(sched) - 1)]
-                for gp in opt.param_groups:
-                    gp["lr"], gp["betas"] = lr_i, (b1, gp["betas"][1])
-                opt.step()
-                window = 0
-            if i + 1 > k:                  # the reference's scheduler lag (runner.py:269-270)
-                sched_steps += 1
-    torch.cuda.synchronize()
+
+    def eager(restart_on_shape_change):
+        m = fresh()
+        opt = diffGradNorm(m.parameters(), lr=lr)
+        cfgm = m.cfg
+        sched_steps, last_B = 0, None
+        for e in range(epochs):
+            window = 0
+            for i, b in enumerate(batches):
+                B = b["image"].shape[0]
+                if restart_on_shape_change and last_B is not None and B != last_B and window == 0:
+                    opt = diffGradNorm(m.parameters(), lr=lr)
+                last_B = B
+                masks = {"drop_path": [torch.ones(B) for _ in cfgm.drop_path_rates], "dropout2d": [torch.ones(B, 128) for _ in range(5)]}
+                if window == 0:
+                    opt.zero_grad(set_to_none=False)
+                out = m(b["image"].cuda(), masks=masks)
+                loss, _ = hl.total_loss(out, {kk: v.cuda() for kk, v in b.items()}, False)
+                (loss / k).backward()
+                window += 1
+                if window == k or i + 1 == len(batches):
+                    lr_i, b1 = sched[min(sched_steps, len(sched) - 1)]
+                    for gp in opt.param_groups:
+                        gp["lr"], gp["betas"] = lr_i, (b1, gp["betas"][1])
+                    opt.step()
+                    window = 0
+                if i + 1 > k:                  # the reference's scheduler lag (runner.py:269-270)
+                    sched_steps += 1
+        torch.cuda.synchronize()
+        return m, sched_steps
+    m2, sched_steps = eager(False)
     assert sched_steps == st.sched_steps
     start = _flat_of(m2, sd)
     moved = float((m2.flat - start).norm())
     assert moved > 0
-    # graph step vs eager autograd path: the same kernels, enqueued differently; parameters agree to float rounding of the update
+    # graph step vs eager autograd path: the same kernels, enqueued differently (the streaming weight gradients split the pixels another
+    # way: gradient rel-L2 ~3e-8 per step).  diffGradNorm's first steps are SIGN-like (m / sqrt(v)): an element whose gradient is rounding
+    # noise flips with that difference and then sits 2 lr away -- 1e-4 of the elements flipped is rel 0.02, 7e-4 is 0.05.  Measured over
+    # the four builds that only regroup fp32 partial sums (register epilogue x narrow kernel, CRD_TUNE_REGE / CRD_TUNE_NARROW; round 5):
+    # 0.0101, 0.0083, 0.0105, 0.0523 -- and 0.75 for an optimizer that restarts at the shape changes (the negative control below).
     rel_ = float((m1.flat - m2.flat).norm()) / moved
-    assert rel_ < 2e-2, rel_
+    m3, _ = eager(True)
+    rel_restart = float((m1.flat - m3.flat).norm()) / moved
+    print(f"ragged last batch: runner vs eager loop rel {rel_:.4f}; vs an optimizer that restarts at the shape changes {rel_restart:.4f}")
+    assert rel_ < 0.12, rel_
     # a run whose optimizer state restarted at the shape changes is far outside that (moments, bias correction and schedule differ)
+    assert rel_restart > 4 * max(rel_, 0.03), (rel_, rel_restart)
 
 
 def _flat_of(model, sd):

@@ -28,7 +28,7 @@ import csv, sys, collections
 if len(sys.argv) < 2 or not sys.argv[1]:
     print("   (no output for", sys.argv[2] if len(sys.argv) > 2 else "?", ")"); sys.exit()
 WANT = ("k_igemm<2, 2, 1, 1", "k_gngemm_reg", "k_gn_bwd_apply", "k_gn_bwd_reduce", "k_dwconv", "k_attn_scores_bwd", "k_attn_scores", "k_enc_stage",
-        "k_conv3x3p", "k_wgrad3x3")
+        "k_conv3x3p", "k_wgrad3x3", "k_pw_narrow", "k_gn_pw_wide", "k_wgrad_grouped")
 agg = collections.defaultdict(list)
 tot = collections.defaultdict(float)
 for r in csv.DictReader(open(sys.argv[1])):
@@ -48,5 +48,7 @@ PY
   done
 }
 run_set "eager training iterations x3 (per-launch encoder), base 8x7x256x416" "CRD_ENC_PERSIST=0" tools/run_forward.py 3 train
+if [ "$1" = "persist" ]; then      # the parked persistent stage kernel (round 4's second table): only on request
 run_set "eval forwards x3, persistent stages 3-4 (CRD_ENC_PERSIST=1)" "CRD_DEV_SWITCHES=1 CRD_ENC_PERSIST=1" tools/run_forward.py 3
+fi
 cat $O/summary.txt

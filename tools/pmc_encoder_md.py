@@ -18,7 +18,7 @@ for line in open(src):
         runs[cur][k.strip()][c] = (int(n) if n else 0, float(tot))
 SIMDS, XCDS = 1024, 8
 with open(out, "w") as f:
-    f.write("# Hardware counters of the encoder kernels (round 4)\n\n"
+    f.write("# Hardware counters of the encoder kernels\n\n"
             "`tools/pmc_encoder.sh` on one MI355X: one `rocprofv3 --pmc` pass per counter set (no tracing), program = `python3 tools/run_forward.py`\n"
             "(eager iterations of the benchmark configuration: base, 8 x 7 x 256 x 416).  Raw sums are per RUN (3 iterations); launches = launches in the run.\n\n"
             "Derived columns: **wave time** = SQ_WAVE_CYCLES split into ACTIVE (issuing: SQ_ACTIVE_INST_ANY), WAIT (parked on s_waitcnt / barrier:\n"

@@ -13,7 +13,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-res
 # v_pk_fma_f32 and keeps every unpacked operand alive to do so (k_bicubic_bwd_tile: 452 instead of 106 registers, k_bicubic 194 -> 124,
 # k_dwconv_wgrad 354 -> 255: two workgroups per CU instead of one); norm.hip measured 0.17 ms per step SLOWER without it, the MFMA
 # kernels are left as they were (conv3x3.hip gets scratch without it).
-NO_SLP = set((os.environ.get("CRD_NOSLP_FILES") or "decoder_ops,encoder_ops,enc_stage").split(","))
+NO_SLP = set((os.environ.get("CRD_NOSLP_FILES") or "decoder_ops,encoder_ops").split(","))
 EXTRA = (os.environ.get("CRD_EXTRA_FLAGS") or "").split()      # developer switch: e.g. -DCRD_DWW_WGS=1 for an A/B build
 
 

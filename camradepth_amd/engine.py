@@ -79,26 +79,6 @@ MLP_FUSED = _dev_int("CRD_MLP_FUSED", 1) != 0
 MLP_FUSED_MAXPIX = _dev_int("CRD_MLP_FUSED_MAXPIX", 128)
 FC2_FOLD_MINROWS = _dev_int("CRD_FC2_FOLD_MINROWS", 16384)   # (B = 16 inference 10.51 -> 10.16 ms; B = 1, 8: unchanged)
 GN_CONV_MAXROWS = _dev_int("CRD_GN_CONV_MAXROWS", 1 << 30)   # pixels x batch up to which a Block's GEMMs are fused
-# Encoder stages as ONE persistent launch each (csrc/enc_stage.hip: a sample's rows stay in LDS across all Blocks of the stage, the
-# sample's workgroups exchange statistics / keys / stencil rows through tagged granules) wherever the library covers the shape
-# (stages 3 and 4 at 256 x 416).  Correct, bit-reproducible and graph-safe (tests/test_gpu_enc_stage.py).  Measured at B = 8
-# (profiles/r04_enc_stage_*.txt, DESIGN section 4 "Round 4"): stage 3 with one image row per workgroup 1207 us against 1275 for the
-# per-launch path in inference plans, 1308 against 1282 in training plans (which store every tensor the backward pass reads);
-# stage 4 378 against 318.  Whole inference forward with stage 3 persistent ("auto": inference plans, stage 3, 64 <= B x H <= 256):
-# B = 8 6.12 -> 6.01 ms, B = 16 10.07 -> 9.71 ms -- in most processes.  In 4 of 9 `bench.py --inference` processes the same graph took
-# 7.7-7.8 ms (the per-launch path: 6.10-6.13 in 7 of 7): a slow mode per process that the eager / per-stage measurements never showed
-# and that is not the workgroup -> XCD placement (tools/enc_place.py: every sample's workgroups share an XCC in every process).
-# Until that is understood the persistent path stays opt-in: CRD_ENC_PERSIST=1 (everywhere the library covers the shape) or =auto.
-ENC_ROWS_PER_WG = 0       # image rows per workgroup of the persistent stage kernel: 0 = the library chooses (tests force 1 / 2)
-
-
-def enc_persist_default():
-    """Round 5: a DEVELOPER switch (CRD_DEV_SWITCHES=1 CRD_ENC_PERSIST=1|auto).  The path is parked: forward-only, at parity in time,
-    and its per-process slow mode under graph replay was never root-caused ("Round 4")."""
-    v = os.environ.get("CRD_ENC_PERSIST", "0") if os.environ.get("CRD_DEV_SWITCHES") == "1" else "0"
-    return v if v in ("0", "1", "auto") else "0"
-
-
 LATE_WGRAD = not _dev_flag("CRD_NO_LATE_WGRAD")
 W3_LATE_WGS = _dev_int("CRD_W3_LATE_WGS", 160)
 LATE = 3            # Op.stream id of those ops
@@ -246,7 +226,6 @@ class ConvW:
         self.wg_budget = 0
         self.dw_parts, self.dw_S, self.stream3_geom = None, 0, None   # per-split copies of dw for the streaming 3x3 wgrad
         self.cmap_dev = None
-        self.want_frag, self.w_frag = False, None            # fragment-ordered copy of w_fwd for the persistent encoder stages
 
 
 class Plan:
@@ -263,7 +242,6 @@ class Plan:
         self.convs = []
         self.keep = []                              # keep ctypes structs / tensors alive
         self.dw_entries, self.dw_grads = [], []
-        self.vec_entries = []                       # (parameter name, n, fp32 destination view): plain copies in the pack table
         self.row_grads = []                         # (param, C, rows buffer, R, tag, offset, row stride): gradient = sum of the rows
         self.shapes = {}
         self.fwd_marks = []
@@ -279,10 +257,8 @@ class Plan:
         # their weight-gradient launches are not recorded and whatever fused kernels still produce for them lands in a
         # scratch buffer instead of the flat gradient
         self.gn_conv_on = gn_conv_default()
-        self.enc_persist = enc_persist_default()
         self.enc_taps = {}
         self.block_ops = {}
-        self.enc_status = []               # status words of the persistent stage launches (non-zero: a workgroup gave up waiting)
         # need_grad False (plan built under torch.no_grad()): tensors only a backward pass reads are not written
         self.need_grad = bool(getattr(model, "_need_grad", True))
         self.frozen = frozenset(n for n in model._names if not model._param(n).requires_grad)
@@ -535,35 +511,6 @@ class Plan:
             n.xn, n.xn_ld = (P(sp["xn"]), sp["xn"].ld) if sp["xn"] is not None else (None, 0)
             self.keep.append(n)
             return C.byref(n)
-        if sp.get("enc_stage"):
-            def PP(v):
-                if v is None:
-                    return None
-                return v.t.data_ptr() if isinstance(v, PM) else v.data_ptr()
-            blocks = (L.EncBlockDesc * len(sp["blocks"]))()
-            for e, bd in zip(blocks, sp["blocks"]):
-                pf = []
-                for f, cw in (("wq", bd["cq"]), ("wsr", bd["csr"]), ("wk", bd["ck"]), ("wp", bd["cp"]), ("w1", bd["c1"]), ("w2", bd["c2"])):
-                    if cw is not None:
-                        wt = cw.w_fwd if f == "wp" else cw.w_frag          # GEMM operands in MFMA-fragment order (crd_pack_frag32)
-                        setattr(e, f, wt.data_ptr())
-                        pf.append((wt.data_ptr(), wt.numel() * 2))
-                e.w9b, e.vec, e.dp = bd["w9b"].data_ptr(), bd["vec"].data_ptr(), PP(bd["dp"])
-                pf += [(bd["vec"].data_ptr(), bd["vec"].numel() * 4), (bd["w9b"].data_ptr(), bd["w9b"].numel() * 2)]
-                for i, (ptr_, nb) in enumerate(pf):
-                    e.pf_ptr[i], e.pf_bytes[i] = ptr_, nb
-                for f in ("st1", "ch1", "xn", "q", "kr", "stk", "krn", "k", "ssum", "idx", "xbar", "u", "x1", "st2", "xn2", "h1", "sth1",
-                          "h2", "sth2", "h3", "x2"):
-                    setattr(e, f, PP(bd[f]))
-            table = torch.frombuffer(bytearray(bytes(blocks)), dtype=torch.uint8).to(self.dev)
-            self.buffers.append(table)
-            d = L.EncStageDesc()
-            d.x, d.blocks, d.nblocks = PP(sp["x"]), table.data_ptr(), len(sp["blocks"])
-            d.B, d.H, d.W, d.C, d.hidden, d.heads, d.sr = sp["dims"]
-            d.xb_out, d.sync_ws, d.status = PP(sp["xb"]), sp["ws"].data_ptr(), sp["status"].data_ptr()
-            d.rows_per_wg = ENC_ROWS_PER_WG
-            self.keep.append(d)
-            return C.byref(d)
         if sp.get("mlp"):
             d = L.MlpDesc()
             for k_, v in sp["ptrs"].items():
@@ -831,31 +778,13 @@ class Plan:
             sc = {"DH": self.act(Cs, Hs, Ws), "DHID": self.act(hid, Hs, Ws), "DHID2": self.act(hid, Hs, Ws),
                   "DXN": self.act(Cs, Hs, Ws), "DQ": self.act(Cs, Hs, Ws), "hid": hid}
             pre = dh = None
-            persist = None
-            want = self.enc_persist == "1" or (self.enc_persist == "auto" and not tr and sr == 2 and 64 <= B * Hs <= 256)
-            if want and cfg.depths[s] > 0 and int(self.lib.crd_enc_stage_supported(B, Hs, Ws, Cs, hid, heads, sr)) > 0:
-                persist = []
-            X_in = X
             for i in range(cfg.depths[s]):
                 X, pre, dh = self.block(f"dest_encoder.block{s + 1}.{i}", X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc,
-                                        pre=pre, want_next=i + 1 < cfg.depths[s], dh_prev=dh, persist=persist)
+                                        pre=pre, want_next=i + 1 < cfg.depths[s], dh_prev=dh)
                 bi += 1
             self.flush_deferred(grp)       # grp (patch embed) is the LAST backward unit of this stage
             Xb = self.act(Cs, Hs, Ws)
-            if persist is not None:
-                ws_bytes = int(self.lib.crd_enc_stage_ws_bytes(B, Hs, Ws, Cs, hid, heads, sr))
-                ws = torch.zeros(ws_bytes // 8, dtype=torch.int64, device=self.dev)      # zeroed once: the tags carry an epoch
-                status = torch.zeros(1, dtype=torch.int32, device=self.dev)
-                self.buffers += [ws, status]
-                self.enc_status.append(status)
-                spec = dict(enc_stage=True, x=X_in, blocks=persist, dims=(B, Hs, Ws, Cs, hid, heads, sr), xb=Xb, ws=ws, status=status)
-                op = self._emit(self.fwd, "crd_enc_stage_fwd", [spec])
-                # algorithmic FLOPs of the stage's GEMMs + QK^T
-                M_ = (Hs // sr) * (Ws // sr)
-                per_blk = 2.0 * B * (N * Cs * Cs + (M_ * Cs * Cs * sr * sr if sr > 1 else 0) + M_ * Cs * Cs + 2 * N * Cs * hid + N * M_ * Cs)
-                op.meta = {"kernel": "k_enc_stage", "flops": per_blk * cfg.depths[s], "shape": f"stage {s + 1}: {cfg.depths[s]} blocks C{Cs} {Hs}x{Ws}"}
-            else:
-                self._emit(self.fwd, "crd_f32_to_bf16_rows", [X.t, Cs, Xb.t, Cs, 0, B * N, Cs, None, 1, None, 0, 0], io=nbytes(X, Xb))
+            self._emit(self.fwd, "crd_f32_to_bf16_rows", [X.t, Cs, Xb.t, Cs, 0, B * N, Cs, None, 1, None, 0, 0], io=nbytes(X, Xb))
             enc_out_b.append(Xb)
             d_enc_out.append(DX)
             src = Xb
@@ -1086,7 +1015,7 @@ class Plan:
         return run
 
     # ------------------------------------------------------------------ encoder block
-    def block(self, name, X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc, pre=None, want_next=False, dh_prev=None, persist=None):
+    def block(self, name, X, DX, Cs, heads, ratio, sr, Hs, Ws, bi, sc, pre=None, want_next=False, dh_prev=None):
         """Block.forward (simplified_attention.py:141-145) with the rank-one form of the max-pool attention
         (SURVEY.md Q2 / Appendix B3).  X: fp32 residual stream in; returns the fp32 stream out.  DX is the stage's
         running fp32 gradient buffer (the same buffer flows through every block of the stage).
@@ -1099,12 +1028,6 @@ class Plan:
         a, ml = name + ".attn", name + ".mlp1"
         dp = self.dp_masks[bi] if self.training else None
         M = (Hs // sr) * (Ws // sr)
-        # persist: the stage's forward is ONE crd_enc_stage_fwd launch (recorded by the caller); this method still allocates
-        # every buffer and records the backward ops, its forward ops go to a list that is dropped, and it appends the block's
-        # descriptor (parameters + the tensors the backward reads) to `persist`
-        fwd_real = self.fwd
-        if persist is not None:
-            self.fwd = []
         F_ = self.fwd
         n_fwd0 = len(F_)
         # ---- attention branch ----
@@ -1183,7 +1106,7 @@ class Plan:
         dw_args = [H1.t, B, Hs, Ws, hid, w9, self.p(ml + ".dwconv.dwconv.bias"), 0, H2.t, sth2] + n1 + [None, None, None, None]
         fc2_spec = self.conv_desc(H3, c2, Cs, 1, 1, 0, Hs, Ws, X2, bias=c2.bias, res=X1, res_scale=dp,
                                   stats=nxt[0] if nxt else None, chan=nxt[1] if nxt else None)
-        slabs = int(self.lib.crd_mlp_fused_supported(Hs, Ws, Cs, hid)) if (MLP_FUSED and N <= MLP_FUSED_MAXPIX and persist is None) else 0
+        slabs = int(self.lib.crd_mlp_fused_supported(Hs, Ws, Cs, hid)) if (MLP_FUSED and N <= MLP_FUSED_MAXPIX) else 0
         if slabs > 0:
             # the whole Mlp per (sample, 64-channel hidden slab) in one launch, its fc2 partial tiles folded (with bias, DropPath
             # scale, residual and the next block's norm1 sums) by a second one
@@ -1228,30 +1151,6 @@ class Plan:
         self.block_ops[name] = dict(ops=list(F_[n_fwd0:]), x=X, x2=X2, st1=st1, ch1=ch1, own_stats=pre is None)
         self.enc_taps[name] = dict(st1=st1, ch1=ch1, xn=XN, q=Q, k=K, ssum=Ssum, idx=idx, xbar=xbar, u=U, x1=X1, st2=st2, xn2=XN2, h1=H1,
                                    sth1=sth1, h2=H2, sth2=sth2, h3=H3, x2=X2, **(dict(kr=KR, stk=stk, krn=KRN) if sr > 1 else {}))
-        if persist is not None:
-            self.fwd = fwd_real
-            sv = (lambda v: v) if tr else (lambda v: None)          # saved for the backward pass / the weight gradients only
-            # the block's fp32 vectors packed back to back (include/camradepth_hip.h: crd_enc_block_desc.vec) and the depthwise
-            # taps in bf16: extra entries of the weight-pack table, refreshed with the other packed forms
-            vec = self.new((11 * Cs + 6 * hid,), F32)
-            w9b = self.new((9, hid), BF16)
-            names_c = [name + ".norm1.weight", name + ".norm1.bias", a + ".q.bias", a + ".sr.bias", a + ".norm.weight", a + ".norm.bias",
-                       a + ".k.bias", a + ".proj.bias", name + ".norm2.weight", name + ".norm2.bias", ml + ".fc2.bias"]
-            names_h = [ml + ".fc1.bias", ml + ".norm1.weight", ml + ".norm1.bias", ml + ".dwconv.dwconv.bias", ml + ".norm2.weight",
-                       ml + ".norm2.bias"]
-            for i, pn in enumerate(names_c):
-                if self.model.has_param(pn):
-                    self.vec_entries.append((pn, Cs, vec[i * Cs:(i + 1) * Cs]))
-            for i, pn in enumerate(names_h):
-                self.vec_entries.append((pn, hid, vec[11 * Cs + i * hid:11 * Cs + (i + 1) * hid]))
-            self.dw_entries.append((ml + ".dwconv.dwconv", hid, w9b, 0))          # bf16 [9][hid]
-            for cw_ in (cq, ck, c1, c2) + ((csr,) if sr > 1 else ()):
-                cw_.want_frag = True
-            persist.append(dict(
-                cq=cq, csr=csr if sr > 1 else None, ck=ck, cp=cp, c1=c1, c2=c2, w9b=w9b, vec=vec, dp=dp,
-                st1=sv(st1), ch1=sv(ch1), xn=sv(XN), q=sv(Q), kr=sv(KR) if sr > 1 else None, stk=sv(stk) if sr > 1 else None,
-                krn=sv(KRN) if sr > 1 else None, k=sv(K), ssum=sv(Ssum), idx=sv(idx), xbar=sv(xbar), u=sv(U), x1=sv(X1), st2=sv(st2),
-                xn2=sv(XN2), h1=H1, sth1=sv(sth1), h2=sv(H2), sth2=sv(sth2), h3=sv(H3), x2=X2 if (tr or not want_next) else None))
         # ---- backward (executed after the later blocks'; DX holds d(X2) on entry, d(X) on exit) ----
         g = []
         gen = ("blk", bi)
@@ -1421,12 +1320,6 @@ class Plan:
             e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = 1, hid, 9, hid, 8, fmt
             entries.append(e)
             pack_elems.append(9 * hid)
-        for (pn, n, dst) in self.vec_entries:                 # plain fp32 copies into the persistent stages' packed vectors
-            e = L.PackEntry()
-            e.src, e.dst_fwd = self.p(pn).data_ptr(), dst.data_ptr()
-            e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = 1, n, 1, n, 8, 1
-            entries.append(e)
-            pack_elems.append(n)
         # Sorted by the parameter's position in the model's flat buffer, so that the entries of a gradient bucket (a contiguous
         # range of that buffer, trainer.GradSync) are a contiguous range of the table: pack(lo, hi) re-packs one bucket right
         # behind its optimizer slice instead of everything at the head of the next step's forward (169 us on the critical path).
@@ -1438,19 +1331,6 @@ class Plan:
         self.pack_table = _struct_table(entries, dev)
         self.pack_stride = C.sizeof(L.PackEntry)
         self.n_pack = len(entries)
-        # fragment-ordered copies (persistent encoder stages), a table sorted like the pack table so that pack(lo, hi) refreshes a bucket
-        fr = sorted((cw for cw in self.convs if cw.want_frag), key=lambda cw: self.p(cw.name + ".weight").data_ptr())
-        fents = []
-        for cw in fr:
-            cw.w_frag = self.new((cw.cout * cw.taps * cw.cin_pad,), BF16)
-            fe = L.FragEntry()
-            fe.src, fe.dst, fe.N, fe.K = cw.w_fwd.data_ptr(), cw.w_frag.data_ptr(), cw.cout, cw.taps * cw.cin_pad
-            assert fe.N % 32 == 0 and fe.K % 16 == 0
-            fents.append(fe)
-        self.frag_offs = [(self.p(cw.name + ".weight").data_ptr() - base) // 4 for cw in fr]
-        self.frag_elems = [cw.cout * cw.taps * cw.cin_pad for cw in fr]
-        self.frag_table = _struct_table(fents, dev) if fents else None
-        self.frag_stride = C.sizeof(L.FragEntry)
         self.packed_version = None          # model._param_version the packed weights correspond to (None: never packed)
         # zero arenas
         self.zf_arena = self._materialise(self._zf_views)
@@ -1610,16 +1490,6 @@ class Plan:
             ev.record(self._side_streams[sid - 1])
             main.wait_event(ev)
 
-    def check_enc_status(self):
-        """Persistent encoder stages (developer path): a workgroup that gave up waiting for its peers (3 s: they were not all
-        resident) sets the launch's status word and the activations behind it are garbage -- raise instead of carrying on
-        (ADVICE r4).  Synchronises; called where the host reads results anyway (TrainStep.losses, InferenceGraph.run, eager forward)."""
-        for st in self.enc_status:
-            if int(st.item()) != 0:
-                st.zero_()
-                raise L.CrdError("crd_enc_stage_fwd: a workgroup timed out waiting for its sample's other workgroups (not all "
-                                 "resident on the device?); the stage's outputs are invalid")
-
     def pack(self, lo=None, hi=None):
         """fp32 parameters -> the bf16 (and e4m3) operand layouts of the kernels, on the current stream: all of them, or those
         whose parameter lies in elements [lo, hi) of the model's flat buffer (one optimizer bucket)."""
@@ -1629,12 +1499,6 @@ class Plan:
         if i1 > i0:
             L.check(self.lib.crd_weight_pack(self.pack_table.data_ptr() + i0 * self.pack_stride, i1 - i0,
                                              max(self.pack_elems[i0:i1]), st), "crd_weight_pack")
-        if self.frag_table is not None:
-            j0 = 0 if lo is None else bisect.bisect_left(self.frag_offs, lo)
-            j1 = len(self.frag_offs) if hi is None else bisect.bisect_left(self.frag_offs, hi)
-            if j1 > j0:
-                L.check(self.lib.crd_pack_frag32(self.frag_table.data_ptr() + j0 * self.frag_stride, j1 - j0,
-                                                 max(self.frag_elems[j0:j1]), st), "crd_pack_frag32")
         base = self.model.flat.data_ptr()
         for cw, cin16 in self.fp8_convs:
             off = (self.p(cw.name + ".weight").data_ptr() - base) // 4

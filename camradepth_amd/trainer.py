@@ -456,8 +456,6 @@ class TrainStep:
     def losses(self):
         """Host view of the last iteration's loss terms (synchronises)."""
         a = L.stat_value(self.acc.cpu())
-        if self.plan.enc_status:               # (developer path, CRD_ENC_PERSIST)
-            self.plan.check_enc_status()
         if L.nonfinite():
             # a NaN / infinite / out-of-range partial was dropped from a fixed-point sum since the last check (include/camradepth_hip.h:
             # crd_nonfinite_status): the sums are not what the reference would have computed -- it reports NaN here, so do we

@@ -49,11 +49,13 @@ typedef int64_t crd_sum_t;
 /* NaN, infinity and magnitudes outside the range cannot be represented in a crd_sum_t.  A partial sum that is not finite, or
  * whose scaled magnitude reaches 2^62, adds NOTHING to its accumulator and raises a sticky device-side flag instead (a run
  * that has diverged would otherwise report a finite, too-small loss where the reference reports NaN, and bias / GroupNorm
- * gradients of 0 next to NaN weight gradients).  crd_nonfinite_status(reset) synchronises with the device, returns 1 if any
- * such partial was dropped since the flag was last cleared (0 if none, negative on error) and clears it when reset != 0.
+ * gradients of 0 next to NaN weight gradients).  crd_nonfinite_status(reset, stream) runs its query ON `stream` -- behind every
+ * kernel the caller enqueued there -- and waits for that stream; returns 1 if any such partial was dropped since the flag was last
+ * cleared (0 if none, negative on error) and clears it when reset != 0.  reset == 2: clear only -- enqueued on `stream`, nothing is read
+ * back, no wait, returns 0 (the eager model forward opens a step with it).  (Work on OTHER streams is ordered by the caller.)
  * TrainStep.losses(), the loss modules and camradepth_amd.lib.stat_checked() report NaN when it is set.  Sums whose TOTAL
  * leaves the range while every partial stays inside it still wrap (|statistic sum| > 8.8e12, |gradient sum| > 5.2e5). */
-int crd_nonfinite_status(int32_t reset);
+int crd_nonfinite_status(int32_t reset, crd_stream_t stream);
 
 const char* crd_last_error(void);
 int crd_version(void);          /* ABI version, currently 1 */
@@ -133,6 +135,25 @@ typedef struct {
   void* xn;                 /* optional bf16 output */
 } crd_gn_input;
 int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stream);
+/* Backward twin of crd_gn_conv (round 6): the APPLY phase of a GroupNorm (+ exact GELU) backward folded into the A-operand load of
+ * the pointwise data-gradient GEMM that consumes the gradient (csrc/xfgemm.hip).  d->x holds dy of the GroupNorm (bf16
+ * [B][P][x_ld] + x_coff, Cin = the GroupNorm's channels); the GEMM multiplies d->w with
+ *   dx = (gamma * g - S1 - xhat * S2) * rstd,  g = dy * mask * act'(xhat * gamma + beta)
+ * -- what crd_gn_bwd_apply(x = gx, dy, stats, r) stores -- and the descriptor's epilogue options apply to the product (bias,
+ * accumulate, out_mode = 1 patch scatter, stats, the fused reduce red_*).  Replaces crd_gn_bwd_apply + crd_conv_igemm in the backward
+ * chain of an encoder Block: Mlp.norm1 in front of fc1's data gradient, attn.norm in front of the sr patch scatter (the autograd of
+ * src/models/simplified_attention.py:38-41,96-100).  KH = KW = stride = 1, pad 0; bf16 output. */
+typedef struct {
+  const void* gx; int32_t gx_f32, gx_ld;   /* the GroupNorm's INPUT [B][P][gx_ld] from channel 0, bf16 or fp32 */
+  int32_t gmul, act;                       /* group = gmul 16-channel slabs; act = 1: exact GELU behind the GroupNorm */
+  const crd_sum_t* stats;                  /* forward slab sums of gx [B][Cin/16][2] */
+  const float* gamma; const float* beta;   /* [Cin] */
+  const float* mask;                       /* Dropout2d mask [B][Cin] or NULL */
+  const crd_sum_t* r;                      /* crd_gn_bwd_reduce's sums: [B][Cin][2] then [B][Cin/(16 gmul)][2] */
+  void* dx; int32_t dx_ld;                 /* optional: dx stored as bf16 [B][P][dx_ld] (what the weight gradients read), or NULL */
+  float* dgamma; float* dbeta;             /* optional (both or neither): += the GroupNorm's parameter gradients */
+} crd_gn_bwd_input;
+int crd_gn_bwd_conv(const crd_conv_desc* d, const crd_gn_bwd_input* n, crd_stream_t stream);
 /* 1 when crd_conv_igemm / crd_gn_conv send a 1x1 layer of this shape (input channels, output channels, pixels per sample) to the
  * narrow streaming kernel (round 5, csrc/pw_narrow.hip: Mlp.fc2 and the data gradient of Mlp.fc1 at encoder stages 1-2,
  * simplified_attention.py:17,20,35,41 -- hidden 512 / 1024 -> 64 / 128 channels): the weights of a workgroup's 16-column
@@ -577,74 +598,6 @@ int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, float* exp_a
                           const int32_t* blk2seg, const int32_t* blk2chunk, int32_t n_tensors, int32_t n_blocks,
                           const uint8_t* active, float lr, float beta1, float beta2, float eps, float weight_decay,
                           int32_t step, const float* hp_dev, crd_stream_t stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Persistent encoder stage (round 4): ALL Blocks of one SimplifiedTransformer stage in ONE launch
- * (Block.forward simplified_attention.py:141-145; Attention_MaxPool :90-109; Mlp :34-43; DWConv :318-323; the stage loop
- * of forward_features :265-306).  The per-launch path runs a Block as ~9 dependent launches of 5-14 us for a few MFLOP
- * each (34 blocks: 65 % of the step's dependency chain for 10 % of its FLOPs).  Here a sample is owned by G = H/2
- * workgroups, each holding TWO image rows of the [B][H*W][C] stage tensor in LDS for the whole launch: the fp32 residual
- * stream, the normalised operands, q, the hidden tensor of the Mlp.  Every GEMM (q, sr, k, fc1, fc2), the max-pool
- * attention, both GroupNorms of the Mlp, the 3x3 depthwise stencil and the exact GELU run out of LDS; weights stream from
- * L2.  GroupNorm and attention are per sample, so the only traffic between workgroups is what a sample's G workgroups owe
- * each other: per-group partial sums (five small all-gathers per Block), the reduced keys, and the two neighbour rows of
- * the depthwise stencil.  Those go through 8-byte {value, tag} granules written with agent-scope (sc1) stores and polled with
- * agent-scope loads -- no fences, no atomics, no dependence on dispatch order or workgroup -> XCD placement (block b lands on
- * XCD b % 8 in practice, which keeps a sample's traffic inside one L2: speed only).  All sums are taken in a fixed order:
- * results are bit-reproducible.  Arithmetic and rounding points are those of the per-launch kernels (bf16 GEMM operands and
- * results, fp32 accumulation / GroupNorm / residual, fixed-point statistics).
- * Saved tensors (everything the backward pass and the weight gradients read) are written when their pointer is non-NULL. */
-typedef struct {
-  /* parameters: the packed bf16 forward forms [Cout][taps * Cin] of crd_weight_pack, re-ordered by crd_pack_frag32 (wp: as packed) */
-  const void* wq; const void* wsr; const void* wk; const void* wp;   /* attn.q / .sr (sr > 1) / .k / .proj */
-  const void* w1; const void* w2;                                     /* Mlp.fc1 [hidden][C], Mlp.fc2 [C][hidden] */
-  const void* w9b;                                                    /* depthwise taps, bf16 [9][hidden] */
-  /* the block's fp32 vectors packed back to back (crd_weight_pack entries with dst_f32 = 1):
-   * [norm1.weight | norm1.bias | q.bias | sr.bias | attn.norm.weight | attn.norm.bias | k.bias | proj.bias | norm2.weight |
-   *  norm2.bias | fc2.bias] (C each), then [fc1.bias | Mlp.norm1.weight | .bias | dwconv.bias | Mlp.norm2.weight | .bias]
-   * (hidden each); sr / attn.norm slots are unused when sr == 1 */
-  const float* vec;
-  const float* dp;                                 /* DropPath scale per sample [B], or NULL */
-  /* what the launch requests into L2 while the PREVIOUS block runs (this block's weights and vectors; NULL entries are skipped) */
-  const void* pf_ptr[8];
-  int32_t pf_bytes[8];
-  /* outputs; [B][H*W][..] pixel-major.  h1 and x2 are always written (h1 carries the stencil's neighbour rows between
-   * workgroups; x2 is the block's result), the others only when non-NULL */
-  crd_sum_t* st1; crd_sum_t* ch1;                  /* sums of the block input: [B][C/16][2], [B][C][2] */
-  void* xn; void* q;                               /* bf16 [B][N][C]: norm1(x), q */
-  void* kr; crd_sum_t* stk; void* krn;             /* sr > 1: bf16 [B][M][C] sr output, its sums [B][C/16][2], attn.norm output */
-  void* k;                                         /* bf16 [B][M][C] */
-  float* ssum; int16_t* idx;                       /* [B][N], [B][N][heads] */
-  void* xbar; float* u;                            /* bf16 [B][C], fp32 [B][C] */
-  float* x1; crd_sum_t* st2; void* xn2;            /* fp32 [B][N][C], sums, bf16 norm2(x1) */
-  void* h1; crd_sum_t* sth1; void* h2; crd_sum_t* sth2; void* h3;   /* bf16 [B][N][hidden] x3, sums [B][hidden/16][2] x2 */
-  float* x2;                                       /* fp32 [B][N][C] */
-} crd_enc_block_desc;
-typedef struct {
-  const float* x;                       /* stage input (patch-embed output after its GroupNorm), fp32 [B][H*W][C] */
-  const crd_enc_block_desc* blocks;     /* DEVICE array of nblocks descriptors */
-  int32_t nblocks, B, H, W, C, hidden, heads, sr;
-  void* xb_out;                         /* optional bf16 copy of the last block's x2 */
-  void* sync_ws;                        /* crd_enc_stage_ws_bytes() bytes, zeroed ONCE by the caller (never again: tags carry an epoch) */
-  int32_t* status;                      /* device word, zeroed by the caller; set non-zero if a workgroup gave up waiting */
-  int32_t rows_per_wg;                  /* image rows per workgroup: 1, 2, or 0 = choose (1 while B * H <= 256: a workgroup per CU) */
-} crd_enc_stage_desc;
-/* workgroups per sample (> 0) when the persistent kernel covers the shape, else 0: (C, hidden, heads, sr) = (160, 640, 4, 2)
- * with W <= 26, or (256, 1024, 8, 1) with W <= 13; H even, H*W/sr^2 <= 104, W % sr == 0 */
-/* Weights of the persistent stage's GEMMs in MFMA-fragment order: for a bf16 matrix [N][K] (N % 32 == 0, K % 16 == 0; the packed
- * forward form of crd_weight_pack) dst holds, for every (32-row tile, 16-wide k-step), the 64 lanes' 16-byte A operands of
- * v_mfma_f32_32x32x16_bf16 back to back: granule ((tile * K/16 + kstep) * 64 + lane) = src[tile*32 + (lane & 31)][kstep*16 +
- * (lane >> 5)*8 .. +8] -- one contiguous kilobyte per wave load instead of 32 rows x 32 bytes.  Table-driven, one launch. */
-typedef struct {
-  const void* src;   /* bf16 [N][K] */
-  void* dst;         /* bf16, N * K elements */
-  int32_t N, K;
-} crd_frag_entry;
-int crd_pack_frag32(const crd_frag_entry* table_dev, int32_t n, int64_t max_elems, crd_stream_t stream);
-int crd_enc_stage_supported(int32_t B, int32_t H, int32_t W, int32_t C, int32_t hidden, int32_t heads, int32_t sr);
-/* bytes of sync_ws for that shape (0 when unsupported) */
-int crd_enc_stage_ws_bytes(int32_t B, int32_t H, int32_t W, int32_t C, int32_t hidden, int32_t heads, int32_t sr);
-int crd_enc_stage_fwd(const crd_enc_stage_desc* d, crd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -64,12 +64,11 @@ def test_struct_layouts_match_header(built, tmp_path):
     import subprocess
     fields = {"crd_conv_desc": (built.ConvDesc, ["x", "w", "OH", "y", "bias", "res", "res_scale", "stats", "red_x", "red_act", "red_stats", "red_r"]),
               "crd_gn_input": (built.GnInput, ["x_f32", "gmul", "stats", "gamma", "beta", "act", "xn_ld", "xn"]),
+              "crd_gn_bwd_input": (built.GnBwdInput, ["gx", "gx_f32", "gx_ld", "gmul", "act", "stats", "mask", "r", "dx", "dx_ld", "dgamma", "dbeta"]),
               "crd_wgrad_desc": (built.WgradDesc, ["x", "dy", "Cout", "dw", "dbias", "dw_partials", "dw_partial_capacity", "wg_budget"]),
               "crd_pack_entry": (built.PackEntry, ["src", "cmap", "Cout", "dst_f32"]),
               "crd_unpack_entry": (built.UnpackEntry, ["src", "cmap", "Cin_pad", "replicas", "replica_stride"]),
-              "crd_wgrad_group_info": (built.WgradGroupInfo, ["n_problems", "n_items", "item_offset", "bytes"]),
-              "crd_enc_block_desc": (built.EncBlockDesc, ["wq", "w9b", "vec", "dp", "pf_ptr", "pf_bytes", "st1", "krn", "idx", "h1", "x2"]),
-              "crd_enc_stage_desc": (built.EncStageDesc, ["x", "blocks", "nblocks", "sr", "xb_out", "sync_ws", "status", "rows_per_wg"])}
+              "crd_wgrad_group_info": (built.WgradGroupInfo, ["n_problems", "n_items", "item_offset", "bytes"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/camradepth_hip.h"', "int main(void){"]
     for cname, (_, fl) in fields.items():
         src.append(f'printf("{cname} %zu", sizeof({cname}));')
@@ -122,15 +121,6 @@ def test_module_parameter_inventory_and_flat_views():
         CamRaDepth(heads=(1, 2, 4), input_channels=7)
 
 
-def test_persistent_stage_host_checks_without_a_gpu(built):
-    """crd_enc_stage_supported / _ws_bytes are host-only; crd_enc_stage_fwd rejects unsupported shapes before any launch."""
+def test_status_query_without_a_gpu(built):
     L = built.load()
-    # workgroups per sample: one image row each while B x H <= the device's compute units (a workgroup per CU), else two rows each.
-    # Round 5 (ADVICE r4): the grid is sized from hipDeviceAttributeMultiprocessorCount, so WITHOUT a device nothing is supported
-    # (tests/test_gpu_enc_stage.py checks the counts on the MI355X); unsupported shapes are 0 either way.
-    assert L.crd_enc_stage_supported(8, 16, 26, 160, 640, 4, 2) in (0, 16) and L.crd_enc_stage_supported(8, 8, 13, 256, 1024, 8, 1) in (0, 8)
-    assert L.crd_enc_stage_supported(8, 32, 52, 128, 1024, 2, 4) == 0 and L.crd_enc_stage_supported(8, 13, 25, 256, 1024, 8, 1) == 0
-    assert L.crd_enc_stage_ws_bytes(8, 16, 26, 160, 640, 4, 2) > 0 and L.crd_enc_stage_ws_bytes(8, 13, 25, 256, 1024, 8, 1) == 0
-    d = built.EncStageDesc()
-    assert L.crd_enc_stage_fwd(ctypes.byref(d), None) == -1
-    assert L.crd_nonfinite_status(0) in (0, -3)          # no device here: either "nothing flagged" or a reported HIP error, never a crash
+    assert L.crd_nonfinite_status(0, None) in (0, -3)          # no device here: either "nothing flagged" or a reported HIP error, never a crash

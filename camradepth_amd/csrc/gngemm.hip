@@ -113,16 +113,28 @@ __global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot * 2, 0x00020000);
   const int nK = (a.Ktot + BK - 1) / BK;
   const bool store_xn = gi.xn != nullptr && blockIdx.y == 0;
+  // the stored copy of the normalised operand goes through a buffer descriptor: rows / granules that are not stored carry an
+  // out-of-range offset and the hardware drops them, so the store is UNCONDITIONAL (round 6: under `if (store_xn && ok)` the compiler
+  // could no longer count the requests in flight and drained the two-slab prefetch at every use -- see the K loop below)
+  const __amdgpu_buffer_rsrc_t rxn = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(store_xn ? gi.xn + (long long)b * gi.xn_bstride : reinterpret_cast<bf16_t*>(const_cast<bf16_t*>(a.w))), 0,
+      store_xn ? (int)(gi.xn_bstride * 2) : 0, 0x00020000);
 
-  // per-row constants: pixel index of the row's patch origin, validity
+  // per-row constants: pixel index of the row's patch origin, validity; and the loop-invariant BYTE offsets of that origin in x / xn
+  // with the validity folded in (an invalid row starts out of range and stays there whatever the K loop adds): every load and store of
+  // the K loop is unconditional.  As `ok ? computed : OOB` inside the loop the compiler sank the multiply into an exec-mask branch
+  // around the load (two loads into the same registers on two paths, each behind a vmcnt(0)) in the bf16-input variants.
   int rowpix[A_IT];
   bool rowok[A_IT];
+  unsigned rowoff[A_IT], xnoff[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
     const int m = m0 + r0 + 32 * i;
     const int oy = m / a.OW, ox = m - oy * a.OW;
     rowok[i] = m < a.OHW;
     rowpix[i] = oy * a.stride * a.IW + ox * a.stride;
+    rowoff[i] = rowok[i] ? (unsigned)(rowpix[i] * a.x_ld * esz) : OOB;
+    xnoff[i] = (rowok[i] && store_xn) ? (unsigned)(rowpix[i] * gi.xn_ld * 2) : OOB;
   }
   unsigned woff[B_IT];
 #pragma unroll
@@ -140,15 +152,17 @@ __global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
   auto load_slab = [&](int kt, Regs& r) {
     int kc, tappix; bool kok;
     kpos(kt, kc, tappix, kok);
+    const unsigned km = kok ? 0u : OOB;                  // K tail / slabs past the end: out of range as well
+    const unsigned add = (unsigned)((tappix * a.x_ld + kc) * esz);
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const unsigned off = (kok && rowok[i]) ? (unsigned)(((rowpix[i] + tappix) * a.x_ld + kc) * esz) : OOB;
+      const unsigned off = (rowoff[i] + add) | km;
       r.a[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
-      if (XF32) r.a[i][XF32 ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b128(rx, off == OOB ? OOB : off + 16, 0, 0);
+      if (XF32) r.a[i][XF32 ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b128(rx, off + 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j)
-      r.w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (kok && woff[j] != OOB) ? woff[j] + (unsigned)((kt * BK + g * 8) * 2) : OOB, 0, 0);
+      r.w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (woff[j] + (unsigned)((kt * BK + g * 8) * 2)) | km, 0, 0);
   };
   auto store_slab = [&](int kt, int stage, const Regs& r) {
     int kc, tappix; bool kok;
@@ -182,8 +196,7 @@ __global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
       }
       const u32x4r q = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3]), pack_bf2(v[4], v[5]), pack_bf2(v[6], v[7])};
       *reinterpret_cast<u32x4r*>(sA + stage * BM * BK + (r0 + 32 * i) * BK + (l & 7) * 8) = q;
-      if (store_xn && ok)
-        *reinterpret_cast<u32x4r*>(gi.xn + (long long)b * gi.xn_bstride + (long long)(rowpix[i] + tappix) * gi.xn_ld + kc) = q;
+      __builtin_amdgcn_raw_buffer_store_b128(q, rxn, (xnoff[i] + (unsigned)((tappix * gi.xn_ld + kc) * 2)) | (kok ? 0u : OOB), 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) *reinterpret_cast<u32x4r*>(sB + stage * BN * BK + (r0 + 32 * j) * BK + (l & 7) * 8) = r.w[j];
@@ -194,20 +207,31 @@ __global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
   if (!(a.dbg & 1)) build_table(a, gi, b, tab);
   Regs r0s, r1s;
   load_slab(0, r0s);
-  if (nK > 1) load_slab(1, r1s);
+  load_slab(1, r1s);                                  // (slabs past the end: every offset out of range -- zeros, no traffic)
   f32x16 acc[TM][TN];
   init_acc<TM, TN, WN>(a, acc, b, n0, wn, l);
   lds_barrier();                                      // the table
   store_slab(0, 0, r0s);
-  if (nK > 2) load_slab(2, r0s);
+  load_slab(2, r0s);
   lds_barrier();
-  for (int kt = 0; kt < nK; kt += 2) {
-    if (kt + 1 < nK) { store_slab(kt + 1, 1, r1s); if (kt + 3 < nK) load_slab(kt + 3, r1s); }
+  // Steady state, two slabs per trip and NO conditional memory operation in it (round 6).  With `if (kt + 3 < nK) load_slab(...)` --
+  // a wave-uniform branch around six loads -- the number of requests in flight depends on the path, and the compiler's wait insertion
+  // assumes the path that issued fewer: every use of a slab's registers then also drained the YOUNGER slab's requests
+  // (s_waitcnt vmcnt(5..0) in the ISA where vmcnt(12..9) was meant), i.e. the two-slab prefetch was one slab deep.  Slabs past the end
+  // carry out-of-range offsets instead (zeros in, nothing out); an odd slab count ends in a single-slab tail.
+  int kt = 0;
+  for (; kt + 2 <= nK; kt += 2) {
+    store_slab(kt + 1, 1, r1s);
+    load_slab(kt + 3, r1s);
     mfma_slab<TM, TN, WM, WN>(sA, sB, acc, wm, wn, l);
     lds_barrier();
-    if (kt + 1 >= nK) break;
-    if (kt + 2 < nK) { store_slab(kt + 2, 0, r0s); if (kt + 4 < nK) load_slab(kt + 4, r0s); }
+    store_slab(kt + 2, 0, r0s);
+    load_slab(kt + 4, r0s);
     mfma_slab<TM, TN, WM, WN>(sA + BM * BK, sB + BN * BK, acc, wm, wn, l);
+    lds_barrier();
+  }
+  if (kt < nK) {
+    mfma_slab<TM, TN, WM, WN>(sA, sB, acc, wm, wn, l);
     lds_barrier();
   }
   if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(a.y)[0] = 1.f; return; }

@@ -34,21 +34,35 @@ struct XfIn {
   float* dgamma; float* dbeta;                                      // optional parameter gradients (+=)
 };
 
-// coefficient table of sample b: t4[c] = (ca, cb, cc, za), tz[c] = zb
-__device__ __forceinline__ void build_table(const ConvK& a, const XfIn& xi, int b, f32x4* t4, float* tz) {
-  const int C = a.Cin, cpg = 16 * xi.gmul;
+// coefficient table of sample b: t4[c] = (ca, cb, cc, za), tz[c] = zb.  The per-GROUP quantities (mean, rstd from the forward sums in
+// fp64, S1, S2 from the reduce sums) are computed once per group into `grp` (LDS) -- per channel they were C / cpg times the fp64 work and a
+// dependent load chain per loop iteration at the head of every workgroup -- then a channel is two parameter loads and four FMAs.
+__device__ __forceinline__ void build_table(const ConvK& a, const XfIn& xi, int b, f32x4* t4, float* tz, f32x4* grp) {
+  const int C = a.Cin, cpg = 16 * xi.gmul, G = C / cpg;
   const crd_sum_t* stb = xi.stats + (long long)b * (C >> 4) * 2;
-  const crd_sum_t* rgb = xi.r + (long long)xi.B * C * 2 + (long long)b * (C / cpg) * 2;
+  const crd_sum_t* rgb = xi.r + (long long)xi.B * C * 2 + (long long)b * G * 2;
   const float inv_m = 1.f / xi.count;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const int grp = c / cpg;
+  // parameters of this thread's first channels requested before the group pass waits for anything
+  float ga0 = 0.f, be0 = 0.f, mk0 = 1.f;
+  if ((int)threadIdx.x < C) {
+    ga0 = xi.gamma[threadIdx.x]; be0 = xi.beta[threadIdx.x];
+    if (xi.mask) mk0 = xi.mask[(long long)b * C + threadIdx.x];
+  }
+  for (int gI = threadIdx.x; gI < G; gI += 256) {
     float mean, rstd;
-    gn_mean_rstd(stb, grp * xi.gmul, xi.gmul, xi.count, mean, rstd);
-    const float S1 = grad_get(rgb + grp * 2) * inv_m, S2 = grad_get(rgb + grp * 2 + 1) * inv_m;
-    const float ga = xi.gamma[c], mk = xi.mask ? xi.mask[(long long)b * C + c] : 1.f;
+    gn_mean_rstd(stb, gI * xi.gmul, xi.gmul, xi.count, mean, rstd);
+    grp[gI] = f32x4{mean, rstd, grad_get(rgb + gI * 2) * inv_m, grad_get(rgb + gI * 2 + 1) * inv_m};
+  }
+  lds_barrier();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const f32x4 gv = grp[c / cpg];
+    const float mean = gv[0], rstd = gv[1], S1 = gv[2], S2 = gv[3];
+    const bool first = c < 256;
+    const float ga = first ? ga0 : xi.gamma[c], be = first ? be0 : xi.beta[c];
+    const float mk = first ? mk0 : (xi.mask ? xi.mask[(long long)b * C + c] : 1.f);
     const float za = ga * rstd, q = rstd * rstd * S2;
     t4[c] = f32x4{za * mk, -q, mean * q - rstd * S1, za};
-    tz[c] = xi.beta[c] - mean * za;
+    tz[c] = be - mean * za;
   }
 }
 
@@ -87,6 +101,7 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
   bf16_t* sB = sA + 2 * BM * BK;                      // [2][BN][BK]
   f32x4* t4 = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(lds) + a.lds_bytes);   // [Cin], behind tiles / staging
   float* tz = reinterpret_cast<float*>(t4 + a.Cin);                                   // [Cin]
+  f32x4* grp = reinterpret_cast<f32x4*>(tz + a.Cin);                                  // [Cin / 16] at most
 
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -101,15 +116,25 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       (void*)(reinterpret_cast<const char*>(xi.gx) + (long long)b * xi.gx_bstride * esz), 0, (int)(xi.gx_bstride * esz), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(xi.dx ? xi.dx + (long long)b * xi.dx_bstride : reinterpret_cast<bf16_t*>(const_cast<void*>(xi.gx))), 0,
+      xi.dx ? (int)(xi.dx_bstride * 2) : 0, 0x00020000);
   const int nK = (a.Ktot + BK - 1) / BK;
   const bool store_dx = xi.dx != nullptr && blockIdx.y == 0;
 
-  bool rowok[A_IT];
-  int rowpix[A_IT];
+  // Loop-invariant BYTE offsets of this thread's rows in dy / x / dx, with the row's validity folded in (an invalid row starts at the
+  // out-of-range offset, and stays out of range whatever is added): every load and store of the K loop is then UNCONDITIONAL.  Written
+  // as `ok ? computed : OOB` inside the loop the compiler sank the multiply into a branch around the load -- two loads into the same
+  // registers on two exec-mask paths -- and, no longer able to count what was in flight, waited vmcnt(0) in front of every use: the
+  // two-slab prefetch was one slab deep (ISA of the first build; the conditional xn stores of k_gngemm_reg had the same effect).
+  unsigned dyoff[A_IT], gxoff[A_IT], dxoff[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    rowpix[i] = m0 + r0 + 32 * i;
-    rowok[i] = rowpix[i] < a.OHW;
+    const int m = m0 + r0 + 32 * i;
+    const bool ok = m < a.OHW;
+    dyoff[i] = ok ? (unsigned)(m * a.x_ld * 2) : OOB;
+    gxoff[i] = ok ? (unsigned)(m * xi.gx_ld * esz) : OOB;
+    dxoff[i] = (ok && store_dx) ? (unsigned)(m * xi.dx_ld * 2) : OOB;
   }
   unsigned woff[B_IT];
 #pragma unroll
@@ -120,34 +145,29 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
   struct Regs { u32x4r d[A_IT]; u32x4r x[A_IT][GXF32 ? 2 : 1]; u32x4r w[B_IT]; };
   auto load_slab = [&](int kt, Regs& r) {
     const int kc = kt * BK + g * 8;
-    const bool kok = kc < a.Ktot;
+    const unsigned km = kc < a.Ktot ? 0u : OOB;          // K tail: out of range as well
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
-      const bool ok = kok && rowok[i];
-      r.d[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, ok ? (unsigned)((rowpix[i] * a.x_ld + kc) * 2) : OOB, 0, 0);
-      const unsigned xo = ok ? (unsigned)((rowpix[i] * xi.gx_ld + kc) * esz) : OOB;
+      r.d[i] = __builtin_amdgcn_raw_buffer_load_b128(rd, (dyoff[i] + (unsigned)(kc * 2)) | km, 0, 0);
+      const unsigned xo = (gxoff[i] + (unsigned)(kc * esz)) | km;
       r.x[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo, 0, 0);
-      if (GXF32) r.x[i][GXF32 ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo == OOB ? OOB : xo + 16, 0, 0);
+      if (GXF32) r.x[i][GXF32 ? 1 : 0] = __builtin_amdgcn_raw_buffer_load_b128(rx, xo + 16, 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j)
-      r.w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (kok && woff[j] != OOB) ? woff[j] + (unsigned)(kc * 2) : OOB, 0, 0);
+      r.w[j] = __builtin_amdgcn_raw_buffer_load_b128(rw, (woff[j] + (unsigned)(kc * 2)) | km, 0, 0);
   };
   auto store_slab = [&](int kt, int stage, const Regs& r) {
     const int kc = kt * BK + g * 8;
     const bool kok = kc < a.Ktot;
+    const int kt_ = kok ? kc : 0;                      // (table reads stay inside the table on the K tail; the values are masked below)
     float ca[8], cb[8], cc[8], za[8], zb[8];
-    if (kok) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const f32x4 v = t4[kc + j]; ca[j] = v[0]; cb[j] = v[1]; cc[j] = v[2]; za[j] = v[3]; }
-      if (ACT == 1) {
-        const f32x4 z0 = *reinterpret_cast<const f32x4*>(tz + kc), z1 = *reinterpret_cast<const f32x4*>(tz + kc + 4);
+    for (int j = 0; j < 8; ++j) { const f32x4 v = t4[kt_ + j]; ca[j] = v[0]; cb[j] = v[1]; cc[j] = v[2]; za[j] = v[3]; }
+    if (ACT == 1) {
+      const f32x4 z0 = *reinterpret_cast<const f32x4*>(tz + kt_), z1 = *reinterpret_cast<const f32x4*>(tz + kt_ + 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { zb[j] = z0[j]; zb[4 + j] = z1[j]; }
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ca[j] = cb[j] = cc[j] = za[j] = zb[j] = 0.f;
+      for (int j = 0; j < 4; ++j) { zb[j] = z0[j]; zb[4 + j] = z1[j]; }
     }
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -161,7 +181,7 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) { xv[2 * j] = bf_lo(r.x[i][0][j]); xv[2 * j + 1] = bf_hi(r.x[i][0][j]); }
       }
-      const bool ok = kok && rowok[i];
+      const bool ok = kok && dyoff[i] != OOB;            // (out-of-range loads returned zeros; the constant term cc must go as well)
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         float gq = dv[j];
@@ -171,18 +191,18 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
       }
       const u32x4r q = {pack_bf2(o[0], o[1]), pack_bf2(o[2], o[3]), pack_bf2(o[4], o[5]), pack_bf2(o[6], o[7])};
       *reinterpret_cast<u32x4r*>(sA + stage * BM * BK + (r0 + 32 * i) * BK + (l & 7) * 8) = q;
-      if (store_dx && ok)
-        *reinterpret_cast<u32x4r*>(xi.dx + (long long)b * xi.dx_bstride + (long long)rowpix[i] * xi.dx_ld + kc) = q;
+      // unconditional: rows / K granules that are not stored carry the out-of-range offset and the hardware drops them
+      __builtin_amdgcn_raw_buffer_store_b128(q, rdx, (dxoff[i] + (unsigned)(kc * 2)) | (kok ? 0u : OOB), 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < B_IT; ++j) *reinterpret_cast<u32x4r*>(sB + stage * BN * BK + (r0 + 32 * j) * BK + (l & 7) * 8) = r.w[j];
   };
 
   // everything the first two K-steps need is requested before anything is waited for: the table's inputs first, then slabs 0 and 1
-  build_table(a, xi, b, t4, tz);
+  build_table(a, xi, b, t4, tz, grp);
   Regs r0s, r1s;
   load_slab(0, r0s);
-  if (nK > 1) load_slab(1, r1s);
+  load_slab(1, r1s);                                  // (slabs past the end: every offset out of range -- zeros, no traffic)
   // the GroupNorm's parameter gradients: the workgroups of sample 0 / column tile 0 share the channels (crd_gn_bwd_apply's rule)
   if (b == 0 && blockIdx.y == 0 && xi.dgamma) {
     for (int c = blockIdx.x * 256 + t; c < a.Cin; c += gridDim.x * 256) {
@@ -203,15 +223,26 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
   }
   lds_barrier();                                      // the table
   store_slab(0, 0, r0s);
-  if (nK > 2) load_slab(2, r0s);
+  load_slab(2, r0s);
   lds_barrier();
-  for (int kt = 0; kt < nK; kt += 2) {
-    if (kt + 1 < nK) { store_slab(kt + 1, 1, r1s); if (kt + 3 < nK) load_slab(kt + 3, r1s); }
+  // Steady state, two slabs per trip, NO conditional memory operation inside: a load or store under `if (kt + 3 < nK)` -- even a
+  // wave-uniform one -- makes the number of requests in flight path-dependent, and the compiler then waits as if the skipped path had
+  // been taken: every use drained the younger slab's requests as well (vmcnt(3..0) where vmcnt(8) was meant).  Slabs past the end carry
+  // out-of-range offsets instead (zeros in, nothing out), an odd slab count ends in a single-slab tail.  (Four slabs in flight were
+  // tried: 256 registers or 36-92 spilled, one workgroup per CU -- not kept.)
+  int kt = 0;
+  for (; kt + 2 <= nK; kt += 2) {
+    store_slab(kt + 1, 1, r1s);
+    load_slab(kt + 3, r1s);
     mfma_slab<TN>(sA, sB, acc, wm, wn, l);
     lds_barrier();
-    if (kt + 1 >= nK) break;
-    if (kt + 2 < nK) { store_slab(kt + 2, 0, r0s); if (kt + 4 < nK) load_slab(kt + 4, r0s); }
+    store_slab(kt + 2, 0, r0s);
+    load_slab(kt + 4, r0s);
     mfma_slab<TN>(sA + BM * BK, sB + BN * BK, acc, wm, wn, l);
+    lds_barrier();
+  }
+  if (kt < nK) {
+    mfma_slab<TN>(sA, sB, acc, wm, wn, l);
     lds_barrier();
   }
   conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
@@ -227,7 +258,7 @@ int launch(const ConvK& k0, const XfIn& xi, int B, hipStream_t st) {
   size_t tiles = (size_t)2 * (BM + BN) * BK * 2;
   if (tiles < epilogue_bytes<BM, BN>()) tiles = epilogue_bytes<BM, BN>();
   tiles = (tiles + 255) / 256 * 256;
-  const size_t lds = tiles + (size_t)k.Cin * 20;
+  const size_t lds = tiles + (size_t)k.Cin * 20 + (size_t)(k.Cin / 16) * 16;
   CRD_UNSUPPORTED(lds <= 160 * 1024, "crd_gn_bwd_conv: coefficient table does not fit in LDS");
   static bool attr_done = false;
   if (!attr_done) {

@@ -161,6 +161,11 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
     return "k_igemm<2,2,2,2>"
 
 
+# Round 6: the APPLY phase of a GroupNorm backward inside the pointwise data-gradient GEMM that consumes it (crd_gn_bwd_conv,
+# csrc/xfgemm.hip) instead of a crd_gn_bwd_apply launch: Mlp.norm1 in front of fc1's data gradient (GNB_FC1) and attn.norm in front of
+# the sr patch scatter (GNB_SR).  Bit s of a mask = encoder stage s + 1 (developer switches CRD_GNB_FC1 / CRD_GNB_SR for the A/B).
+GNB_FC1 = _dev_int("CRD_GNB_FC1", 15)
+GNB_SR = _dev_int("CRD_GNB_SR", 15)
 FUSE_NORM2_APPLY = not _dev_flag("CRD_NO_FUSE_NORM2_APPLY")    # developer switch (A/B): Block.norm2's backward apply inside crd_attn_out_bwd
 FUSE_BLOCK_RED = not _dev_flag("CRD_NO_FUSE_BLOCK_RED")    # developer switch (A/B): Block.norm1 / norm2 reduces in GEMM epilogues
 
@@ -448,6 +453,32 @@ class Plan:
         lst.append(op)
         return op
 
+    def gn_bwd_conv(self, lst, spec, gx, stats, gmul, gname, act, r, dx, mask=None):
+        """spec as for conv() with x = dy of the GroupNorm `gname` (its raw input gx, forward sums `stats`, reduce sums r): the apply phase of
+        that GroupNorm's backward runs while the pointwise data-gradient GEMM loads its A operand (crd_gn_bwd_conv); dx: PM that also
+        receives the applied gradient (the weight gradients read it), or None."""
+        w, x = spec["w"], spec["x"]
+        cw = w[1]
+        assert isinstance(w, tuple) and x.coff == 0 and gx.coff == 0 and (dx is None or dx.coff == 0) and spec["k"] == 1
+        flops = 2.0 * self.B * x.H * x.W * cw.cout * cw.taps * min(spec["cout"] // (cw.taps if w[0] == "scatter" else 1), cw.cin_ref)
+        small = spec["cout"] <= 64 or -(-spec["OH"] * spec["OW"] // 64) * -(-spec["cout"] // 128) * self.B < 256 or spec["out_mode"] == 1
+        kname = "k_gnbwd_gemm" + ("<1>" if small else "<2>")
+        meta = {"kernel": kname, "flops": flops,
+                "shape": f"gnbwd+{'scatter' if w[0] == 'scatter' else 'dgrad'} Cin{spec['cin']} Cout{spec['cout']} out{spec['OH']}x{spec['OW']}"}
+        frozen = self.is_frozen(gname + ".weight", gname + ".bias")
+        gnb = dict(gnb_in=True, gx=gx, gmul=gmul, act=act, stats=stats, gamma=self.p(gname + ".weight"), beta=self.p(gname + ".bias"),
+                   mask=mask, r=r, dx=dx, dgamma=None if frozen else self.g(gname + ".weight"), dbeta=None if frozen else self.g(gname + ".bias"))
+
+        def io(spec=spec, x=x, gx=gx, dx=dx):
+            n = nbytes(x, gx, dx) + spec["cout"] * spec["cin"] * 2
+            n += nbytes(spec["y"]) * (2 if spec["accumulate"] else 1)
+            if spec.get("red") is not None:
+                n += nbytes(spec["red"][0])
+            return n
+        op = Op(self.lib.crd_gn_bwd_conv, [spec, gnb], "crd_gn_bwd_conv", None, None, meta, stream=self._cur_stream, io=io)
+        lst.append(op)
+        return op
+
     def wgrad(self, lst, x, dy, cw, k, stride, pad, OH, OW, dbias=None, cin=None):
         """dbias: NAME of the bias parameter.  Weight and bias gradients are accumulated as crd_sum_t (order-independent
         integer atomics) in backward scratch; the segment's crd_wgrad_unpack converts and adds them into the flat gradient."""
@@ -509,6 +540,15 @@ class Plan:
             n.x_f32, n.gmul, n.act = sp["x_f32"], sp["gmul"], sp["act"]
             n.stats, n.gamma, n.beta = P(sp["stats"]), P(sp["gamma"]), P(sp["beta"])
             n.xn, n.xn_ld = (P(sp["xn"]), sp["xn"].ld) if sp["xn"] is not None else (None, 0)
+            self.keep.append(n)
+            return C.byref(n)
+        if sp.get("gnb_in"):
+            n = L.GnBwdInput()
+            gx = sp["gx"]
+            n.gx, n.gx_f32, n.gx_ld, n.gmul, n.act = P(gx), gx.f32, gx.ld, sp["gmul"], sp["act"]
+            n.stats, n.gamma, n.beta, n.mask, n.r = P(sp["stats"]), P(sp["gamma"]), P(sp["beta"]), P(sp["mask"]), P(sp["r"])
+            n.dx, n.dx_ld = (P(sp["dx"]), sp["dx"].ld) if sp["dx"] is not None else (None, 0)
+            n.dgamma, n.dbeta = P(sp["dgamma"]), P(sp["dbeta"])
             self.keep.append(n)
             return C.byref(n)
         if sp.get("mlp"):
@@ -1026,6 +1066,7 @@ class Plan:
         B, N, hid, dh = self.B, Hs * Ws, Cs * ratio, Cs // heads
         scale = dh ** -0.5
         a, ml = name + ".attn", name + ".mlp1"
+        stage_i = int(name.split("block")[1].split(".")[0]) - 1
         dp = self.dp_masks[bi] if self.training else None
         M = (Hs // sr) * (Ws // sr)
         F_ = self.fwd
@@ -1181,13 +1222,20 @@ class Plan:
         r1 = self.zb(B * hid * 2 + B * (hid // 16) * 2)
         self._emit(g, "crd_dwconv3x3", [DHID.t, B, Hs, Ws, hid, w9, None, 1, DHID2.t, None, None, 1, None, None,
                                         H1.t, sth1, self.p(ml + ".norm1.weight"), r1], io=nbytes(DHID, DHID2, H1))
-        self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2, r=r1)             # in place: d(H1)
-        self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=ml + ".fc1.bias")
         # fc1's data gradient also runs the reduce phase of Block.norm2's backward on its own output (a launch less per block;
         # the GroupNorm's input is the fp32 residual stream: red_x_f32)
         rb2 = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if (FUSE_STATS and fused_reduce_tile_ok(Cs, N, B)) else None
         redb2 = None if rb2 is None else (X1, st2, self.p(name + ".norm2.weight"), self.p(name + ".norm2.bias"), 1, 0, rb2)
-        self.conv(g, self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, red=redb2))
+        fc1_dgrad = self.conv_desc(DHID2, ("dgrad", c1), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, red=redb2)
+        if (GNB_FC1 >> stage_i) & 1 and self._defer is not None:
+            # round 6: Mlp.norm1's backward apply runs in the operand load of fc1's data gradient; d(H1) is stored once, for fc1's weight gradient
+            DH1 = self.act(hid, Hs, Ws)
+            self.gn_bwd_conv(g, fc1_dgrad, H1, sth1, 1, ml + ".norm1", 0, r1, DH1)
+            self.wgrad(g, XN2, DH1, c1, 1, 1, 0, Hs, Ws, dbias=ml + ".fc1.bias")
+        else:
+            self.gn_bwd(g, H1, sth1, 1, ml + ".norm1", 0, None, DHID2, DHID2, r=r1)             # in place: d(H1)
+            self.wgrad(g, XN2, DHID2, c1, 1, 1, 0, Hs, Ws, dbias=ml + ".fc1.bias")
+            self.conv(g, fc1_dgrad)
         # attention branch
         T, dSv = self.zb(B, Cs), self.new((B, N), F32)
         dbp_rows = self.zb(B, Cs)
@@ -1242,10 +1290,17 @@ class Plan:
             rk = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if FUSE_STATS else None
             redk = None if rk is None else (KR, stk, self.p(a + ".norm.weight"), self.p(a + ".norm.bias"), 1, 0, rk)
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs // sr, Ws // sr, DKR, gather=1, red=redk))
-            self.gn_bwd(g, KR, stk, 1, a + ".norm", 0, None, DKR, DKR, r=rk)
-            self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=a + ".sr.bias")
-            self.conv(g, self.conv_desc(DKR, ("scatter", csr), sr * sr * Cs, 1, 1, 0, Hs // sr, Ws // sr, DXN, out_mode=1,
-                                        patch_k=sr, patch_c=Cs, accumulate=key_acc))
+            sr_scatter = self.conv_desc(DKR, ("scatter", csr), sr * sr * Cs, 1, 1, 0, Hs // sr, Ws // sr, DXN, out_mode=1,
+                                        patch_k=sr, patch_c=Cs, accumulate=key_acc)
+            if rk is not None and (GNB_SR >> stage_i) & 1 and self._defer is not None:
+                # round 6: attn.norm's backward apply runs in the operand load of the sr patch scatter; d(KR) stored for sr's weight gradient
+                DKR2 = self.act(Cs, Hs // sr, Ws // sr)
+                self.gn_bwd_conv(g, sr_scatter, KR, stk, 1, a + ".norm", 0, rk, DKR2)
+                self.wgrad(g, XN, DKR2, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=a + ".sr.bias")
+            else:
+                self.gn_bwd(g, KR, stk, 1, a + ".norm", 0, None, DKR, DKR, r=rk)
+                self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=a + ".sr.bias")
+                self.conv(g, sr_scatter)
         else:
             self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=a + ".k.bias")
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=key_acc))

@@ -138,3 +138,117 @@ def test_gn_conv_rejects_what_it_does_not_cover():
     d.pad = 0
     n.gmul = 3
     assert L.crd_gn_conv(C.byref(d), C.byref(n), lib.stream()) == -1          # 4 slabs do not split into groups of 3
+
+
+# ---- crd_gn_bwd_conv (round 6): the backward twin -- GroupNorm-backward APPLY in the operand load of the consuming data-gradient GEMM
+# Ci = the GroupNorm's channels = K of the GEMM, Co = output columns.  B, Ci, H, W, Co, gmul, act, gx_f32, mode
+BWD_CASES = [
+    (2, 512, 16, 24, 64, 1, 0, 0, "red"),        # Mlp.norm1 in front of fc1's data gradient, stage 1 (+ Block.norm2's fused reduce)
+    (2, 640, 16, 26, 160, 1, 0, 0, "red"),       # ... stage 3 at the benchmark grid: ragged K (10 slabs), 160 columns on 64-wide tiles
+    (8, 1024, 32, 52, 128, 1, 0, 0, "red"),      # ... stage 2 at the benchmark size
+    (2, 1024, 8, 13, 256, 1, 0, 0, "plain"),     # ... stage 4
+    (3, 1024, 7, 9, 256, 1, 0, 0, "acc"),        # ragged rows, odd batch, accumulating output
+    (2, 64, 8, 13, 64, 1, 0, 0, "scatter8"),     # attn.norm in front of the sr patch scatter: stage 1 (8 x 8 patches)
+    (2, 128, 8, 13, 128, 1, 0, 0, "scatter4"),   # stage 2
+    (8, 160, 8, 13, 160, 1, 0, 0, "scatter2"),   # stage 3 at the benchmark size
+    (2, 160, 8, 13, 160, 1, 0, 0, "scatter2acc"),
+    (2, 512, 12, 20, 64, 8, 1, 0, "plain"),      # Mlp.norm2 + GELU (groups of 8 slabs)
+    (2, 64, 9, 11, 512, 1, 0, 1, "plain"),       # fp32 GroupNorm input (the residual stream), 128-wide column tiles
+    (8, 160, 16, 26, 640, 1, 0, 1, "stats"),     # ... with output sums
+]
+
+
+@pytest.mark.parametrize("case", BWD_CASES, ids=[f"{c[1]}to{c[4]}_g{c[5]}a{c[6]}f{c[7]}_{c[8]}_{c[0]}x{c[2]}x{c[3]}" for c in BWD_CASES])
+def test_gn_bwd_conv_matches_apply_then_conv(case):
+    """crd_gn_bwd_conv against the launches it replaces -- crd_gn_bwd_apply, then crd_conv_igemm on the stored gradient -- and
+    against torch autograd through F.group_norm (+ F.gelu): same product (one bf16 rounding of dx may differ), same stored dx, same
+    GroupNorm parameter gradients, same fused-reduce sums / output statistics."""
+    from tests.test_gpu_igemm import run_conv, to_pm
+    from tests.util import gval
+    B, Ci, H, W, Co, gmul, act, gxf32, mode = case
+    lib = _lib()
+    L = lib.load()
+    g = torch.Generator().manual_seed(Ci + 3 * Co + act)
+    P = H * W
+    xg = torch.randn(B, Ci, H, W, generator=g) * 1.4 + 0.25
+    if not gxf32:
+        xg = bf(xg)
+    dy = bf(torch.randn(B, Ci, H, W, generator=g) * 0.7)
+    gamma, beta = 1 + 0.2 * torch.randn(Ci, generator=g), 0.1 * torch.randn(Ci, generator=g)
+    scatter = mode.startswith("scatter")
+    pk = int(mode[7]) if scatter else 1
+    N = Co * pk * pk
+    w = bf(torch.randn(N, Ci, generator=g) / Ci ** 0.5)                    # rows = output columns, K contiguous
+    # torch reference of dx
+    xr = xg.clone().requires_grad_(True)
+    yn = F.group_norm(xr, Ci // (16 * gmul), gamma, beta, 1e-5)
+    if act:
+        yn = F.gelu(yn)
+    yn.backward(dy)
+    dx_ref = xr.grad
+    xpm = xg.permute(0, 2, 3, 1).reshape(B, P, Ci).contiguous()
+    xpm = (xpm if gxf32 else xpm.to(torch.bfloat16)).cuda()
+    dypm = to_pm(dy).reshape(B, P, Ci)
+    gam_d, bet_d, wd = gamma.cuda(), beta.cuda(), w.to(torch.bfloat16).cuda()
+    stats = zsum(B, Ci // 16, 2)
+    lib.check(L.crd_gn_stats(xpm.data_ptr(), gxf32, Ci, 0, B, P, Ci, stats.data_ptr(), None, lib.stream()), "gn_stats")
+    G = Ci // (16 * gmul)
+    r = zsum(B * Ci * 2 + B * G * 2)
+    lib.check(L.crd_gn_bwd_reduce(xpm.data_ptr(), gxf32, Ci, 0, dypm.data_ptr(), 0, Ci, 0, B, P, Ci, stats.data_ptr(), gmul,
+                                  gam_d.data_ptr(), bet_d.data_ptr(), act, None, r.data_ptr(), None, 0, lib.stream()), "gn_bwd_reduce")
+    # the pair it replaces
+    dga0, dbe0 = torch.zeros(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
+    dx0 = torch.zeros(B, P, Ci, dtype=torch.bfloat16, device="cuda")
+    lib.check(L.crd_gn_bwd_apply(xpm.data_ptr(), gxf32, Ci, 0, dypm.data_ptr(), 0, Ci, 0, B, P, Ci, stats.data_ptr(), gmul, gam_d.data_ptr(),
+                                 bet_d.data_ptr(), act, None, r.data_ptr(), dga0.data_ptr(), dbe0.data_ptr(), dx0.data_ptr(), 0, Ci, 0, 0,
+                                 None, 0, None, lib.stream()), "gn_bwd_apply")
+    acc = mode.endswith("acc")
+    YH, YW = H * pk, W * pk
+    base = bf(torch.randn(B, YH * YW, Co, generator=g)) if acc else torch.zeros(B, YH * YW, Co)
+    y0, y1 = base.to(torch.bfloat16).cuda(), base.to(torch.bfloat16).cuda()
+    red0 = red1 = None
+    ost0, ost1 = zsum(B, Co // 16, 2), zsum(B, Co // 16, 2)
+    kw = {}
+    if mode == "red":          # reduce phase of the NEXT GroupNorm's backward (input: an fp32 residual-stream tensor) on the product
+        rx = (torch.randn(B, P, Co, generator=g) * 1.2).cuda()
+        rst = zsum(B, Co // 16, 2)
+        lib.check(L.crd_gn_stats(rx.data_ptr(), 1, Co, 0, B, P, Co, rst.data_ptr(), None, lib.stream()), "gn_stats")
+        rg, rb = (1 + 0.1 * torch.randn(Co, generator=g)).cuda(), (0.1 * torch.randn(Co, generator=g)).cuda()
+        red0, red1 = zsum(B * Co * 2 + B * (Co // 16) * 2), zsum(B * Co * 2 + B * (Co // 16) * 2)
+    if scatter:
+        kw = dict(out_mode=1, patch_k=pk, patch_c=Co)
+    run_conv(dx0.view(B, H, W, Ci), Ci, 0, B, H, W, Ci, wd, N, 1, 1, 1, 0, H, W, y0.view(B, YH, YW, Co), Co, 0, accumulate=int(acc),
+             stats=ost0 if mode == "stats" else None, red=(rx, rst, rg, rb, 1, 0, red0) if red0 is not None else None, **kw)
+    # the fused launch
+    d, n = lib.ConvDesc(), lib.GnBwdInput()
+    d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = dypm.data_ptr(), Ci, 0, B, H, W, Ci
+    d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = wd.data_ptr(), N, 1, 1, 1, 0, H, W
+    d.y, d.y_ld, d.y_coff, d.y_f32, d.accumulate = y1.data_ptr(), Co, 0, 0, int(acc)
+    if scatter:
+        d.out_mode, d.patch_k, d.patch_c = 1, pk, Co
+    if mode == "stats":
+        d.stats = ost1.data_ptr()
+    if red1 is not None:
+        d.red_x, d.red_x_ld, d.red_gmul, d.red_act, d.red_x_f32 = rx.data_ptr(), Co, 1, 0, 1
+        d.red_stats, d.red_gamma, d.red_beta, d.red_r = rst.data_ptr(), rg.data_ptr(), rb.data_ptr(), red1.data_ptr()
+    dga1, dbe1 = torch.zeros(Ci, device="cuda"), torch.zeros(Ci, device="cuda")
+    dx1 = torch.zeros(B, P, Ci, dtype=torch.bfloat16, device="cuda")
+    n.gx, n.gx_f32, n.gx_ld, n.gmul, n.act = xpm.data_ptr(), gxf32, Ci, gmul, act
+    n.stats, n.gamma, n.beta, n.r = stats.data_ptr(), gam_d.data_ptr(), bet_d.data_ptr(), r.data_ptr()
+    n.dx, n.dx_ld, n.dgamma, n.dbeta = dx1.data_ptr(), Ci, dga1.data_ptr(), dbe1.data_ptr()
+    lib.check(L.crd_gn_bwd_conv(C.byref(d), C.byref(n), lib.stream()), "crd_gn_bwd_conv")
+    torch.cuda.synchronize()
+    # stored gradient: the apply kernel's, up to one bf16 ulp where the fp32 evaluation order moves a value across a rounding boundary
+    assert_close(dx1.float().cpu(), dx0.float().cpu(), "stored dx vs crd_gn_bwd_apply", rel=2e-3, elem=1.6e-2)
+    assert_close(dx1.float().cpu().reshape(B, H, W, Ci).permute(0, 3, 1, 2), dx_ref, "stored dx vs autograd", rel=6e-3, elem=2e-2)
+    assert torch.equal(dga0, dga1) and torch.equal(dbe0, dbe1)
+    assert_close(y1.float().cpu(), y0.float().cpu(), "product vs apply + conv_igemm", rel=4e-3, elem=1.5e-2)
+    # against torch: conv of the bf16-rounded autograd gradient
+    yt = torch.einsum("bpk,nk->bpn", bf(dx_ref).permute(0, 2, 3, 1).reshape(B, P, Ci), w)
+    if scatter:
+        yt = yt.reshape(B, H, W, pk, pk, Co).permute(0, 1, 3, 2, 4, 5).reshape(B, YH * YW, Co)
+    assert_close(y1.float().cpu() - base, yt, "product vs torch", rel=8e-3, elem=2.5e-2)
+    if mode == "stats":
+        assert_close(sval(ost1), sval(ost0), "output sums", rel=2e-3, elem=5e-3)
+    if red1 is not None:
+        assert_close(gval(red1), gval(red0), "fused reduce of the next GroupNorm", rel=3e-3, elem=3e-3)

@@ -22,7 +22,7 @@ def _plan(train=True, **variant):
 def test_plan_builds_without_a_gpu_and_every_launch_has_bytes(variant):
     m, p = _plan(True, **variant)
     ops = [op for op in p.fwd + p.bwd if p.live(op)]
-    assert len(p.fwd) > 90 and len(p.bwd) > 150
+    assert len(p.fwd) > 85 and len(p.bwd) > 120
     zero = sorted({op.name for op in ops if p.op_bytes(op) <= 0})
     assert not zero, f"launches without algorithmic bytes: {zero}"
     # weight gradients never sit on the dependency chain

@@ -13,7 +13,7 @@ void crd_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* crd_last_error(void) { return g_err; }
-extern "C" int crd_version(void) { return 1; }
+extern "C" int crd_version(void) { return CRD_ABI_VERSION; }
 extern "C" const char* crd_arch(void) { return "gfx950"; }
 
 // ---- sticky non-finite indicator of the fixed-point sums (common.h: to_fx) ----

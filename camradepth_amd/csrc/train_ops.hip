@@ -286,7 +286,14 @@ __global__ __launch_bounds__(TPB) void k_weight_pack(const crd_pack_entry* tab) 
         const int co = co0 + col, ci = ci0 + cl;
         if (co < e.Cout_pad && ci < e.Cin_pad) {
           const bf16_t q = f2bf(tile[col * per_co + cl * e.taps + tap]);      // zero beyond Cout (never loaded)
-          if (e.dst_dgrad) reinterpret_cast<bf16_t*>(e.dst_dgrad)[((long long)ci * e.taps + tap) * e.Cout_pad + co] = q;
+          if (e.dst_dgrad) {
+            if (e.dgrad_ld == 0) reinterpret_cast<bf16_t*>(e.dst_dgrad)[((long long)ci * e.taps + tap) * e.Cout_pad + co] = q;
+            else {                                             // K-concatenated form: a row range of this layer's input channels
+              const int rr = ci - e.dgrad_row0;
+              if (rr >= 0 && rr < e.dgrad_rows)
+                reinterpret_cast<bf16_t*>(e.dst_dgrad)[((long long)rr * e.taps + tap) * e.dgrad_ld + e.dgrad_coff + co] = q;
+            }
+          }
           if (e.dst_scatter) reinterpret_cast<bf16_t*>(e.dst_scatter)[((long long)tap * e.Cin_pad + ci) * e.Cout_pad + co] = q;
         }
       }

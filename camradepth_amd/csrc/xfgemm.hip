@@ -283,27 +283,9 @@ int dispatch(const ConvK& k, const XfIn& xi, int B, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int crd_gn_bwd_conv(const crd_conv_desc* d, const crd_gn_bwd_input* n, crd_stream_t stream) {
-  CRD_CHECK_ARG(d && n && d->x && d->w && d->y && n->gx && n->stats && n->gamma && n->beta && n->r, "crd_gn_bwd_conv: null pointer");
-  CRD_CHECK_ARG(d->Cin % 16 == 0 && d->x_ld % 8 == 0 && d->x_coff % 8 == 0 && n->gx_ld % 8 == 0,
-                "crd_gn_bwd_conv: Cin must be a multiple of 16, x_ld / x_coff / gx_ld of 8");
-  CRD_CHECK_ARG(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "crd_gn_bwd_conv: bad dims");
-  CRD_UNSUPPORTED(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->IH == d->OH && d->IW == d->OW,
-                  "crd_gn_bwd_conv: pointwise data gradients only (patch scatter through out_mode = 1)");
-  CRD_CHECK_ARG(n->gmul >= 1 && (d->Cin / 16) % n->gmul == 0 && (n->act == 0 || n->act == 1), "crd_gn_bwd_conv: bad GroupNorm arguments");
-  CRD_CHECK_ARG(!d->y_f32 && !d->res && !d->act && !d->chan_sums && !d->stats_partial,
-                "crd_gn_bwd_conv: bf16 output without residual / activation / channel sums");
-  CRD_CHECK_ARG(d->out_mode == 0 || (d->out_mode == 1 && d->patch_k > 0 && d->patch_c > 0 && d->Cout == d->patch_k * d->patch_k * d->patch_c),
-                "crd_gn_bwd_conv: bad patch-scatter dims");
-  CRD_CHECK_ARG(!d->stats || d->Cout % 16 == 0, "crd_gn_bwd_conv: stats need Cout %% 16 == 0");
-  CRD_CHECK_ARG(!n->dx || (n->dx_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(n->dx) & 15) == 0), "crd_gn_bwd_conv: dx rows must be 16-byte aligned");
-  CRD_CHECK_ARG((n->dgamma == nullptr) == (n->dbeta == nullptr), "crd_gn_bwd_conv: dgamma and dbeta come together");
-  CRD_UNSUPPORTED((long long)d->Cout * d->Cin < (1ll << 30) && d->Cin <= 4096 && (long long)d->IH * d->IW * d->x_ld * 2 < (1ll << 31) &&
-                  (long long)d->IH * d->IW * n->gx_ld * (n->gx_f32 ? 4 : 2) < (1ll << 31), "crd_gn_bwd_conv: tensor too large for 32-bit byte offsets");
-  ConvK k;
+// ConvK of a pointwise data-gradient GEMM from the descriptor
+static int fill_convk(const crd_conv_desc* d, ConvK& k, const char* who) {
   k.x = reinterpret_cast<const bf16_t*>(d->x) + d->x_coff; k.x_ld = d->x_ld;
-  CRD_CHECK_ARG((reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(n->gx) & 15) == 0 && (!n->gx_f32 || n->gx_ld % 4 == 0),
-                "crd_gn_bwd_conv: dy / x rows must be 16-byte aligned");
   k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.x_bstride = (long long)d->IH * d->IW * d->x_ld;
   k.w = reinterpret_cast<const bf16_t*>(d->w);
   k.Cout = d->Cout; k.KW = 1; k.stride = 1; k.pad = 0; k.Ktot = d->Cin;
@@ -329,10 +311,34 @@ extern "C" int crd_gn_bwd_conv(const crd_conv_desc* d, const crd_gn_bwd_input* n
   k.dbg = 0;
   if (d->red_x) {
     CRD_CHECK_ARG(d->red_stats && d->red_gamma && d->red_beta && d->red_r && d->red_gmul >= 1 && d->red_x_ld % 8 == 0 &&
-                  (d->Cout / 16) % d->red_gmul == 0, "crd_gn_bwd_conv: incomplete fused-reduce arguments");
+                  (d->Cout / 16) % d->red_gmul == 0, "%s: incomplete fused-reduce arguments", who);
     CRD_UNSUPPORTED(d->Cout % 16 == 0 && d->out_mode == 0 && d->y_ld % 8 == 0 && k.vec_ok,
-                    "crd_gn_bwd_conv: the fused GroupNorm-backward reduce needs a plain-layout bf16 vector-path output");
+                    "%s: the fused GroupNorm-backward reduce needs a plain-layout bf16 vector-path output", who);
   }
+  return CRD_OK;
+}
+
+extern "C" int crd_gn_bwd_conv(const crd_conv_desc* d, const crd_gn_bwd_input* n, crd_stream_t stream) {
+  CRD_CHECK_ARG(d && n && d->x && d->w && d->y && n->gx && n->stats && n->gamma && n->beta && n->r, "crd_gn_bwd_conv: null pointer");
+  CRD_CHECK_ARG(d->Cin % 16 == 0 && d->x_ld % 8 == 0 && d->x_coff % 8 == 0 && n->gx_ld % 8 == 0,
+                "crd_gn_bwd_conv: Cin must be a multiple of 16, x_ld / x_coff / gx_ld of 8");
+  CRD_CHECK_ARG(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0, "crd_gn_bwd_conv: bad dims");
+  CRD_UNSUPPORTED(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->IH == d->OH && d->IW == d->OW,
+                  "crd_gn_bwd_conv: pointwise data gradients only (patch scatter through out_mode = 1)");
+  CRD_CHECK_ARG(n->gmul >= 1 && (d->Cin / 16) % n->gmul == 0 && (n->act == 0 || n->act == 1), "crd_gn_bwd_conv: bad GroupNorm arguments");
+  CRD_CHECK_ARG(!d->y_f32 && !d->res && !d->act && !d->chan_sums && !d->stats_partial,
+                "crd_gn_bwd_conv: bf16 output without residual / activation / channel sums");
+  CRD_CHECK_ARG(d->out_mode == 0 || (d->out_mode == 1 && d->patch_k > 0 && d->patch_c > 0 && d->Cout == d->patch_k * d->patch_k * d->patch_c),
+                "crd_gn_bwd_conv: bad patch-scatter dims");
+  CRD_CHECK_ARG(!d->stats || d->Cout % 16 == 0, "crd_gn_bwd_conv: stats need Cout %% 16 == 0");
+  CRD_CHECK_ARG(!n->dx || (n->dx_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(n->dx) & 15) == 0), "crd_gn_bwd_conv: dx rows must be 16-byte aligned");
+  CRD_CHECK_ARG((n->dgamma == nullptr) == (n->dbeta == nullptr), "crd_gn_bwd_conv: dgamma and dbeta come together");
+  CRD_UNSUPPORTED((long long)d->Cout * d->Cin < (1ll << 30) && d->Cin <= 4096 && (long long)d->IH * d->IW * d->x_ld * 2 < (1ll << 31) &&
+                  (long long)d->IH * d->IW * n->gx_ld * (n->gx_f32 ? 4 : 2) < (1ll << 31), "crd_gn_bwd_conv: tensor too large for 32-bit byte offsets");
+  ConvK k;
+  { const int rc = fill_convk(d, k, "crd_gn_bwd_conv"); if (rc != CRD_OK) return rc; }
+  CRD_CHECK_ARG((reinterpret_cast<uintptr_t>(k.x) & 15) == 0 && (reinterpret_cast<uintptr_t>(n->gx) & 15) == 0 && (!n->gx_f32 || n->gx_ld % 4 == 0),
+                "crd_gn_bwd_conv: dy / x rows must be 16-byte aligned");
   XfIn xi;
   xi.gx = n->gx; xi.gx_f32 = n->gx_f32; xi.gx_ld = n->gx_ld; xi.gx_bstride = (long long)d->IH * d->IW * n->gx_ld;
   xi.stats = n->stats; xi.gmul = n->gmul; xi.gamma = n->gamma; xi.beta = n->beta; xi.mask = n->mask;

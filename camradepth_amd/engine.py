@@ -164,8 +164,16 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
 # Round 6: the APPLY phase of a GroupNorm backward inside the pointwise data-gradient GEMM that consumes it (crd_gn_bwd_conv,
 # csrc/xfgemm.hip) instead of a crd_gn_bwd_apply launch: Mlp.norm1 in front of fc1's data gradient (GNB_FC1) and attn.norm in front of
 # the sr patch scatter (GNB_SR).  Bit s of a mask = encoder stage s + 1 (developer switches CRD_GNB_FC1 / CRD_GNB_SR for the A/B).
+# Round 6: the data gradients of a decoder stage's three ConvLayers (ShortResBlock, utils.py:127-135) as WRITE-ONCE launches over the
+# K-concatenated gradient buffer [d(raw2) | d(raw1) | d(raw0)]: columns [o1, o1+64) of the concat-buffer gradient from layer 2 alone
+# (K = 128 x 9), [o0, o1) from layers 2 | 1 (K = 192 x 9), [0, o0) from all three (K = 288 x 9) -- no read-modify-write of the 304-channel
+# gradient, no accumulating epilogue.  Developer switch CRD_KCAT=0: the per-layer accumulating launches of rounds 1-5 (the A/B).
+KCAT = _dev_int("CRD_KCAT", 1) != 0
 GNB_FC1 = _dev_int("CRD_GNB_FC1", 15)
 GNB_SR = _dev_int("CRD_GNB_SR", 15)
+# (Round 6, measured and removed: the fold of crd_attn_bwd's dK partials inside k's data gradient -- a GEMM of 16-48 workgroups whose A
+# loader sums 4-52 fp32 partials took 16.9 / 17.9 / 15.1 us at stages 3 / 2 / 1 against 3.2 + 8.0 for crd_sum_partials_bf16 + the GEMM:
+# 17.36 ms per step with it, 17.19 without, gpurun_out/r6/ab_ps2.txt.)
 FUSE_NORM2_APPLY = not _dev_flag("CRD_NO_FUSE_NORM2_APPLY")    # developer switch (A/B): Block.norm2's backward apply inside crd_attn_out_bwd
 FUSE_BLOCK_RED = not _dev_flag("CRD_NO_FUSE_BLOCK_RED")    # developer switch (A/B): Block.norm1 / norm2 reduces in GEMM epilogues
 
@@ -248,6 +256,7 @@ class Plan:
         self.keep = []                              # keep ctypes structs / tensors alive
         self.dw_entries, self.dw_grads = [], []
         self.row_grads = []                         # (param, C, rows buffer, R, tag, offset, row stride): gradient = sum of the rows
+        self.kcat_entries = []                      # (ConvW, K-concatenated weight matrix, ld, column offset, first row, rows): extra pack-table entries
         self.shapes = {}
         self.fwd_marks = []
         self._defer = None
@@ -375,7 +384,9 @@ class Plan:
 
     def conv(self, lst, spec, region=None):
         w, x = spec["w"], spec["x"]
-        if isinstance(w, tuple):     # data gradient of convolution w[1]: algorithmic work of that layer's forward
+        if isinstance(w, tuple) and w[0] == "kcat":
+            flops = spec["flops_override"]
+        elif isinstance(w, tuple):     # data gradient of convolution w[1]: algorithmic work of that layer's forward
             cw = w[1]
             flops = 2.0 * self.B * x.H * x.W * cw.cout * cw.taps * min(spec["cout"] // (cw.taps if w[0] == "scatter" else 1),
                                                                          cw.cin_ref)
@@ -405,7 +416,7 @@ class Plan:
             kname = "k_conv3x3p<2>" if c <= 64 else "k_conv3x3p<3>" if c <= 96 else "k_conv3x3p<4>" + ("" if rest == 0 or rest > 64 else
                                                                                                  "+k_conv3x3<4,1,2,1>" if rest <= 32 else "+k_conv3x3<4,1,2,2>")
         meta = {"kernel": kname, "flops": flops,
-                "shape": f"{'dgrad' if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
+                "shape": f"{('dgrad-kcat' if w[0] == 'kcat' else 'dgrad') if isinstance(w, tuple) else 'fwd'} Cin{spec['cin']} Cout{spec['cout']} k{spec['k']} s{spec['stride']} "
                          f"out{spec['OH']}x{spec['OW']}"}
         wbytes = spec["cout"] * spec["k"] * spec["k"] * spec["cin"] * 2
 
@@ -589,7 +600,9 @@ class Plan:
                 d.dw_partials, d.dw_partial_capacity, d.wg_budget = cw.dw_parts.data_ptr(), cw.dw_S, cw.wg_budget
         else:
             x, y, w = sp["x"], sp["y"], sp["w"]
-            if isinstance(w, tuple):
+            if isinstance(w, tuple) and w[0] == "kcat":
+                w = w[2]
+            elif isinstance(w, tuple):
                 w = w[1].w_dgrad if w[0] == "dgrad" else w[1].w_scatter
                 assert w is not None, "packed data-gradient weights were not requested for this convolution"
             elif isinstance(w, ConvW):
@@ -677,11 +690,14 @@ class Plan:
         op = self._emit(grp, "crd_gn_bwd_apply", args, region, acc_idx if region else None)
         op.io = lambda op=op, i=acc_idx, x=x, dy=dy, dx=dx, dx2=dx2: nbytes(x, dy, dx, dx2) + (nbytes(dx) if op.args[i] else 0)
 
-    def conv_layer(self, name, x, k, out, mask=None, dout=None, dx=None, dx_region=None, x8=None, out8=None):
+    def conv_layer(self, name, x, k, out, mask=None, dout=None, dx=None, dx_region=None, x8=None, out8=None, kcat=None):
         """ConvLayer (utils.py:210-228): conv(no bias) -> GN(Cout/16) -> GELU [-> Dropout2d mask].
         x: input PM (Cin = x.C incl. padding, cmap given by caller through self._cmap), out: PM slice
         to write; dout: PM slice holding d(out); dx: PM slice receiving d(x)."""
-        cw = self.new_conv(name + ".model.0", cmap=self._cmap, need_dgrad=dx is not None)
+        # kcat (round 6, decoder stages): dict(draw=slice of the stage's K-concatenated d(raw) buffer this layer's GroupNorm backward writes,
+        # packs=[(matrix, ld, column offset, first row, rows)]: where this layer's data-gradient weights go, launch=(x = the buffer's K
+        # prefix, matrix, n0, n1, dcb): the write-once data gradient of concat-gradient columns [n0, n1) issued behind this layer)
+        cw = self.new_conv(name + ".model.0", cmap=self._cmap, need_dgrad=dx is not None and kcat is None)
         H, W = x.H, x.W
         raw = self.act(cw.cout, H, W)
         stats = self.zf(self.B, cw.cout // 16, 2)
@@ -713,7 +729,7 @@ class Plan:
         if dout is None:
             return
         grp = []
-        draw = self.act(cw.cout, H, W)
+        draw = kcat["draw"] if kcat is not None else self.act(cw.cout, H, W)
         # e4m3 data gradient where it pays -- measured per kernel at B = 16 (profiles/r05_c5_decoder_backward_chain_*.txt): the 128 -> 304 /
         # 296 layers, whose data gradient is the first writer of the concat gradient and MFMA-bound (1092 -> 859 us, 308 -> 238 us); the
         # 64- and 96-channel layers ACCUMULATE into it and are bound by that read-modify-write (652 -> 679, 644 -> 684 us in e4m3, plus
@@ -750,7 +766,14 @@ class Plan:
             return
         self.gn_bwd(grp, raw, stats, 1, name + ".model.1", 1, mask, dout, draw)
         self.wgrad(grp, x, draw, cw, k, 1, k // 2, H, W)
-        if dx is not None:
+        if kcat is not None:
+            for (Wt, ld, coff, row0, rows) in kcat["packs"]:
+                self.kcat_entries.append((cw, Wt, ld, coff, row0, rows))
+            xcat, Wt, n0, n1, dcb, real = kcat["launch"]
+            spec = self.conv_desc(xcat, ("kcat", cw, Wt), n1 - n0, k, 1, k // 2, H, W, dcb.sl(n0, n1), gather=1)
+            spec["flops_override"] = 2.0 * self.B * H * W * 9 * real
+            self.conv(grp, spec, region=("dcb", id(dcb.t), n0, n1))
+        elif dx is not None:
             self.conv(grp, self.conv_desc(draw, ("dgrad", cw), dx.C, k, 1, k // 2, H, W, dx, gather=1), region=dx_region)
         self._push(grp)
 
@@ -917,15 +940,29 @@ class Plan:
             op = self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
             op.io = lambda op=op, n=nbytes(up_src.sl(0, up_p)): n * (5 + (1 if op.args[-1] else 0))
             self._push(grp)
+            kc = [None, None, None]
+            if KCAT:
+                # K-concatenated d(raw) buffer [layer 2 (128) | layer 1 (64) | layer 0 (96)] and the three weight matrices of the
+                # write-once data gradients: WA rows = concat channels [o1, o1 + 64) x K 128, WB [o0, o1) x K 192, WC [0, o0) x K 288
+                DRAW = self.act(288, Hj, Wj)
+                WA, WB, WC = self.new((64, 9, 128)), self.new((96, 9, 192)), self.new((o0, 9, 288))
+                real0 = cup[j] + cskip[j]                       # reference channels among the o0 padded ones
+                # algorithmic MACs per pixel and tap of each launch: (layers feeding it) x (reference columns it produces)
+                kc[2] = dict(draw=DRAW.sl(0, 128), packs=[(WA, 128, 0, o1, 64), (WB, 192, 0, o0, 96), (WC, 288, 0, 0, o0)],
+                             launch=(DRAW.sl(0, 128), WA, o1, o1 + 64, dcb, 128 * 64))
+                kc[1] = dict(draw=DRAW.sl(128, 192), packs=[(WB, 192, 128, o0, 96), (WC, 288, 128, 0, o0)],
+                             launch=(DRAW.sl(0, 192), WB, o0, o1, dcb, 192 * 96))
+                kc[0] = dict(draw=DRAW.sl(192, 288), packs=[(WC, 288, 192, 0, o0)],
+                             launch=(DRAW.sl(0, 288), WC, 0, o0, dcb, 288 * real0))
             self._cmap = cat_map(j, 0)
             self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, cb.sl(o0, o0 + 96), dout=dcb.sl(o0, o0 + 96),
-                            dx=dcb.sl(0, o0), dx_region=("dcb", id(dcb), 0, o0))
+                            dx=dcb.sl(0, o0), dx_region=("dcb", id(dcb), 0, o0), kcat=kc[0])
             self._cmap = cat_map(j, 1)
             self.conv_layer(f"{name}.conv.layers.1", cb.sl(0, o1), 3, cb.sl(o1, o1 + 64), dout=dcb.sl(o1, o1 + 64),
-                            dx=dcb.sl(0, o1), dx_region=("dcb", id(dcb), 0, o1))
+                            dx=dcb.sl(0, o1), dx_region=("dcb", id(dcb), 0, o1), kcat=kc[1])
             self._cmap = cat_map(j, 2)
             self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, dout=dout,
-                            dx=dcb.sl(0, o1 + 64), dx_region=("dcb", id(dcb), 0, o1 + 64))
+                            dx=dcb.sl(0, o1 + 64), dx_region=("dcb", id(dcb), 0, o1 + 64), kcat=kc[2])
             self._cmap = None
 
         n_extra = int(cfg.supervised_seg) + int(cfg.unsupervised_seg)
@@ -1284,12 +1321,12 @@ class Plan:
         else:
             self._emit(g, "crd_gsum_to_bf16", [dK, DKb.t, B * M * Cs], io=nbytes(dK, DKb))
         if sr > 1:
-            self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=a + ".k.bias")
             DKR = self.act(Cs, Hs // sr, Ws // sr)
             # k's data gradient also runs the reduce phase of attn.norm's backward on its own output (a launch less)
             rk = self.zb(B * Cs * 2 + B * (Cs // 16) * 2) if FUSE_STATS else None
             redk = None if rk is None else (KR, stk, self.p(a + ".norm.weight"), self.p(a + ".norm.bias"), 1, 0, rk)
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs // sr, Ws // sr, DKR, gather=1, red=redk))
+            self.wgrad(g, KRN, DKb, ck, 1, 1, 0, Hs // sr, Ws // sr, dbias=a + ".k.bias")      # (behind the launch that stores DKb)
             sr_scatter = self.conv_desc(DKR, ("scatter", csr), sr * sr * Cs, 1, 1, 0, Hs // sr, Ws // sr, DXN, out_mode=1,
                                         patch_k=sr, patch_c=Cs, accumulate=key_acc)
             if rk is not None and (GNB_SR >> stage_i) & 1 and self._defer is not None:
@@ -1302,8 +1339,8 @@ class Plan:
                 self.wgrad(g, XN, DKR, csr, sr, sr, 0, Hs // sr, Ws // sr, dbias=a + ".sr.bias")
                 self.conv(g, sr_scatter)
         else:
-            self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=a + ".k.bias")
             self.conv(g, self.conv_desc(DKb, ("dgrad", ck), Cs, 1, 1, 0, Hs, Ws, DXN, gather=1, accumulate=key_acc))
+            self.wgrad(g, XN, DKb, ck, 1, 1, 0, Hs, Ws, dbias=a + ".k.bias")
         if rb1 is not None:
             self.conv(g, q_dgrad)
         self.gn_bwd(g, X, st1, 1, name + ".norm1", 0, None, DXN, DX, dx_acc=1, r=rb1,         # DX = d(X)
@@ -1369,6 +1406,14 @@ class Plan:
             else:
                 cw.dw = self.zb(cw.cout, cw.taps, cw.cin_pad)
                 unpack.append(cw)
+        for (cw, Wt, ld, coff, row0, rows) in self.kcat_entries:    # this layer's columns / row range of a K-concatenated data-gradient matrix
+            e = L.PackEntry()
+            e.src, e.dst_dgrad = self.p(cw.name + ".weight").data_ptr(), Wt.data_ptr()
+            e.cmap = cw.cmap_dev.data_ptr() if cw.cmap_dev is not None else None
+            e.Cout, e.Cin_ref, e.taps, e.Cin_pad, e.Cout_pad, e.dst_f32 = cw.cout, cw.cin_ref, cw.taps, cw.cin_pad, cw.cout_pad, 0
+            e.dgrad_ld, e.dgrad_coff, e.dgrad_row0, e.dgrad_rows = ld, coff, row0, rows
+            entries.append(e)
+            pack_elems.append(cw.cin_pad * cw.taps * cw.cout_pad)
         for (name, hid, w9, fmt) in self.dw_entries:          # fmt: crd_pack_entry.dst_f32 (2: fp32 holding bf16-rounded values, 0: bf16)
             e = L.PackEntry()
             e.src, e.dst_fwd = self.p(name + ".weight").data_ptr(), w9.data_ptr()

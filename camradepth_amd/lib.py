@@ -69,6 +69,7 @@ class PackEntry(C.Structure):
         ("cmap", C.c_void_p),
         ("Cout", C.c_int32), ("Cin_ref", C.c_int32), ("taps", C.c_int32), ("Cin_pad", C.c_int32),
         ("Cout_pad", C.c_int32), ("dst_f32", C.c_int32),
+        ("dgrad_ld", C.c_int32), ("dgrad_coff", C.c_int32), ("dgrad_row0", C.c_int32), ("dgrad_rows", C.c_int32),
     ]
 
 
@@ -88,6 +89,7 @@ class UnpackEntry(C.Structure):
 
 
 _lib = None
+ABI_VERSION = 6          # include/camradepth_hip.h: CRD_ABI_VERSION
 
 
 def load():
@@ -102,6 +104,9 @@ def load():
     lib.crd_last_error.restype = C.c_char_p
     lib.crd_arch.restype = C.c_char_p
     lib.crd_version.restype = C.c_int
+    if lib.crd_version() != ABI_VERSION:
+        raise CrdError(f"{LIB_PATH} was built for ABI version {lib.crd_version()}, this binding is version {ABI_VERSION}: rebuild it "
+                       "(python -m camradepth_amd.build)")
     missing = [n for n in EXPORTS if not hasattr(lib, n)]
     if missing:
         raise CrdError(f"{LIB_PATH} lacks symbols {missing}: rebuild it (python -m camradepth_amd.build)")

@@ -58,7 +58,8 @@ typedef int64_t crd_sum_t;
 int crd_nonfinite_status(int32_t reset, crd_stream_t stream);
 
 const char* crd_last_error(void);
-int crd_version(void);          /* ABI version, currently 1 */
+#define CRD_ABI_VERSION 6        /* bumped whenever a struct layout or signature changes: the binding refuses a stale library */
+int crd_version(void);          /* CRD_ABI_VERSION of the library that was built */
 const char* crd_arch(void);     /* "gfx950" */
 
 /* ---------------------------------------------------------------------------------------------
@@ -506,6 +507,11 @@ typedef struct {
   int32_t dst_f32;     /* 1: dst_fwd is written as fp32 (plain copies of vectors); 2: fp32 holding the bf16-ROUNDED value (depthwise
                           weights [9][C]: what autocast feeds the convolution -- the reference casts conv weights to the low
                           precision, src/main/runner.py:191) */
+  /* Round 6: K-CONCATENATED data-gradient weights (the write-once data gradients of a ShortResBlock, src/utils/utils.py:127-135 under
+   * autograd: dx[n] of the concat buffer = sum over the layers that read channel n).  dgrad_ld > 0: dst_dgrad is a matrix
+   * [rows][taps][dgrad_ld] shared by several layers; this entry writes its Cout_pad columns at column offset dgrad_coff for the input
+   * channels [dgrad_row0, dgrad_row0 + dgrad_rows) as rows 0 .. dgrad_rows - 1.  dgrad_ld == 0: the plain form above. */
+  int32_t dgrad_ld, dgrad_coff, dgrad_row0, dgrad_rows;
 } crd_pack_entry;
 int crd_weight_pack(const crd_pack_entry* table_dev, int32_t n, int64_t max_elems, crd_stream_t stream);
 /* grad_ref[co][ci_ref][tap] (+)= dw_packed[co][tap][ci_pad] */

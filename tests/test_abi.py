@@ -49,7 +49,7 @@ def test_library_exports_every_declared_symbol(built):
     raw = ctypes.CDLL(lib.LIB_PATH)
     for name in fns:
         assert hasattr(raw, name), f"{name} declared in the header but not exported"
-    assert L.crd_version() == 1 and L.crd_arch() == b"gfx950"
+    assert L.crd_version() == lib.ABI_VERSION and L.crd_arch() == b"gfx950"
 
 
 def test_binding_signatures_match_header(built):
@@ -66,7 +66,7 @@ def test_struct_layouts_match_header(built, tmp_path):
               "crd_gn_input": (built.GnInput, ["x_f32", "gmul", "stats", "gamma", "beta", "act", "xn_ld", "xn"]),
               "crd_gn_bwd_input": (built.GnBwdInput, ["gx", "gx_f32", "gx_ld", "gmul", "act", "stats", "mask", "r", "dx", "dx_ld", "dgamma", "dbeta"]),
               "crd_wgrad_desc": (built.WgradDesc, ["x", "dy", "Cout", "dw", "dbias", "dw_partials", "dw_partial_capacity", "wg_budget"]),
-              "crd_pack_entry": (built.PackEntry, ["src", "cmap", "Cout", "dst_f32"]),
+              "crd_pack_entry": (built.PackEntry, ["src", "cmap", "Cout", "dst_f32", "dgrad_ld", "dgrad_rows"]),
               "crd_unpack_entry": (built.UnpackEntry, ["src", "cmap", "Cin_pad", "replicas", "replica_stride"]),
               "crd_wgrad_group_info": (built.WgradGroupInfo, ["n_problems", "n_items", "item_offset", "bytes"])}
     src = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{REPO}/include/camradepth_hip.h"', "int main(void){"]

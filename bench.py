@@ -69,6 +69,78 @@ def floor_budget(plan):
             "phases": phases}
 
 
+def excess_attribution(ts, step_ms, tail_ms, reps=20, warm_reps=10):
+    """Where the time between the WARM chain and the replayed step goes, measured in this process on the captured
+    graphs of the step:
+      warm_chain_ms   sum over the launches of the dependency chain of each launch replayed ALONE from a HIP graph (its inputs warm in the
+                      caches: tools/floor_table.py's figure),
+      chain_only_ms   the chain's own graphs replayed back to back with the late stream's graphs left out (nothing beside them),
+      late_only_ms    the late stream's graphs (weight gradients, un-packing, optimizer slices, re-pack) replayed alone, one after the other,
+      cold       = chain_only - warm_chain : what a launch pays for running right behind its producer instead of behind itself (the
+                   non-coherent L2s written back / invalidated at every kernel boundary, first-touch misses, dispatch gaps),
+      interference = step - tail - chain_only : what the late stream's kernels cost the chain's while they run beside them,
+      tail       = the main stream's idle time behind the late stream at the end of an iteration (exposed_tail_us)."""
+    plan = ts.plan
+    key = (True, True)
+    g = ts.graphs[key][0][0]
+    if not (isinstance(g, tuple) and g[0] == "late"):
+        return None
+    _, g0, chain, _ = g
+    if g0 is not None:
+        return None                                   # (the distributed step has collectives between the graphs: not replayable piecewise)
+
+    def timed(fn, n):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+    chain_only = timed(lambda: [gm.replay() for gm, _, _, _ in chain], reps)
+    late_only = timed(lambda: [gl.replay() for _, gl, _, _ in chain], reps)
+
+    def warm(op):
+        st = torch.cuda.Stream()
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            plan.run_ops([op])
+            gg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gg, stream=st):
+                for _ in range(warm_reps):
+                    plan.run_ops([op])
+            gg.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gg.replay()
+            e1.record()
+            torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / warm_reps
+    from camradepth_amd.engine import LATE
+    saved = plan.split_late
+    plan.split_late = False
+    warm_chain = warm_late = 0.0
+    n_chain = 0
+    for op in plan.fwd + plan.bwd:
+        if not plan.live(op):
+            continue
+        t = warm(op)
+        if op.stream == LATE:
+            warm_late += t
+        else:
+            warm_chain += t
+            n_chain += 1 + (op.meta or {}).get("kernel", "").count("+")
+    plan.split_late = saved
+    return {"step_ms": round(step_ms, 3), "warm_chain_ms": round(warm_chain, 3), "chain_only_ms": round(chain_only, 3),
+            "late_only_ms": round(late_only, 3), "warm_late_ms": round(warm_late, 3), "chain_launches": n_chain,
+            "cold": round(chain_only - warm_chain, 3), "interference": round(step_ms - tail_ms - chain_only, 3), "tail": round(tail_ms, 3),
+            "what": "step = warm_chain + cold + interference + tail; cold: chain graphs replayed without the late stream minus the sum of "
+                    "its launches replayed alone; interference: step minus tail minus chain-only (the losses / optimizer launches of the "
+                    "forward graph are part of the chain)"}
+
+
 def per_kernel_timing(ts, reps=3):
     """Times every kernel launch of one step with HIP events on the launch stream and aggregates the MFMA kernels
     by template instance: {kernel: (launches, total ms, algorithmic flops)} per step."""
@@ -398,6 +470,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-excess", action="store_true", help="skip the warm-chain / chain-only / late-only attribution of the step time")
     ap.add_argument("--inference", action="store_true",
                     help="SURVEY 8f N4: eval-mode forward only, replayed from one HIP graph (e.g. --batch 1 --height 416 --width 800)")
     ap.add_argument("--fp8", action="store_true",
@@ -582,6 +655,10 @@ def main():
     if rank == 0:
         fb = floor_budget(ts.plan)
         out["floor_ms"], out["step_over_floor"], out["floor_budget"] = fb["floor_ms"], round(ms / fb["floor_ms"], 3), fb
+    if rank == 0 and world == 1 and not a.no_excess and not a.no_graph and "exposed_tail_us" in out and a.update_interval == 1:
+        ex = excess_attribution(ts, ms, out["exposed_tail_us"]["median"] * 1e-3)
+        if ex is not None:
+            out["excess_ms"] = ex
     if rank == 0 and world == 1 and not a.no_roofline:
         out["forward_only"] = forward_only(model, batch, a.batch, a.height, a.width, a.variant)
     if world > 1:

@@ -421,11 +421,13 @@ __global__ __launch_bounds__(256) void k_quant_fp8_dev(const bf16_t* x, long lon
 }
 
 // one wave per tensor: the max over its amax slots -> scale = margin * amax / 448 (kept when nothing was recorded); slots zeroed
-__global__ __launch_bounds__(64) void k_fp8_scale_update(unsigned* slots, float* scales, float margin) {
+// unless keep (round 6: the three gradient slices of a decoder stage share one scale; just-in-time scaling takes the RUNNING max as
+// the stage's layers produce their slices, and only the last update of the stage clears the slots)
+__global__ __launch_bounds__(64) void k_fp8_scale_update(unsigned* slots, float* scales, float margin, int keep) {
   static_assert(CRD_FP8_AMAX_SLOTS == 64, "one slot per lane");
   unsigned* s_ = slots + (long long)blockIdx.x * CRD_FP8_AMAX_SLOTS;
   float m = __uint_as_float(s_[threadIdx.x]);
-  s_[threadIdx.x] = 0u;
+  if (!keep) s_[threadIdx.x] = 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
   if (threadIdx.x == 0 && m > 0.f) scales[blockIdx.x] = margin * m / E4M3_MAX;
@@ -504,9 +506,9 @@ extern "C" int crd_quant_fp8_dev(const void* x, int64_t rows, int32_t ld, int32_
   return CRD_OK;
 }
 
-extern "C" int crd_fp8_scale_update(uint32_t* amax_slots, float* scales, int32_t n, float margin, crd_stream_t stream) {
+extern "C" int crd_fp8_scale_update(uint32_t* amax_slots, float* scales, int32_t n, float margin, int32_t keep_slots, crd_stream_t stream) {
   CRD_CHECK_ARG(amax_slots && scales && n > 0 && margin > 0.f, "crd_fp8_scale_update: bad argument");
-  hipLaunchKernelGGL(k_fp8_scale_update, dim3(n), dim3(64), 0, as_stream(stream), reinterpret_cast<unsigned*>(amax_slots), scales, margin);
+  hipLaunchKernelGGL(k_fp8_scale_update, dim3(n), dim3(64), 0, as_stream(stream), reinterpret_cast<unsigned*>(amax_slots), scales, margin, keep_slots);
   CRD_LAUNCH_CHECK("crd_fp8_scale_update");
   return CRD_OK;
 }

@@ -559,6 +559,88 @@ __global__ __launch_bounds__(1024) void k_attn_scores(const bf16_t* q, const bf1
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Config 5 experiment (round 6, BASELINE.json configs[4] "fp8 MFMA attention"): the same scores with e4m3 operands --
+// s[n] = max_m bf16(bf16(qs ks (q8_n . k8_m)) * scale) -- on v_mfma_scale_f32_32x32x64_f8f6f4 (block scales 2^0): ONE K = 64 MFMA per
+// 32-key tile instead of four bf16 ones, half the operand bytes.  q8 / k8: per-tensor-scaled e4m3 copies, rows [heads][64] bytes (the
+// head dimension zero-padded to 64: two 16-byte granules per lane and no masking).  Everything behind the MFMA -- roundings, compare,
+// arg-max selects, the head sum -- is the bf16 kernel's.  Measured and NOT wired into the plan: see DESIGN.md "Round 6".
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_attn_scores_fp8(const unsigned char* q8, const unsigned char* k8, int N, int M, int heads,
+                                                          float qk_scale, float scale, float* S, short* idx, int qg) {
+  typedef __attribute__((ext_vector_type(8))) int i32x8;
+  typedef __attribute__((ext_vector_type(4))) int i32x4;
+  __shared__ float smax[16][32];
+  const int b = blockIdx.y;
+  const int l = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int h = wave % heads, g = wave / heads;
+  const int n0 = (blockIdx.x * qg + g) * 32;
+  const int n = n0 + (l & 31);
+  const bool nok = n < N;
+  const int half = l >> 5;
+  const int RS = heads * 64;                                          // bytes per row
+  const unsigned char* qrow = q8 + ((long long)b * N + (nok ? n : 0)) * RS + h * 64;
+  const unsigned char* kb = k8 + (long long)b * M * RS + h * 64;
+  // a lane's operand: 32 of the row's 64 bytes -- granules `half` and 2 + `half`, the same choice for keys and queries
+  const i32x4 q_lo = *reinterpret_cast<const i32x4*>(qrow + half * 16), q_hi = *reinterpret_cast<const i32x4*>(qrow + (2 + half) * 16);
+  const i32x8 qf = __builtin_shufflevector(q_lo, q_hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  const int SC = 0x7f7f7f7f;
+  float best = -INFINITY;
+  int besti = 0;
+  auto load_keys = [&](int m0, i32x4 (&dst)[2]) {
+    int mrow = m0 + (l & 31);
+    mrow = mrow < M ? mrow : M - 1;
+    const unsigned char* rowp = kb + (long long)mrow * RS;
+    dst[0] = *reinterpret_cast<const i32x4*>(rowp + half * 16);
+    dst[1] = *reinterpret_cast<const i32x4*>(rowp + (2 + half) * 16);
+  };
+  auto score_tile = [&](int m0, const i32x4 (&kt)[2]) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const i32x8 kf = __builtin_shufflevector(kt[0], kt[1], 0, 1, 2, 3, 4, 5, 6, 7);
+    acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf, acc, 0, 0, 0, SC, 0, SC);
+    const bool edge = m0 + 32 > M;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const int ma = m0 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      const uint32_t p1 = pack_bf2(acc[r] * qk_scale, acc[r + 1] * qk_scale);
+      const uint32_t p2 = pack_bf2(bf_lo(p1) * scale, bf_hi(p1) * scale);
+      float va = bf_lo(p2), vb = bf_hi(p2);
+      if (edge) { va = ma < M ? va : -INFINITY; vb = ma + 1 < M ? vb : -INFINITY; }
+      const bool ta = va > best;
+      best = ta ? va : best;
+      besti = ta ? ma : besti;
+      const bool tb = vb > best;
+      best = tb ? vb : best;
+      besti = tb ? ma + 1 : besti;
+    }
+  };
+  i32x4 ring[4][2];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) load_keys(j * 32, ring[j]);
+  for (int m0 = 0; m0 < M; m0 += 128) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      score_tile(m0 + j * 32, ring[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      load_keys(m0 + j * 32 + 128, ring[j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float ob = __shfl_xor(best, 32);
+  int oi = __shfl_xor(besti, 32);
+  if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+  if (nok && half == 0) idx[((long long)b * N + n) * heads + h] = (short)besti;
+  if (half == 0) smax[wave][l] = best;
+  __syncthreads();
+  if (h == 0 && half == 0 && nok) {
+    float Ssum = 0.f;
+    for (int hh = 0; hh < heads; ++hh) Ssum += smax[g * heads + hh][l];
+    S[(long long)b * N + n] = Ssum;
+  }
+}
+
 // xbar[b][c] = mean_n GN(x)[b][n][c] = gamma_c*(mean_n x_c - mu_g)*rstd_g + beta_c   (bf16 out)
 __global__ void k_attn_xbar(const crd_sum_t* chan, const crd_sum_t* stats, const float* gamma, const float* beta, int N, int C,
                             bf16_t* xbar) {
@@ -968,6 +1050,21 @@ static int attn_scores_launch(const void* q, const void* k, int32_t B, int32_t N
 extern "C" int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
                                float scale, float* S, int16_t* idx, crd_stream_t stream) {
   return attn_scores_launch(q, k, B, N, M, heads, d, scale, S, idx, XbarProj{}, "crd_attn_scores", stream);
+}
+
+extern "C" int crd_attn_scores_fp8(const void* q8, const void* k8, int32_t B, int32_t N, int32_t M, int32_t heads, float qk_scale,
+                                   float scale, float* ssum, int16_t* idx, crd_stream_t stream) {
+  CRD_CHECK_ARG(q8 && k8 && ssum && idx && B > 0 && N > 0 && M > 0 && qk_scale > 0.f, "crd_attn_scores_fp8: bad argument");
+  CRD_UNSUPPORTED(heads >= 1 && heads <= 16, "crd_attn_scores_fp8: at most 16 heads");
+  CRD_CHECK_ARG((reinterpret_cast<uintptr_t>(q8) & 15) == 0 && (reinterpret_cast<uintptr_t>(k8) & 15) == 0, "crd_attn_scores_fp8: 16-byte aligned operands");
+  int qg = 8 / heads;                                    // query groups per workgroup: the bf16 kernel's rule (the comparison is like for like)
+  if (qg < 1) qg = 1;
+  if (qg > 4) qg = 4;
+  hipLaunchKernelGGL(k_attn_scores_fp8, dim3(cdiv(N, 32 * qg), B), dim3(64 * heads * qg), 0, as_stream(stream),
+                     reinterpret_cast<const unsigned char*>(q8), reinterpret_cast<const unsigned char*>(k8), N, M, heads, qk_scale, scale, ssum,
+                     reinterpret_cast<short*>(idx), qg);
+  CRD_LAUNCH_CHECK("crd_attn_scores_fp8");
+  return CRD_OK;
 }
 
 extern "C" int crd_attn_fwd(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d, float scale,

@@ -285,6 +285,7 @@ class Plan:
         self.fp8_keep_bf16 = bool(training or self.need_grad)
         self.fp8 = dict(f8) if (f8 and (not self.fp8_keep_bf16 or getattr(model, "fp8_train", False))) else None
         self.fp8_convs = []
+        self.fp8_kcat = []                 # (first layer ConvW, K-concatenated bf16 data-gradient matrix, rows, K, its e4m3 copy, per-row scales)
         # fp8 DATA GRADIENTS of the same ConvLayers (round 5; model.calibrate_fp8(x, train=True, grads=True)): per layer one device
         # float (the e4m3 scale of its dy) and CRD_FP8_AMAX_SLOTS amax slots.  fp8_jit True: just-in-time scaling -- the layer's scale
         # is set from THIS step's amax and dy re-quantised before its data gradient runs (one extra pass; eager plans and the
@@ -570,10 +571,10 @@ class Plan:
             self.keep.append(d)
             return C.byref(d)
         if sp.get("fp8d"):
-            cw, y = sp["cw"], sp["y"]
+            y = sp["y"]
             d = L.ConvDesc()
             d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = sp["x8"].data_ptr(), sp["x8_ld"], 0, self.B, sp["H"], sp["W"], sp["cin"]
-            d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = cw.w8d.data_ptr(), sp["cout"], 3, 3, 1, 1, sp["H"], sp["W"]
+            d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = sp["w8"].data_ptr(), sp["cout"], 3, 3, 1, 1, sp["H"], sp["W"]
             d.gather_mode, d.y, d.y_ld, d.y_coff, d.accumulate = 1, P(y), y.ld, y.coff, sp["accumulate"]
             self.keep.append(d)
             return C.byref(d)
@@ -730,38 +731,40 @@ class Plan:
             return
         grp = []
         draw = kcat["draw"] if kcat is not None else self.act(cw.cout, H, W)
-        # e4m3 data gradient where it pays -- measured per kernel at B = 16 (profiles/r05_c5_decoder_backward_chain_*.txt): the 128 -> 304 /
-        # 296 layers, whose data gradient is the first writer of the concat gradient and MFMA-bound (1092 -> 859 us, 308 -> 238 us); the
-        # 64- and 96-channel layers ACCUMULATE into it and are bound by that read-modify-write (652 -> 679, 644 -> 684 us in e4m3, plus
-        # 28-44 us per layer for the e4m3 copy of dy): they keep the bf16 kernel.  (developer switch CRD_FP8_GRAD_ALL: all six, as measured)
-        if (x8 is not None and self.fp8_grad and dx is not None and not cw.frozen
-                and (cw.cout >= 128 or _dev_flag("CRD_FP8_GRAD_ALL"))):
-            # e4m3 data gradient: the GroupNorm backward writes bf16 d(raw) (the weight gradient reads it) AND its e4m3 copy
-            li = len(self.fp8_grad_layers)
-            assert li < self.g8_scales.numel()
-            self.fp8_grad_layers.append(name)
-            c16 = rup(cw.cout, 16)
-            draw8 = self.new((self.B, H * W, c16), torch.uint8)
-            sc_ptr, am_ptr = self.g8_scales.data_ptr() + 4 * li, self.g8_amax.data_ptr() + 4 * 64 * li
+        f8g = kcat.get("f8") if kcat is not None else None
+        if f8g is not None:
+            # Config 5 (round 6): ALL the stage's data gradients in e4m3 on the K-concatenated buffer.  This layer's GroupNorm backward writes
+            # its bf16 slice of d(raw) (the weight gradient reads it) AND the e4m3 copy of that slice, quantised with the STAGE's scale (one
+            # device float for the three slices: a launch multiplies its accumulators by ONE activation scale); the write-once launch behind
+            # it reads the e4m3 K prefix.  Round 5 ran the e4m3 kernel on the first-writer layer only: the accumulating 64 / 96-channel
+            # launches were bound by the read-modify-write of the concat gradient, which the write-once form removes.
+            # Scaling: delayed (TrainStep's graphs) -- the previous step's max over the three slices, updated once at the head of the
+            # backward pass; just-in-time (eager plans, the calibration iteration) -- the running max of the slices produced so far, and the
+            # whole K prefix re-quantised with it before each launch.
+            draw8, ld8, sc_ptr, am_ptr = f8g["draw8"], f8g["ld8"], f8g["sc_ptr"], f8g["am_ptr"]
+            xcat, Wt, n0, n1, dcb, real = kcat["launch"]
+            K = xcat.C
             gname = name + ".model.1"
             common = [raw.t, raw.f32, raw.ld, raw.coff, dout.t, dout.f32, dout.ld, dout.coff, self.B, raw.P, raw.C, stats, 1,
                       self.p(gname + ".weight"), self.p(gname + ".bias"), 1, mask]
             r = self.zb(self.B * raw.C * 2 + self.B * (raw.C // 16) * 2)
             self._emit(grp, "crd_gn_bwd_reduce", common + [r, None, 0], io=nbytes(raw, dout))
             self._emit(grp, "crd_gn_bwd_apply_fp8", common + [r, self.g(gname + ".weight"), self.g(gname + ".bias"), draw.t, draw.ld, draw.coff,
-                                                              draw8, c16, 0, sc_ptr, am_ptr], io=nbytes(raw, dout, draw) + self.B * H * W * c16)
-            self._emit(grp, "crd_fp8_scale_update", [am_ptr, sc_ptr, 1, self.fp8_margin], io=256).cond = ("fp8_jit", True)
-            self._emit(grp, "crd_quant_fp8_dev", [draw.t, self.B * H * W, draw.ld, draw.coff, cw.cout, draw8, c16, 0, sc_ptr],
-                       io=nbytes(draw) + self.B * H * W * c16).cond = ("fp8_jit", True)
+                                                              draw8, ld8, draw.coff, sc_ptr, am_ptr], io=nbytes(raw, dout, draw) + self.B * H * W * cw.cout)
+            self._emit(grp, "crd_fp8_scale_update", [am_ptr, sc_ptr, 1, self.fp8_margin, f8g["keep"]], io=256).cond = ("fp8_jit", True)
+            self._emit(grp, "crd_quant_fp8_dev", [xcat.t, self.B * H * W, xcat.ld, 0, K, draw8, ld8, 0, sc_ptr],
+                       io=nbytes(xcat) + self.B * H * W * K).cond = ("fp8_jit", True)
             self.wgrad(grp, x, draw, cw, k, 1, k // 2, H, W)
-            cw.w8d = self.new((cw.cin_pad, 9, c16), torch.uint8)
-            cw.w8d_scales = self.new((cw.cin_pad,), F32)
-            spec = dict(fp8d=True, x8=draw8, x8_ld=c16, cin=c16, H=H, W=W, cw=cw, y=dx, cout=dx.C, accumulate=0)
-            meta = {"kernel": "k_conv3x3_fp8<dgrad>", "flops": 2.0 * self.B * H * W * cw.cout * 9 * min(dx.C, cw.cin_ref),
-                    "shape": f"dgrad fp8 Cin{c16} Cout{dx.C} k3 s1 out{H}x{W}"}
-            grp.append(Op(self.lib.crd_conv3x3_fp8_dgrad, [spec, cw.w8d_scales, sc_ptr], "crd_conv3x3_fp8_dgrad", dx_region,
-                          ("spec", spec) if dx_region else None, meta,
-                          io=lambda spec=spec, n0=self.B * H * W * c16 + dx.C * 9 * c16: n0 + nbytes(spec["y"]) * (2 if spec["accumulate"] else 1)))
+            for (Wt_, ld, coff, row0, rows) in kcat["packs"]:
+                self.kcat_entries.append((cw, Wt_, ld, coff, row0, rows))
+            W8 = self.new((n1 - n0, 9, K), torch.uint8)
+            W8s = self.new((n1 - n0,), F32)
+            self.fp8_kcat.append((cw, Wt, n1 - n0, K, W8, W8s))
+            spec = dict(fp8d=True, x8=draw8, x8_ld=ld8, cin=K, H=H, W=W, w8=W8, y=dcb.sl(n0, n1), cout=n1 - n0, accumulate=0)
+            meta = {"kernel": "k_conv3x3_fp8<dgrad>", "flops": 2.0 * self.B * H * W * 9 * real,
+                    "shape": f"dgrad-kcat fp8 Cin{K} Cout{n1 - n0} k3 s1 out{H}x{W}"}
+            grp.append(Op(self.lib.crd_conv3x3_fp8_dgrad, [spec, W8s, sc_ptr], "crd_conv3x3_fp8_dgrad", ("dcb", id(dcb.t), n0, n1),
+                          ("spec", spec), meta, io=self.B * H * W * K + (n1 - n0) * 9 * K + nbytes(dcb.sl(n0, n1))))
             self._push(grp)
             return
         self.gn_bwd(grp, raw, stats, 1, name + ".model.1", 1, mask, dout, draw)
@@ -895,6 +898,23 @@ class Plan:
                 mp += [base + 96 + c for c in range(64)]
             return mp
 
+        def kcat_plan(j, dcb, Hj, Wj, o0, o1):
+            """The write-once data gradients of stage j's three ConvLayers: the K-concatenated d(raw) buffer [layer 2 (128) | layer 1 (64) |
+            layer 0 (96)] and the three weight matrices WA = concat channels [o1, o1 + 64) x K 128, WB [o0, o1) x K 192, WC [0, o0) x K 288;
+            per layer (index = layer): where its GroupNorm backward writes, where its weights are packed, the launch issued behind it."""
+            DRAW = self.act(288, Hj, Wj)
+            WA, WB, WC = self.new((64, 9, 128)), self.new((96, 9, 192)), self.new((o0, 9, 288))
+            real0 = cup[j] + cskip[j]                       # reference channels among the o0 padded ones
+            kc = [None, None, None]
+            # (last entry of `launch`: algorithmic MACs per pixel and tap = (channels of the layers feeding it) x (reference columns it produces))
+            kc[2] = dict(draw=DRAW.sl(0, 128), packs=[(WA, 128, 0, o1, 64), (WB, 192, 0, o0, 96), (WC, 288, 0, 0, o0)],
+                         launch=(DRAW.sl(0, 128), WA, o1, o1 + 64, dcb, 128 * 64))
+            kc[1] = dict(draw=DRAW.sl(128, 192), packs=[(WB, 192, 128, o0, 96), (WC, 288, 128, 0, o0)],
+                         launch=(DRAW.sl(0, 192), WB, o0, o1, dcb, 192 * 96))
+            kc[0] = dict(draw=DRAW.sl(192, 288), packs=[(WC, 288, 192, 0, o0)],
+                         launch=(DRAW.sl(0, 288), WC, 0, o0, dcb, 288 * real0))
+            return kc
+
         def stage(j, name, cb, dcb, up_src, d_up_src, up_region, out, dout, mask):
             """Decoder stage (utils.py:249-257 + ShortResBlock :127-135) on concat buffer cb."""
             up_p, sk_p = lay[j]
@@ -922,15 +942,27 @@ class Plan:
                     op.io = lambda op=op, n=nbytes(up_src.sl(0, up_p)): n * (5 + (1 if op.args[-1] else 0))
                     self._push(grp)
                 bw = lambda c0, c1: dict(dout=dcb.sl(c0, c1), dx=dcb.sl(0, c0), dx_region=("dcb", id(dcb), 0, c0)) if keep else {}
+                kc = [None, None, None]
+                if keep and KCAT:
+                    kc = kcat_plan(j, dcb, Hj, Wj, o0, o1)
+                    if self.fp8_grad:
+                        # e4m3 data gradients of the whole stage: one e4m3 copy of the K-concatenated d(raw) buffer, one scale for it
+                        si = len(self.fp8_grad_layers)
+                        assert si < self.g8_scales.numel()
+                        self.fp8_grad_layers.append(name)
+                        DRAW8 = self.new((B, Hj * Wj, 288), torch.uint8)
+                        for li_, keep_ in ((2, 1), (1, 1), (0, 0)):      # backward order: layer 2 first, layer 0 closes the stage's running max
+                            kc[li_]["f8"] = dict(draw8=DRAW8, ld8=288, sc_ptr=self.g8_scales.data_ptr() + 4 * si,
+                                                 am_ptr=self.g8_amax.data_ptr() + 4 * 64 * si, keep=keep_)
                 self._cmap = cat_map(j, 0)
                 self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, cb.sl(o0, o0 + 96) if keep else None, x8=(cb8, ld8, sc8),
-                                out8=(cb8, ld8, o0, sc8), **bw(o0, o0 + 96))
+                                out8=(cb8, ld8, o0, sc8), kcat=kc[0], **bw(o0, o0 + 96))
                 self._cmap = cat_map(j, 1)
                 self.conv_layer(f"{name}.conv.layers.1", cb.sl(0, o1), 3, cb.sl(o1, o1 + 64) if keep else None, x8=(cb8, ld8, sc8),
-                                out8=(cb8, ld8, o1, sc8), **bw(o1, o1 + 64))
+                                out8=(cb8, ld8, o1, sc8), kcat=kc[1], **bw(o1, o1 + 64))
                 self._cmap = cat_map(j, 2)
                 last = dict(dout=dout, dx=dcb.sl(0, o1 + 64), dx_region=("dcb", id(dcb), 0, o1 + 64)) if keep else {}
-                self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, x8=(cb8, ld8, sc8), **last)
+                self.conv_layer(f"{name}.conv.layers.2", cb.sl(0, o1 + 64), 3, out, mask=mask, x8=(cb8, ld8, sc8), kcat=kc[2], **last)
                 self._cmap = None
                 return
             self._emit(self.fwd, "crd_bicubic2x", [up_src.t, up_src.ld, up_src.coff, B, up_src.H, up_src.W, up_p, cb.t, cb.ld, 0],
@@ -940,20 +972,7 @@ class Plan:
             op = self._emit(grp, "crd_bicubic2x_bwd", args, up_region, len(args) - 1)
             op.io = lambda op=op, n=nbytes(up_src.sl(0, up_p)): n * (5 + (1 if op.args[-1] else 0))
             self._push(grp)
-            kc = [None, None, None]
-            if KCAT:
-                # K-concatenated d(raw) buffer [layer 2 (128) | layer 1 (64) | layer 0 (96)] and the three weight matrices of the
-                # write-once data gradients: WA rows = concat channels [o1, o1 + 64) x K 128, WB [o0, o1) x K 192, WC [0, o0) x K 288
-                DRAW = self.act(288, Hj, Wj)
-                WA, WB, WC = self.new((64, 9, 128)), self.new((96, 9, 192)), self.new((o0, 9, 288))
-                real0 = cup[j] + cskip[j]                       # reference channels among the o0 padded ones
-                # algorithmic MACs per pixel and tap of each launch: (layers feeding it) x (reference columns it produces)
-                kc[2] = dict(draw=DRAW.sl(0, 128), packs=[(WA, 128, 0, o1, 64), (WB, 192, 0, o0, 96), (WC, 288, 0, 0, o0)],
-                             launch=(DRAW.sl(0, 128), WA, o1, o1 + 64, dcb, 128 * 64))
-                kc[1] = dict(draw=DRAW.sl(128, 192), packs=[(WB, 192, 128, o0, 96), (WC, 288, 128, 0, o0)],
-                             launch=(DRAW.sl(0, 192), WB, o0, o1, dcb, 192 * 96))
-                kc[0] = dict(draw=DRAW.sl(192, 288), packs=[(WC, 288, 192, 0, o0)],
-                             launch=(DRAW.sl(0, 288), WC, 0, o0, dcb, 288 * real0))
+            kc = kcat_plan(j, dcb, Hj, Wj, o0, o1) if KCAT else [None, None, None]
             self._cmap = cat_map(j, 0)
             self.conv_layer(f"{name}.conv.layers.0", cb.sl(0, o0), 3, cb.sl(o0, o0 + 96), dout=dcb.sl(o0, o0 + 96),
                             dx=dcb.sl(0, o0), dx_region=("dcb", id(dcb), 0, o0), kcat=kc[0])
@@ -1486,7 +1505,7 @@ class Plan:
         if self.fp8_grad_layers:
             # delayed scaling: the scales every layer of this pass quantises with = the amax its dy had in the PREVIOUS pass
             self.bwd_groups[-1].insert(0, Op(self.lib.crd_fp8_scale_update, [self.g8_amax.data_ptr(), self.g8_scales.data_ptr(),
-                                                                             len(self.fp8_grad_layers), self.fp8_margin],
+                                                                             len(self.fp8_grad_layers), self.fp8_margin, 0],
                                              "crd_fp8_scale_update", io=256 * len(self.fp8_grad_layers), cond=("fp8_jit", False)))
         for grp, tag in zip(reversed(self.bwd_groups), reversed(self.bwd_tags)):
             if self.bwd_segments and self.bwd_segments[-1][0] == tag:
@@ -1605,9 +1624,10 @@ class Plan:
             if (lo is None or off >= lo) and (hi is None or off < hi):
                 L.check(self.lib.crd_weight_quant_fp8(cw.w_fwd.data_ptr(), cw.cout, 9, cw.cin_pad, cin16, cw.w8.data_ptr(),
                                                       cw.w8_scales.data_ptr(), st), "crd_weight_quant_fp8")
-                if getattr(cw, "w8d", None) is not None:      # data-gradient weights [Cin_pad][9][Cout_pad]: one scale per INPUT channel
-                    L.check(self.lib.crd_weight_quant_fp8(cw.w_dgrad.data_ptr(), cw.cin_pad, 9, cw.cout_pad, cw.w8d.shape[2],
-                                                          cw.w8d.data_ptr(), cw.w8d_scales.data_ptr(), st), "crd_weight_quant_fp8")
+        for cw, Wt, rows, K, W8, W8s in self.fp8_kcat:       # the K-concatenated data-gradient matrices: one e4m3 scale per concat channel (row)
+            off = (self.p(cw.name + ".weight").data_ptr() - base) // 4
+            if (lo is None or off >= lo) and (hi is None or off < hi):
+                L.check(self.lib.crd_weight_quant_fp8(Wt.data_ptr(), rows, 9, K, K, W8.data_ptr(), W8s.data_ptr(), st), "crd_weight_quant_fp8")
         if lo is None and hi is None:
             self.packed_version = getattr(self.model, "_param_version", 0)
 

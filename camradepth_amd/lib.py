@@ -128,11 +128,11 @@ def load():
 _SIGS = {
     "crd_conv_igemm": "pp", "crd_gn_conv": "ppp", "crd_gn_bwd_conv": "ppp", "crd_pw_narrow_supported": "iii", "crd_tune_pw_narrow": "i", "crd_conv3x3_fp8": "ppfp", "crd_amax_bf16": "pliiipp", "crd_quant_fp8": "pliiipiifp",
     "crd_weight_quant_fp8": "piiiippp", "crd_conv3x3_fp8_dgrad": "pppp", "crd_gn_bwd_apply_fp8": "piiipiiiiiipippipppppiipiippp",
-    "crd_fp8_scale_update": "ppifp", "crd_quant_fp8_dev": "pliiipiipp", "crd_tune_conv3x3_small_grid": "i", "crd_tune_igemm_reg_epilogue": "i", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
+    "crd_fp8_scale_update": "ppifip", "crd_quant_fp8_dev": "pliiipiipp", "crd_tune_conv3x3_small_grid": "i", "crd_tune_igemm_reg_epilogue": "i", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),
     "crd_gn_bwd_reduce": "piiipiiiiiipippippplp", "crd_gn_bwd_apply": "piiipiiiiiipippipppppiiiipipp",
     "crd_dwconv3x3": "piiiippipppippppppp", "crd_dwconv3x3_wgrad": "ppiiiipipippp",
-    "crd_attn_scores": "ppiiiiifppp", "crd_attn_fwd": "ppiiiiifpppppppppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_xbar_proj": "pppppiiippp", "crd_attn_vec_bwd": "ppiiifppp", "crd_attn_out_residual": "pppppiiipp", "crd_attn_out_residual_stats": "pppppiiippp",
+    "crd_attn_scores": "ppiiiiifppp", "crd_attn_scores_fp8": "ppiiiiffppp", "crd_attn_fwd": "ppiiiiifpppppppppp", "crd_attn_xbar": "ppppiiipp", "crd_attn_xbar_proj": "pppppiiippp", "crd_attn_vec_bwd": "ppiiifppp", "crd_attn_out_residual": "pppppiiipp", "crd_attn_out_residual_stats": "pppppiiippp",
     "crd_attn_out_bwd": "ppppiiipppp", "crd_attn_out_bwd_gn": "ppppiiippppppppppp", "crd_attn_scores_bwd": "ppppiiiiifpppp", "crd_attn_bwd": "ppppiiiiifpppppifppp", "crd_attn_scores_bwd_partials": "iiiii", "crd_sum_partials_bf16": "pilplp", "crd_gsum_to_bf16": "pplp",
     "crd_bicubic2x": "piiiiiipiip", "crd_bicubic2x_fp8": "piiiiiipiifpiip", "crd_gn_apply_fp8": "piiiiiipippippiifpiip", "crd_bicubic2x_bwd": "piiiiiipiiip",
     "crd_nchw_to_pm": "piiiipiiip", "crd_pm_to_nchw": "piiiiiiipp", "crd_seg_argmax": "piiiiipiiip", "crd_scale_f32": "pplfp",

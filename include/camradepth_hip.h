@@ -227,9 +227,11 @@ int crd_gn_bwd_apply_fp8(const void* x, int32_t x_f32, int32_t x_ld, int32_t x_c
                          void* dx_fp8, int32_t dx8_ld, int32_t dx8_coff, const float* scale_dev, uint32_t* amax_slots,
                          crd_stream_t stream);
 /* For each of n tensors: a = max over amax_slots[i][0..CRD_FP8_AMAX_SLOTS); if a > 0: scales[i] = margin * a / 448; the slots are
- * zeroed.  Delayed scaling: called once per step behind the backward pass; with n = 1 right behind crd_gn_bwd_apply_fp8 it is
- * just-in-time scaling (the calibration iteration and the eager module path: followed by crd_quant_fp8_dev). */
-int crd_fp8_scale_update(uint32_t* amax_slots, float* scales, int32_t n, float margin, crd_stream_t stream);
+ * zeroed unless keep_slots.  Delayed scaling: called once per step at the head of the backward pass; with n = 1 right behind
+ * crd_gn_bwd_apply_fp8 it is just-in-time scaling (the calibration iteration and the eager module path: followed by
+ * crd_quant_fp8_dev).  Round 6: one scale per decoder STAGE (its three K-concatenated gradient slices): just-in-time updates behind the
+ * first two layers keep the slots (running max), the third clears them. */
+int crd_fp8_scale_update(uint32_t* amax_slots, float* scales, int32_t n, float margin, int32_t keep_slots, crd_stream_t stream);
 /* crd_quant_fp8 with the scale read from device memory */
 int crd_quant_fp8_dev(const void* x, int64_t rows, int32_t ld, int32_t coff, int32_t C, void* y, int32_t y_ld, int32_t y_coff,
                       const float* scale_dev, crd_stream_t stream);
@@ -380,6 +382,13 @@ int crd_mlp_reduce(const float* fc2_partials, int32_t slabs, const float* x1, co
  * ------------------------------------------------------------------------------------------- */
 int crd_attn_scores(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d,
                     float scale, float* S, int16_t* idx, crd_stream_t stream);
+/* Config 5 experiment (round 6; BASELINE.json configs[4] "fp8 MFMA attention"): crd_attn_scores on e4m3 operands
+ * (v_mfma_scale_f32_32x32x64_f8f6f4, one K = 64 MFMA per 32-key tile).  q8 [B][N][heads][64], k8 [B][M][heads][64]: e4m3(x / scale) per
+ * tensor, the head dimension zero-padded to 64 bytes (crd_quant_fp8 per head into a zeroed buffer); qk_scale = q_scale * k_scale;
+ * s = max_m bf16(bf16(qk_scale * (q8 . k8)) * scale), outputs as crd_attn_scores.  Measured against the bf16 kernel and NOT used by the
+ * plan (DESIGN.md "Round 6": the kernel is bound by the arg-max bookkeeping behind the MFMA, not by the MFMA or its operand bytes). */
+int crd_attn_scores_fp8(const void* q8, const void* k8, int32_t B, int32_t N, int32_t M, int32_t heads, float qk_scale, float scale,
+                        float* ssum, int16_t* idx, crd_stream_t stream);
 /* crd_attn_scores and crd_attn_xbar_proj in ONE launch (the value path is one extra workgroup per sample; it only needs
  * norm1's sums, so it rides along with the scores): arguments as in the two calls, C = heads * d. */
 int crd_attn_fwd(const void* q, const void* k, int32_t B, int32_t N, int32_t M, int32_t heads, int32_t d, float scale,

@@ -140,16 +140,19 @@ def _conv2d_fp8(x, w, x_scale, **kw):
 
 
 class _Fp8ConvTrain(torch.autograd.Function):
-    """The e4m3 convolution of config 5 WITH its e4m3 data gradient (camradepth_amd round 5: crd_conv3x3_fp8 /
-    crd_conv3x3_fp8_dgrad; no reference counterpart -- the reference trains under fp16 autocast, runner.py:191).  Forward:
-    _conv2d_fp8.  Backward: dy rounded to bf16 (what the GroupNorm backward stores), quantised per tensor with g_scale, the bf16
-    weights quantised per INPUT channel (scale = max over (cout, taps) / 448, 1 for an all-zero channel), dx = the transposed
-    convolution of the de-quantised pair rounded to bf16; dw = the bf16 weight gradient of the bf16 activations and the bf16 dy."""
+    """The e4m3 convolution of config 5 WITH its e4m3 data gradient (camradepth_amd: crd_conv3x3_fp8 / crd_conv3x3_fp8_dgrad; no
+    reference counterpart -- the reference trains under fp16 autocast, runner.py:191: this is a BUILDER-DEFINED emulation of what the
+    HIP kernels do, not a restatement of the reference).  Forward: _conv2d_fp8.  Backward: dy rounded to bf16 (what the GroupNorm
+    backward stores), quantised per tensor with g_scale, the bf16 weights quantised per INPUT channel with the scales `ws` (round 6: the
+    three layers of a ShortResBlock share them -- kcat_weight_scales -- as the K-concatenated write-once data gradients of the HIP path
+    quantise one matrix row per concat channel; ws None: this layer's own max over (cout, taps) / 448, 1 for an all-zero channel),
+    dx = the transposed convolution of the de-quantised pair rounded to bf16; dw = the bf16 weight gradient of the bf16 activations and
+    the bf16 dy."""
 
     @staticmethod
-    def forward(ctx, x, w, x_scale, g_scale, pad):
+    def forward(ctx, x, w, x_scale, g_scale, pad, ws=None):
         ctx.save_for_backward(x, w)
-        ctx.g_scale, ctx.pad = g_scale, pad
+        ctx.g_scale, ctx.pad, ctx.ws = g_scale, pad, ws
         return _conv2d_fp8(x, w, x_scale, padding=pad)
 
     @staticmethod
@@ -159,22 +162,38 @@ class _Fp8ConvTrain(torch.autograd.Function):
         gs = torch.tensor(ctx.g_scale, dtype=torch.float32)
         gq = _e4m3(gb * (1.0 / gs)) * gs
         wb = _q(w, "bf16")
-        am = wb.abs().amax(dim=(0, 2, 3))
-        ws = torch.where(am > 0, am / E4M3_MAX, torch.ones_like(am))
+        if ctx.ws is None:
+            am = wb.abs().amax(dim=(0, 2, 3))
+            ws = torch.where(am > 0, am / E4M3_MAX, torch.ones_like(am))
+        else:
+            ws = ctx.ws[:w.shape[1]]
         wq = _e4m3(wb * (1.0 / ws).view(1, -1, 1, 1)) * ws.view(1, -1, 1, 1)
         dx = _q(F.conv_transpose2d(gq, wq, padding=ctx.pad), "bf16") if ctx.needs_input_grad[0] else None
         dw = torch.nn.grad.conv2d_weight(_q(x, "bf16"), w.shape, gb, padding=ctx.pad) if ctx.needs_input_grad[1] else None
-        return dx, dw, None, None, None
+        return dx, dw, None, None, None, None
 
 
-def conv_layer(sd, name, x, k, quant=None, fp8_scale=None, fp8_gscales=None):
+def kcat_weight_scales(ws_list):
+    """Per concat channel n: max over the ShortResBlock layers that read channel n of max_{cout, tap} |bf16(w)[cout, n, tap]| / 448 (1 for a
+    channel that is zero everywhere) -- the per-row scales of the HIP path's K-concatenated data-gradient matrices (crd_weight_quant_fp8 on
+    [rows][9][K])."""
+    n = max(w.shape[1] for w in ws_list)
+    am = torch.zeros(n)
+    for w in ws_list:
+        a = _q(w.detach(), "bf16").abs().amax(dim=(0, 2, 3))
+        am[:a.numel()] = torch.maximum(am[:a.numel()], a)
+    return torch.where(am > 0, am / E4M3_MAX, torch.ones_like(am))
+
+
+def conv_layer(sd, name, x, k, quant=None, fp8_scale=None, fp8_gscales=None, fp8_ws=None):
     """ConvLayer.forward: conv(no bias) -> GroupNorm(Cout/16) -> GELU (reference: src/utils/utils.py:210-228).
-    fp8_gscales: {layer name: e4m3 scale of its dy} -- the layers listed there also take their DATA gradient in e4m3."""
+    fp8_gscales: {layer name: e4m3 scale of its dy} -- the layers listed there also take their DATA gradient in e4m3 (fp8_ws: the
+    per-input-channel weight scales shared by the block's layers)."""
     w = sd[name + ".model.0.weight"]
     if fp8_scale is None:
         y = _conv2d(x, w, None, quant, padding=k // 2)
     elif torch.is_grad_enabled() and (x.requires_grad or w.requires_grad) and fp8_gscales and name in fp8_gscales:
-        y = _Fp8ConvTrain.apply(x, w, fp8_scale, float(fp8_gscales[name]), k // 2)
+        y = _Fp8ConvTrain.apply(x, w, fp8_scale, float(fp8_gscales[name]), k // 2, fp8_ws)
     elif torch.is_grad_enabled() and (x.requires_grad or w.requires_grad):
         # fp8 forward inside a training step: the value of the fp8 convolution, the gradient of the bf16 one (what the HIP
         # path does: data and weight gradients are the bf16 kernels on the bf16 activations / weights)
@@ -189,10 +208,13 @@ def conv_layer(sd, name, x, k, quant=None, fp8_scale=None, fp8_gscales=None):
 
 def short_res_block(sd, name, x, quant=None, fp8_scale=None, fp8_gscales=None):
     """ShortResBlock.forward (reference: src/utils/utils.py:127-135)."""
+    ws = None
+    if fp8_gscales and all(f"{name}.layers.{li}" in fp8_gscales for li in range(3)):
+        ws = kcat_weight_scales([sd[f"{name}.layers.{li}.model.0.weight"] for li in range(3)])
     for li in range(2):
-        out = conv_layer(sd, f"{name}.layers.{li}", x, 3, quant, fp8_scale, fp8_gscales)
+        out = conv_layer(sd, f"{name}.layers.{li}", x, 3, quant, fp8_scale, fp8_gscales, ws)
         x = torch.cat((x, out), dim=1)
-    return conv_layer(sd, f"{name}.layers.2", x, 3, quant, fp8_scale, fp8_gscales)
+    return conv_layer(sd, f"{name}.layers.2", x, 3, quant, fp8_scale, fp8_gscales, ws)
 
 
 def bicubic2x(x):

@@ -394,7 +394,7 @@ def test_gn_bwd_apply_fp8_equals_the_bf16_kernel_plus_quantisation():
         assert amax == float(dx.float().abs().max()) and int((slots != 0).sum()) > 1                  # spread over several slots
         scales = torch.tensor([7.0, 9.0], device="cuda")
         two = torch.stack([slots, torch.zeros_like(slots)]).contiguous()
-        lib.check(L.crd_fp8_scale_update(two.data_ptr(), scales.data_ptr(), 2, 1.0, lib.stream()), "scale_update")
+        lib.check(L.crd_fp8_scale_update(two.data_ptr(), scales.data_ptr(), 2, 1.0, 0, lib.stream()), "scale_update")
         torch.cuda.synchronize()
         assert abs(float(scales[0]) - amax / 448.0) <= 1e-7 * amax and float(scales[1]) == 9.0          # nothing recorded: the scale is kept
         assert int(two.abs().max()) == 0
@@ -424,15 +424,16 @@ def _fp8_grad_step_vs_oracle(depths, B, H, W, seed=77, reference_init=False):
     out = model(x, masks=masks)
     plan = model._plans[model._plan_key(x)]
     n8 = sum(op.name == "crd_conv3x3_fp8_dgrad" for op in plan.bwd)
-    # stages with >= 192 tiles of 16 x 32 pixels take the fp8 route (B = 2: the full-resolution stage only); per stage the e4m3 DATA
-    # gradient runs for the 128-channel layer (the MFMA-bound first writer of the concat gradient; all three with CRD_FP8_GRAD_ALL)
-    per_stage = 3 if (os.environ.get("CRD_DEV_SWITCHES") == "1" and os.environ.get("CRD_FP8_GRAD_ALL") is not None) else 1
-    want = per_stage * (2 if B * (H // 32) * (W // 64) >= 192 else 1)
-    assert plan.training and plan.fp8_jit and n8 == len(plan.fp8_grad_layers) == want                   # the native e4m3 data gradients ran
+    # stages with >= 192 tiles of 16 x 32 pixels take the fp8 route (B = 2: the full-resolution stage only); round 6: per stage ALL three
+    # data gradients are e4m3 -- the write-once launches over the K-concatenated gradient buffer -- with ONE dy scale per stage
+    stages = 2 if B * (H // 32) * (W // 64) >= 192 else 1
+    assert plan.training and plan.fp8_jit and n8 == 3 * stages and len(plan.fp8_grad_layers) == stages      # the native e4m3 data gradients ran
     loss, _ = hl.total_loss(out, {k: v.cuda() for k, v in batch.items()}, False)
     loss.backward()
     torch.cuda.synchronize()
-    gsc = {n: float(plan.g8_scales[i]) for i, n in enumerate(plan.fp8_grad_layers)}                    # just-in-time: THIS step's amax / 448
+    # just-in-time: THIS step's max |dy| over the stage's three slices / 448 (the launches behind layers 2 and 1 ran with the running max of
+    # the slices produced until then: a difference of one e4m3 quantisation grid for those two launches, inside the tolerances below)
+    gsc = {f"{n}.conv.layers.{li}": float(plan.g8_scales[i]) for i, n in enumerate(plan.fp8_grad_layers) for li in range(3)}
     assert all(0 < s < 1 for s in gsc.values()) and int(plan.g8_amax.abs().max()) == 0
     sdo = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
     o = om.forward(sdo, batch["image"], cfg, quant="bf16", masks=masks, fp8_scales=scales, fp8_grad_scales=gsc)
@@ -488,8 +489,8 @@ def test_fp8_data_gradients_train_step_at_full_depth_vs_oracle_fp8_mode():
 
 def test_fp8_graph_step_with_delayed_scaling_equals_the_just_in_time_step_on_the_calibration_batch():
     """TrainStep captures the delayed-scaling variant after one just-in-time calibration iteration on the batch in its buffers: the
-    first graph step quantises with exactly the scales that iteration left, i.e. it equals the eager just-in-time step BIT FOR BIT;
-    a second step on the same batch uses step 1's amax (delayed) and still agrees to e4m3 rounding."""
+    first graph step quantises with exactly the scales that iteration left (equal scales, equal losses; gradients equal to e4m3 rounding:
+    see the comment at the assertion); a second step on the same batch uses step 1's amax (delayed)."""
     from camradepth_amd import synth
     from camradepth_amd.config import ModelConfig
     from camradepth_amd.trainer import TrainStep
@@ -525,4 +526,53 @@ def test_fp8_graph_step_with_delayed_scaling_equals_the_just_in_time_step_on_the
           f"gradient rel-L2 {r:.3e}, scales {sg[:2].tolist()} / {se[:2].tolist()}")
     assert lg == le
     assert torch.equal(sg[:2], se[:2])
-    assert r < 2e-7          # measured 3.5e-8: the same difference as the bf16 graph-vs-eager step (weight-gradient split counts), nothing from the scaling mode
+    # Round 6: one scale per STAGE.  The graph step quantises all three slices with the calibrated stage scale; the just-in-time step ran the
+    # launches behind layers 2 and 1 with the running max of the slices produced until then -- the same values on another e4m3 grid for two
+    # of the three launches of a stage: agreement to e4m3 rounding, no longer bit for bit (round 5, per-layer scales: 3.5e-8).
+    assert r < 2e-2
+
+
+# ---- round 6: the e4m3 attention scores (BASELINE.json configs[4] "fp8 MFMA attention"): an experiment with a verdict, not a plan path
+def _quant_heads(lib, L, x, heads, d, scale):
+    """bf16 [B, P, heads * d] -> e4m3 [B, P, heads, 64] (head dimension zero-padded), per-tensor scale: crd_quant_fp8 per head."""
+    B, P, C = x.shape
+    y = torch.zeros(B, P, heads, 64, dtype=torch.uint8, device="cuda")
+    for h in range(heads):
+        lib.check(L.crd_quant_fp8(x.data_ptr(), B * P, C, h * d, d, y.data_ptr(), heads * 64, h * 64, float(scale), lib.stream()), "crd_quant_fp8")
+    return y
+
+
+@pytest.mark.parametrize("B,N,M,heads,d", [(2, 6656, 104, 1, 64), (2, 1664, 104, 2, 64), (2, 416, 104, 4, 40), (2, 104, 104, 8, 32), (1, 77, 45, 4, 40)])
+def test_attention_scores_e4m3_variant_and_argmax_flip_rate(B, N, M, heads, d):
+    """crd_attn_scores_fp8 against torch on the de-quantised operands (same rounding points as the bf16 kernel behind the product), and
+    what e4m3 operands do to the ARG-MAX the max-pool attention routes its gradient through (simplified_attention.py:104-106): the
+    flip rate against the bf16 kernel on the same q, k.  The numbers printed here are the ones DESIGN.md quotes for the decision."""
+    from camradepth_amd import lib
+    L = lib.load()
+    g = torch.Generator().manual_seed(N + 7 * heads)
+    C = heads * d
+    q = (torch.randn(B, N, C, generator=g) * 0.8).to(torch.bfloat16).cuda()
+    k = (torch.randn(B, M, C, generator=g) * 0.8).to(torch.bfloat16).cuda()
+    scale = d ** -0.5
+    qs, ks = float(q.float().abs().max()) / 448.0, float(k.float().abs().max()) / 448.0
+    q8, k8 = _quant_heads(lib, L, q, heads, d, qs), _quant_heads(lib, L, k, heads, d, ks)
+    S8, i8 = torch.zeros(B, N, device="cuda"), torch.zeros(B, N, heads, dtype=torch.int16, device="cuda")
+    lib.check(L.crd_attn_scores_fp8(q8.data_ptr(), k8.data_ptr(), B, N, M, heads, qs * ks, scale, S8.data_ptr(), i8.data_ptr(), lib.stream()), "scores fp8")
+    S16, i16 = torch.zeros(B, N, device="cuda"), torch.zeros(B, N, heads, dtype=torch.int16, device="cuda")
+    lib.check(L.crd_attn_scores(q.data_ptr(), k.data_ptr(), B, N, M, heads, d, scale, S16.data_ptr(), i16.data_ptr(), lib.stream()), "scores bf16")
+    torch.cuda.synchronize()
+    # torch on the de-quantised operands
+    deq = lambda t8, sc: t8.view(torch.float8_e4m3fn).float()[..., :d] * sc                   # [B, P, heads, d]
+    qd, kd = deq(q8, 1.0).cpu(), deq(k8, 1.0).cpu()
+    prod = torch.einsum("bnhd,bmhd->bhnm", qd, kd) * (qs * ks)
+    sc_ = (prod.to(torch.bfloat16).float() * scale).to(torch.bfloat16).float()
+    best, arg = sc_.max(-1)                                                                    # [B, heads, N]
+    S_ref = best.sum(1)
+    same = (arg.permute(0, 2, 1) == i8.cpu().long()).float().mean().item()
+    err = float((S8.cpu() - S_ref).abs().max() / (S_ref.abs().max() + 1e-9))
+    flips = (i8 != i16).float().mean().item()
+    dS = float((S8 - S16).norm() / (S16.norm() + 1e-9))
+    print(f"e4m3 scores B{B} N{N} M{M} heads{heads} d{d}: arg-max equal to torch's on the de-quantised operands {100 * same:.2f} %, max |S - S_ref| "
+          f"{err:.2e}; against the bf16 kernel: {100 * flips:.1f} % of the (query, head) arg-maxes flip, S rel-L2 {dS:.3e}")
+    assert same > 0.99 and err < 2e-2          # (ties between equal bf16 scores may resolve differently; the values agree)
+    assert flips < 0.6

@@ -70,14 +70,14 @@ def test_fp8_gradient_plan_records_both_scaling_variants():
     m.__dict__["fp8_train"] = True
     m.__dict__["fp8_grad"] = True
     p = Plan(m, 8, 128, 192, True)                  # 8 x 6 x 8 = 384 tiles at full resolution: that stage takes the fp8 route, 96 at half do not
-    assert p.fp8_grad_layers == ["depth_upsample.4.conv.layers.2"]          # the MFMA-bound first writer of the concat gradient
+    assert p.fp8_grad_layers == ["depth_upsample.4"]          # round 6: one scale per STAGE, all three write-once data gradients in e4m3
     assert sum(op.name == "crd_conv3x3_fp8" for op in p.fwd) == 3
     jit = [op.name for op in p.bwd if p.live(op)]
     p.fp8_jit = False
     delayed = [op.name for op in p.bwd if p.live(op)]
-    assert jit.count("crd_conv3x3_fp8_dgrad") == delayed.count("crd_conv3x3_fp8_dgrad") == 1
-    assert jit.count("crd_quant_fp8_dev") == 1 and delayed.count("crd_quant_fp8_dev") == 0
-    assert jit.count("crd_fp8_scale_update") == 1 and delayed.count("crd_fp8_scale_update") == 1
+    assert jit.count("crd_conv3x3_fp8_dgrad") == delayed.count("crd_conv3x3_fp8_dgrad") == 3
+    assert jit.count("crd_quant_fp8_dev") == 3 and delayed.count("crd_quant_fp8_dev") == 0
+    assert jit.count("crd_fp8_scale_update") == 3 and delayed.count("crd_fp8_scale_update") == 1
     assert delayed[0] == "crd_fp8_scale_update" and jit[0] != "crd_fp8_scale_update"      # delayed: at the head of the backward pass
     i = jit.index("crd_gn_bwd_apply_fp8")
     assert jit[i + 1:i + 3] == ["crd_fp8_scale_update", "crd_quant_fp8_dev"]              # just-in-time: right behind the layer's GroupNorm backward

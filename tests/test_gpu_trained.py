@@ -120,7 +120,9 @@ def test_fp8_mode_at_the_trained_operating_point(trained):
         if i in (0, 59):
             v = ts.losses()
             first, last = (v if i == 0 else first), v
-    assert not ts.plan.fp8_jit and math.isfinite(last["loss"]) and last["rmse"] < 1.5 * first["rmse"] + 5e-3, (first, last)
+    # (training RMSE of ONE batch each -- different batches at steps 0 and 59, dropout on: +-3e-3 between batches; a regression from the
+    # e4m3 gradients would show in the held-out gate below)
+    assert not ts.plan.fp8_jit and math.isfinite(last["loss"]) and last["rmse"] < first["rmse"] + 6e-3, (first, last)
     model.calibrate_fp8(None)
     model.eval()
     after = []
@@ -130,7 +132,7 @@ def test_fp8_mode_at_the_trained_operating_point(trained):
     print(f"60 steps with e4m3 forward + data gradients: training rmse {first['rmse']:.5f} -> {last['rmse']:.5f}; held-out RMSE (bf16 eval) "
           f"before {[round(r[1], 5) for r in rows]} (fp32 oracle) after {[round(a, 5) for a in after]}")
     for a, (r8, r32) in zip(after, rows):
-        assert a < 1.5 * r32 + 5e-3, (a, r32)
+        assert a < r32 + 1e-3, (a, r32)            # held-out RMSE after the e4m3 steps <= before + 1e-3 (measured: -6.6e-4 / +7e-5)
     with torch.no_grad():
         model.flat.copy_(saved)                                    # leave the fixture as it was found
     model.mark_params_changed()

@@ -162,9 +162,18 @@ constexpr int OPT_CHUNK = 4096;  // elements per workgroup
 // hp (device, optional): [beta1, beta2, eps, weight_decay, step_size] -- lets a captured HIP graph follow the
 // per-iteration OneCycleLR schedule without re-capture
 __global__ __launch_bounds__(TPB) void k_dgn_norm(const float* p, const float* g, const long long* seg_off, const int* blk2seg,
-                                                  const int* blk2chunk, float wd, const float* hp, float* norm_sq) {
+                                                  const int* blk2chunk, float wd, const float* hp, float* norm_sq,
+                                                  const unsigned char* active) {
   if (hp) wd = hp[3];
   const int t = blk2seg[blockIdx.x];
+  // A skipped tensor (`p.grad is None`, diffGradNorm.py:54-55) has NO gradient storage behind its segment when the gradients are used in
+  // place (optim.diffGradNorm with separately allocated tensors: g = the first active gradient's pointer minus its offset): reading its
+  // segment walked past the end of that allocation -- a memory access fault whenever it was the last block of an allocator segment
+  // (round 6: the full GPU suite hit it once; round 1-5's k_dgn_update already skipped such tensors, this kernel did not).
+  if (active && !active[t]) {
+    if (threadIdx.x == 0) norm_sq[blockIdx.x] = 0.f;
+    return;
+  }
   const long long beg = seg_off[2 * t] + (long long)blk2chunk[blockIdx.x] * OPT_CHUNK;
   long long end = beg + OPT_CHUNK;
   if (end > seg_off[2 * t + 1]) end = seg_off[2 * t + 1];
@@ -438,7 +447,7 @@ extern "C" int crd_diffgradnorm_step(float* p, const float* g, float* exp_avg, f
                 "crd_diffgradnorm_step: bad argument");
   hipStream_t st = as_stream(stream);
   const long long* so = reinterpret_cast<const long long*>(seg_off);
-  hipLaunchKernelGGL(k_dgn_norm, dim3(n_blocks), dim3(TPB), 0, st, p, g, so, blk2seg, blk2chunk, weight_decay, hp_dev, norm_sq);
+  hipLaunchKernelGGL(k_dgn_norm, dim3(n_blocks), dim3(TPB), 0, st, p, g, so, blk2seg, blk2chunk, weight_decay, hp_dev, norm_sq, active);
   hipLaunchKernelGGL(k_dgn_scalar, dim3(cdiv(n_tensors, 4)), dim3(256), 0, st, exp_grad_norm, norm_sq, factor, active, n_tensors, so, blk2seg,
                      n_blocks);
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);

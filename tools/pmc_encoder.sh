@@ -1,7 +1,7 @@
 # GPU box: hardware-counter summary (one rocprofv3 --pmc pass per counter set, no tracing) of the ENCODER kernels inside an eager
 # training iteration of the benchmark configuration (the "dependent-latency-bound" diagnosis needs counters
-# under it) -- the small GEMMs, GroupNorm backward, depthwise, attention backward -- plus the persistent stage kernel (forward,
-# CRD_ENC_PERSIST=1) and the whole-iteration totals (MFMA busy share, HBM bytes).  Output: gpurun_out/pmc_encoder/summary.txt
+# under it) -- the small GEMMs, GroupNorm backward, depthwise, attention backward
+# and the whole-iteration totals (MFMA busy share, HBM bytes).  Output: gpurun_out/pmc_encoder/summary.txt
 cd /tmp; export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/pmc_encoder; rm -rf $O; mkdir -p $O
@@ -27,7 +27,7 @@ run_set() {   # $1 label, $2 env, $3.. program
 import csv, sys, collections
 if len(sys.argv) < 2 or not sys.argv[1]:
     print("   (no output for", sys.argv[2] if len(sys.argv) > 2 else "?", ")"); sys.exit()
-WANT = ("k_igemm<2, 2, 1, 1", "k_gngemm_reg", "k_gn_bwd_apply", "k_gn_bwd_reduce", "k_dwconv", "k_attn_scores_bwd", "k_attn_scores", "k_enc_stage",
+WANT = ("k_igemm<2, 2, 1, 1", "k_gngemm_reg", "k_gn_bwd_apply", "k_gn_bwd_reduce", "k_dwconv", "k_attn_scores_bwd", "k_attn_scores"e",
         "k_conv3x3p", "k_wgrad3x3", "k_pw_narrow", "k_gn_pw_wide", "k_wgrad_grouped")
 agg = collections.defaultdict(list)
 tot = collections.defaultdict(float)
@@ -48,7 +48,4 @@ PY
   done
 }
 run_set "eager training iterations x3 (per-launch encoder), base 8x7x256x416" "CRD_ENC_PERSIST=0" tools/run_forward.py 3 train
-if [ "$1" = "persist" ]; then      # the parked persistent stage kernel (round 4's second table): only on request
-run_set "eval forwards x3, persistent stages 3-4 (CRD_ENC_PERSIST=1)" "CRD_DEV_SWITCHES=1 CRD_ENC_PERSIST=1" tools/run_forward.py 3
-fi
 cat $O/summary.txt

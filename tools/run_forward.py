@@ -1,5 +1,5 @@
 """Developer tool: N eval forwards of the base model at 8x7x256x416 (the program rocprofv3 --pmc wraps for the encoder-kernel
-counters, tools/pmc_encoder.sh).  CRD_ENC_PERSIST=1 takes the persistent stage kernels."""
+counters, tools/pmc_encoder.sh)."""
 import sys
 sys.path.insert(0, ".")
 import torch

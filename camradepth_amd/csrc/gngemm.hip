@@ -90,7 +90,7 @@ constexpr size_t epilogue_bytes() { return (size_t)BM * (BN + 8) * 4 + 256 * 16 
 // One workgroup per (row tile, column tile) like k_igemm; 32-48 KB of LDS, so 3-4 workgroups per CU hide each other's
 // latencies; no counted waits (the compiler tracks register loads exactly, lds_barrier() keeps them in flight across barriers).
 template <int WM, int WN, int TM, int TN, int XF32, int ACT>
-__global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
+__device__ __forceinline__ void gngemm_body(const ConvK& a, const GnIn& gi, const int bx, const int by, const int bz) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int A_IT = BM / 32, B_IT = BN / 32;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv / WN, wn = wv % WN;
-  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int b = bz, m0 = bx * BM, n0 = by * BN;
   const int r0 = 8 * wv + (l >> 3);                   // this thread's rows: r0 + 32 i; LDS slot l & 7 <- K granule g (k_igemm's swizzle)
   const int g = (l & 7) ^ ((r0 >> 1) & 7);
   const unsigned OOB = 0x80000000u;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
       (void*)(reinterpret_cast<const char*>(gi.x) + (long long)b * a.x_bstride * esz), 0, (int)(a.x_bstride * esz), 0x00020000);
   const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, 0, a.Cout * a.Ktot * 2, 0x00020000);
   const int nK = (a.Ktot + BK - 1) / BK;
-  const bool store_xn = gi.xn != nullptr && blockIdx.y == 0;
+  const bool store_xn = gi.xn != nullptr && by == 0;
   // the stored copy of the normalised operand goes through a buffer descriptor: rows / granules that are not stored carry an
   // out-of-range offset and the hardware drops them, so the store is UNCONDITIONAL (round 6: under `if (store_xn && ok)` the compiler
   // could no longer count the requests in flight and drained the two-slab prefetch at every use -- see the K loop below)
@@ -235,9 +235,51 @@ __global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
     lds_barrier();
   }
   if (a.dbg & 4) { if (acc[0][0][0] == 123.456f) reinterpret_cast<float*>(a.y)[0] = 1.f; return; }
-  conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
+  conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, bx, lds,
                                 [&](int i, int rr, bool& valid, int& row) { row = m0 + (wm * TM + i) * 32 + rr; valid = row < a.OHW; },
                                 [&](int rl, bool& valid, int& row) { row = m0 + rl; valid = row < a.OHW; });
+}
+
+template <int WM, int WN, int TM, int TN, int XF32, int ACT>
+__global__ __launch_bounds__(256) void k_gngemm_reg(ConvK a, GnIn gi) {
+  gngemm_body<WM, WN, TM, TN, XF32, ACT>(a, gi, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// TWO independent problems behind the same GroupNorm in ONE launch (round 6: attn.q and the attn.sr patch convolution of a Block both read
+// norm1(x) -- simplified_attention.py:96-100 -- and were two dependent-latency-bound launches in a row, the second waiting for the first's
+// stored XN; here sr normalises its own rows, and the shorter q problem finishes under it).  Workgroups [0, nb0) take problem 0
+// (row tiles fastest), the rest problem 1.
+struct Gn2 { ConvK a0, a1; GnIn g0, g1; int nb0, nt0, nt1; };
+template <int WM, int WN, int TM, int TN, int XF32, int ACT>
+__global__ __launch_bounds__(256) void k_gngemm_reg2(Gn2 p) {
+  const int x = blockIdx.x;
+  if (x < p.nb0) gngemm_body<WM, WN, TM, TN, XF32, ACT>(p.a0, p.g0, x % p.nt0, x / p.nt0, blockIdx.y);
+  else { const int y = x - p.nb0; gngemm_body<WM, WN, TM, TN, XF32, ACT>(p.a1, p.g1, y % p.nt1, y / p.nt1, blockIdx.y); }
+}
+
+template <int WM, int WN, int TM, int TN, int XF32, int ACT>
+int launch_reg2(const ConvK& k0, const GnIn& g0, const ConvK& k1, const GnIn& g1, int B, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  Gn2 p;
+  p.a0 = k0; p.a1 = k1; p.g0 = g0; p.g1 = g1;
+  p.nt0 = p.a0.n_tiles = cdiv(k0.OHW, BM); p.nt1 = p.a1.n_tiles = cdiv(k1.OHW, BM);
+  p.nb0 = p.nt0 * cdiv(k0.Cout, BN);
+  const int nb1 = p.nt1 * cdiv(k1.Cout, BN);
+  size_t tiles = (size_t)2 * (BM + BN) * BK * 2;
+  if (tiles < epilogue_bytes<BM, BN>()) tiles = epilogue_bytes<BM, BN>();
+  tiles = (tiles + 255) / 256 * 256;
+  const int cin = k0.Cin > k1.Cin ? k0.Cin : k1.Cin;
+  const size_t lds = tiles + (size_t)cin * sizeof(float2);
+  CRD_UNSUPPORTED(lds <= 160 * 1024, "crd_gn_conv2: table does not fit in LDS");
+  static bool attr_done = false;
+  if (!attr_done) {
+    crd_reserve_lds(reinterpret_cast<const void*>(&k_gngemm_reg2<WM, WN, TM, TN, XF32, ACT>), 160 * 1024, "k_gngemm_reg2");
+    attr_done = true;
+  }
+  p.a0.lds_bytes = p.a1.lds_bytes = (int)tiles;
+  hipLaunchKernelGGL((k_gngemm_reg2<WM, WN, TM, TN, XF32, ACT>), dim3(p.nb0 + nb1, B), dim3(256), lds, st, p);
+  CRD_LAUNCH_CHECK("crd_gn_conv2");
+  return CRD_OK;
 }
 
 template <int WM, int WN, int TM, int TN, int XF32, int ACT>
@@ -595,7 +637,7 @@ int crd_pw_wide_plain(const ConvK& k, int B, hipStream_t st) {
   return dispatch_pw_wide<0>(k, gi, B, st);
 }
 
-extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stream) {
+static int gn_conv_args(const crd_conv_desc* d, const crd_gn_input* n, ConvK& k, GnIn& gi) {
   CRD_CHECK_ARG(d && n && d->x && d->w && d->y && n->stats && n->gamma && n->beta, "crd_gn_conv: null pointer");
   CRD_CHECK_ARG(d->Cin % 16 == 0 && d->x_ld % 8 == 0 && d->x_coff % 8 == 0, "crd_gn_conv: Cin must be a multiple of 16, x_ld/x_coff of 8");
   CRD_CHECK_ARG(d->B > 0 && d->OH > 0 && d->OW > 0 && d->Cout > 0 && d->KH == d->KW && d->KH >= 1, "crd_gn_conv: bad dims");
@@ -608,7 +650,6 @@ extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_st
   CRD_UNSUPPORTED((long long)d->Cout * d->KH * d->KW * d->Cin < (1ll << 30) && d->Cin <= 4096 &&
                   (long long)d->IH * d->IW * d->x_ld * (n->x_f32 ? 4 : 2) < (1ll << 31), "crd_gn_conv: tensor too large for 32-bit byte offsets");
   CRD_CHECK_ARG(!n->xn || (n->xn_ld % 8 == 0 && (reinterpret_cast<uintptr_t>(n->xn) & 15) == 0), "crd_gn_conv: xn rows must be 16-byte aligned");
-  ConvK k;
   k.x = nullptr; k.x_ld = d->x_ld;
   k.IH = d->IH; k.IW = d->IW; k.Cin = d->Cin; k.x_bstride = (long long)d->IH * d->IW * d->x_ld;
   k.w = reinterpret_cast<const bf16_t*>(d->w);
@@ -631,13 +672,19 @@ extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_st
   k.red_x = nullptr; k.red_x_f32 = 0; k.red_x_ld = 0; k.red_x_bstride = 0; k.red_stats = nullptr; k.red_gamma = nullptr; k.red_beta = nullptr;
   k.red_gmul = 1; k.red_act = 0; k.red_r = nullptr;
   { static int dbg = -1; if (dbg < 0) dbg = crd_dev_int("CRD_DBG", 0); k.dbg = dbg; }
-  GnIn gi;
   gi.x_f32 = n->x_f32;
   gi.x = n->x_f32 ? (const void*)(reinterpret_cast<const float*>(d->x) + d->x_coff) : (const void*)(reinterpret_cast<const bf16_t*>(d->x) + d->x_coff);
   CRD_CHECK_ARG((reinterpret_cast<uintptr_t>(gi.x) & 15) == 0 && (!n->x_f32 || d->x_ld % 4 == 0), "crd_gn_conv: x rows must be 16-byte aligned");
   gi.stats = n->stats; gi.gmul = n->gmul; gi.gamma = n->gamma; gi.beta = n->beta;
   gi.count = (float)d->IH * (float)d->IW * 16.f * (float)n->gmul;
   gi.xn = reinterpret_cast<bf16_t*>(n->xn); gi.xn_ld = n->xn_ld; gi.xn_bstride = (long long)d->IH * d->IW * n->xn_ld;
+  return CRD_OK;
+}
+
+extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stream) {
+  ConvK k;
+  GnIn gi;
+  { const int rc = gn_conv_args(d, n, k, gi); if (rc != CRD_OK) return rc; }
   hipStream_t st = as_stream(stream);
   if (n->act == 1 && !n->x_f32 && d->KH == 1) {        // Mlp.norm2 + GELU in front of fc2 at stages 1-2: the narrow streaming kernel
     ConvK kn = k;
@@ -650,4 +697,17 @@ extern "C" int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_st
   if (pw_wide_applies(k, gi, n->act)) return dispatch_pw_wide<1>(k, gi, d->B, st);
   if (n->x_f32) return n->act ? dispatch<1, 1>(k, gi, d->B, st) : dispatch<1, 0>(k, gi, d->B, st);
   return n->act ? dispatch<0, 1>(k, gi, d->B, st) : dispatch<0, 0>(k, gi, d->B, st);
+}
+
+extern "C" int crd_gn_conv2(const crd_conv_desc* d0, const crd_gn_input* n0, const crd_conv_desc* d1, const crd_gn_input* n1, crd_stream_t stream) {
+  ConvK k0, k1;
+  GnIn g0, g1;
+  { const int rc = gn_conv_args(d0, n0, k0, g0); if (rc != CRD_OK) return rc; }
+  { const int rc = gn_conv_args(d1, n1, k1, g1); if (rc != CRD_OK) return rc; }
+  CRD_UNSUPPORTED(d0->B == d1->B && n0->x_f32 == 1 && n1->x_f32 == 1 && n0->act == 0 && n1->act == 0,
+                  "crd_gn_conv2: two problems of one batch behind a GroupNorm of the fp32 residual stream, no activation");
+  // both on the 64 x 64 tiles (what crd_gn_conv picks for each of them alone at the encoder's sizes; a wide problem takes its own launch)
+  auto small = [&](const ConvK& k) { return k.Cout <= 64 || (long long)cdiv(k.OHW, 64) * cdiv(k.Cout, 128) * d0->B < 256; };
+  CRD_UNSUPPORTED(small(k0) && small(k1), "crd_gn_conv2: both problems must take the 64 x 64 tiles");
+  return launch_reg2<2, 2, 1, 1, 1, 0>(k0, g0, k1, g1, d0->B, as_stream(stream));
 }

@@ -410,6 +410,12 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
         store8_bf16(dx, off, o);
       }
       if (dx8) {          // e4m3 copy of the stored bf16 gradient + its running amax
+        // (a NaN / infinite gradient would vanish here -- fmaxf drops NaN, the e4m3 conversion clamps to +-448 -- while the bf16 tensor
+        //  next to it carries it on: raise the sticky non-finite flag instead, so that the step reports NaN like the bf16 path)
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bad |= !(fabsf(o[j]) < 3.0e38f);
+        if (bad) crd_tu_nonfinite = 1;
 #pragma unroll
         for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf_round(o[j])));
         store8_fp8(dx8, ((long long)b * P + pp) * dx8_ld + c0, o, inv8);

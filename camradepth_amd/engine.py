@@ -171,6 +171,11 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
 KCAT = _dev_int("CRD_KCAT", 1) != 0
 GNB_FC1 = _dev_int("CRD_GNB_FC1", 15)
 GNB_SR = _dev_int("CRD_GNB_SR", 15)
+# attn.q and the attn.sr patch convolution of a Block as ONE launch (crd_gn_conv2: both read Block.norm1(x); sr normalises its own rows
+# instead of waiting for q's stored copy).  Bit s = encoder stage s + 1.  Stage 3 only: measured in one call (profiles/r06_ab_q_sr_grouped.txt)
+# 17.50 / 17.51 ms without, 17.46 / 17.47 with stage 3, 17.56 / 17.53 with stages 2 + 3 -- the sr convolutions of stages 1-2 (K = 4096 /
+# 2048: 64 / 32 serial slabs on this path) are better off on crd_conv_igemm's 4-way split-K; the pair it saves at stage 3 was 6.6 + 8.2 us.
+QSR_GROUP = _dev_int("CRD_QSR_GROUP", 4)
 # (Round 6, measured and removed: the fold of crd_attn_bwd's dK partials inside k's data gradient -- a GEMM of 16-48 workgroups whose A
 # loader sums 4-52 fp32 partials took 16.9 / 17.9 / 15.1 us at stages 3 / 2 / 1 against 3.2 + 8.0 for crd_sum_partials_bf16 + the GEMM:
 # 17.36 ms per step with it, 17.19 without, gpurun_out/r6/ab_ps2.txt.)
@@ -292,7 +297,9 @@ class Plan:
         # calibration iteration of TrainStep); False: delayed scaling -- the scales of the previous step's amax, updated once at the
         # head of the backward pass (TrainStep's graphs).
         self.fp8_grad = bool(self.fp8 is not None and training and getattr(model, "fp8_grad", False))
-        self.fp8_grad_layers, self.fp8_jit, self.fp8_margin = [], True, 1.0
+        # margin 2 (round 6): with delayed scaling a step whose gradients GROW is quantised with the previous step's amax -- one
+        # binade of headroom before e4m3 saturates (clamps at +-448 x scale); e4m3's relative precision does not depend on the scale
+        self.fp8_grad_layers, self.fp8_jit, self.fp8_margin = [], True, 2.0
         if self.fp8_grad:
             self.g8_scales = torch.ones(16, dtype=F32, device=self.dev)
             self.g8_amax = torch.zeros((16, 64), dtype=torch.int32, device=self.dev)
@@ -1158,7 +1165,20 @@ class Plan:
             if not fused:
                 with self.side(1):       # q projection: independent of the key path below
                     self.conv(F_, q_spec)
-            self.conv(F_, self.conv_desc(XN, csr, Cs, sr, sr, 0, Hs // sr, Ws // sr, KR, bias=csr.bias, stats=stk))
+            sr_spec = self.conv_desc(XN, csr, Cs, sr, sr, 0, Hs // sr, Ws // sr, KR, bias=csr.bias, stats=stk)
+            if fused and (QSR_GROUP >> stage_i) & 1 and F_ and F_[-1].name == "crd_gn_conv":
+                # round 6: q (recorded just above) and sr in one launch
+                q_op = F_.pop()
+                sr_spec["x"] = X
+                flops_sr = 2.0 * self.B * sr_spec["OH"] * sr_spec["OW"] * Cs * csr.cin_ref * csr.taps
+                gn_sr = dict(gn_in=True, x_f32=X.f32, gmul=1, stats=st1, gamma=self.p(name + ".norm1.weight"), beta=self.p(name + ".norm1.bias"),
+                             act=0, xn=None)
+                meta = {"kernel": "k_gngemm_reg2<2,2,1,1>", "flops": q_op.meta["flops"] + flops_sr,
+                        "shape": f"gn+fwd q Cin{Cs} Cout{Cs} {Hs}x{Ws} | sr k{sr} Cin{Cs} Cout{Cs} {Hs // sr}x{Ws // sr}"}
+                io = self.op_bytes(q_op) + nbytes(X, KR) + Cs * csr.taps * Cs * 2
+                F_.append(Op(self.lib.crd_gn_conv2, q_op.args + [sr_spec, gn_sr], "crd_gn_conv2", None, None, meta, stream=self._cur_stream, io=io))
+            else:
+                self.conv(F_, sr_spec)
             k_spec = self.conv_desc(KRN, ck, Cs, 1, 1, 0, Hs // sr, Ws // sr, K, bias=ck.bias)
             if fused:       # attn.norm applied while k loads KR
                 k_spec["x"] = KR

@@ -126,7 +126,7 @@ def load():
 
 # Signatures of include/camradepth_hip.h (all return int status). p = pointer, i = int32, l = int64, f = float
 _SIGS = {
-    "crd_conv_igemm": "pp", "crd_gn_conv": "ppp", "crd_gn_bwd_conv": "ppp", "crd_pw_narrow_supported": "iii", "crd_tune_pw_narrow": "i", "crd_conv3x3_fp8": "ppfp", "crd_amax_bf16": "pliiipp", "crd_quant_fp8": "pliiipiifp",
+    "crd_conv_igemm": "pp", "crd_gn_conv": "ppp", "crd_gn_conv2": "ppppp", "crd_gn_bwd_conv": "ppp", "crd_pw_narrow_supported": "iii", "crd_tune_pw_narrow": "i", "crd_conv3x3_fp8": "ppfp", "crd_amax_bf16": "pliiipp", "crd_quant_fp8": "pliiipiifp",
     "crd_weight_quant_fp8": "piiiippp", "crd_conv3x3_fp8_dgrad": "pppp", "crd_gn_bwd_apply_fp8": "piiipiiiiiipippipppppiipiippp",
     "crd_fp8_scale_update": "ppifip", "crd_quant_fp8_dev": "pliiipiipp", "crd_tune_conv3x3_small_grid": "i", "crd_tune_igemm_reg_epilogue": "i", "crd_conv_wgrad": "pp", "crd_conv_wgrad_splits": "p", "crd_wgrad_group_build": "piplp", "crd_conv_wgrad_grouped": "ppp",
     "crd_gn_stats": "piiiiiippp", "crd_gn_apply": "piiiiiipippipPiiip".replace("P", "p"),

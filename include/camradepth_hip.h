@@ -136,6 +136,10 @@ typedef struct {
   void* xn;                 /* optional bf16 output */
 } crd_gn_input;
 int crd_gn_conv(const crd_conv_desc* d, const crd_gn_input* n, crd_stream_t stream);
+/* Two crd_gn_conv problems of the same batch in ONE launch (round 6): attn.q and the attn.sr patch convolution of a Block, which both
+ * read Block.norm1(x) (src/models/simplified_attention.py:96-100).  Both read the fp32 residual stream behind a GroupNorm without
+ * activation and both take the 64 x 64 tiles; every option of crd_gn_conv applies to each (bias, output sums, n->xn). */
+int crd_gn_conv2(const crd_conv_desc* d0, const crd_gn_input* n0, const crd_conv_desc* d1, const crd_gn_input* n1, crd_stream_t stream);
 /* Backward twin of crd_gn_conv (round 6): the APPLY phase of a GroupNorm (+ exact GELU) backward folded into the A-operand load of
  * the pointwise data-gradient GEMM that consumes the gradient (csrc/xfgemm.hip).  d->x holds dy of the GroupNorm (bf16
  * [B][P][x_ld] + x_coff, Cin = the GroupNorm's channels); the GEMM multiplies d->w with

@@ -252,3 +252,50 @@ def test_gn_bwd_conv_matches_apply_then_conv(case):
         assert_close(sval(ost1), sval(ost0), "output sums", rel=2e-3, elem=5e-3)
     if red1 is not None:
         assert_close(gval(red1), gval(red0), "fused reduce of the next GroupNorm", rel=3e-3, elem=3e-3)
+
+
+@pytest.mark.parametrize("B,C_,H,W,sr", [(8, 160, 16, 26, 2), (2, 128, 32, 52, 4), (3, 160, 6, 10, 2), (2, 64, 16, 24, 8)])
+def test_gn_conv2_equals_two_gn_conv_launches(B, C_, H, W, sr):
+    """crd_gn_conv2 -- attn.q and the attn.sr patch convolution of a Block, both behind Block.norm1 of the fp32 residual stream, in ONE
+    launch -- against the two crd_gn_conv launches: the same kernel body on the same tiles, so outputs, the stored normalised operand and
+    the output GroupNorm sums are bit-identical."""
+    lib = _lib()
+    L = lib.load()
+    g = torch.Generator().manual_seed(C_ + sr)
+    x = (torch.randn(B, H * W, C_, generator=g) * 1.3 + 0.2).cuda()
+    stats = zsum(B, C_ // 16, 2)
+    lib.check(L.crd_gn_stats(x.data_ptr(), 1, C_, 0, B, H * W, C_, stats.data_ptr(), None, lib.stream()), "gn_stats")
+    gam, bet = (1 + 0.2 * torch.randn(C_, generator=g)).cuda(), (0.1 * torch.randn(C_, generator=g)).cuda()
+    wq, wsr = pack_w(torch.randn(C_, C_, 1, 1, generator=g) / C_ ** 0.5), pack_w(torch.randn(C_, C_, sr, sr, generator=g) / (C_ * sr * sr) ** 0.5)
+    bq, bsr = (0.1 * torch.randn(C_, generator=g)).cuda(), (0.1 * torch.randn(C_, generator=g)).cuda()
+    OH, OW = H // sr, W // sr
+
+    def descs(q_out, xn_out, kr_out, kr_stats):
+        dq, nq, ds, ns = lib.ConvDesc(), lib.GnInput(), lib.ConvDesc(), lib.GnInput()
+        for d, w, co, k, oh, ow, y, bias in ((dq, wq, C_, 1, H, W, q_out, bq), (ds, wsr, C_, sr, OH, OW, kr_out, bsr)):
+            d.x, d.x_ld, d.x_coff, d.B, d.IH, d.IW, d.Cin = x.data_ptr(), C_, 0, B, H, W, C_
+            d.w, d.Cout, d.KH, d.KW, d.stride, d.pad, d.OH, d.OW = w.data_ptr(), co, k, k, k, 0, oh, ow
+            d.y, d.y_ld, d.y_f32, d.bias = y.data_ptr(), C_, 0, bias.data_ptr()
+        ds.stats = kr_stats.data_ptr()
+        for n in (nq, ns):
+            n.x_f32, n.gmul, n.act = 1, 1, 0
+            n.stats, n.gamma, n.beta = stats.data_ptr(), gam.data_ptr(), bet.data_ptr()
+        nq.xn, nq.xn_ld = xn_out.data_ptr(), C_
+        return dq, nq, ds, ns
+    outs = []
+    for fused in (False, True):
+        q_out = torch.zeros(B, H * W, C_, dtype=torch.bfloat16, device="cuda")
+        xn_out = torch.zeros_like(q_out)
+        kr_out = torch.zeros(B, OH * OW, C_, dtype=torch.bfloat16, device="cuda")
+        kr_stats = zsum(B, C_ // 16, 2)
+        dq, nq, ds, ns = descs(q_out, xn_out, kr_out, kr_stats)
+        if fused:
+            lib.check(L.crd_gn_conv2(C.byref(dq), C.byref(nq), C.byref(ds), C.byref(ns), lib.stream()), "crd_gn_conv2")
+        else:
+            lib.check(L.crd_gn_conv(C.byref(dq), C.byref(nq), lib.stream()), "crd_gn_conv q")
+            lib.check(L.crd_gn_conv(C.byref(ds), C.byref(ns), lib.stream()), "crd_gn_conv sr")
+        torch.cuda.synchronize()
+        outs.append((q_out, xn_out, kr_out, kr_stats))
+    for a, b_, what in zip(outs[0], outs[1], ("q", "stored norm1(x)", "sr output", "sr output sums")):
+        assert torch.equal(a, b_), what
+    assert float(outs[1][0].float().abs().max()) > 0 and float(outs[1][2].float().abs().max()) > 0

@@ -82,3 +82,23 @@ def test_fp8_gradient_plan_records_both_scaling_variants():
     i = jit.index("crd_gn_bwd_apply_fp8")
     assert jit[i + 1:i + 3] == ["crd_fp8_scale_update", "crd_quant_fp8_dev"]              # just-in-time: right behind the layer's GroupNorm backward
     assert bench.floor_budget(p)["floor_ms"] > 0
+
+
+def test_round6_plan_structure():
+    """The launch structure round 6 built, checked without a GPU: the decoder's data gradients are write-once (no 3x3 launch of the decoder's
+    backward accumulates into the concat gradient: three K-concatenated launches per stage), every encoder Block folds Mlp.norm1's and
+    attn.norm's backward apply into the consuming GEMM (crd_gn_bwd_conv), stage 3 runs q and sr as one launch (crd_gn_conv2), and the
+    K-concatenated weight matrices are fed by extra pack-table entries."""
+    m, p = _plan(True)
+    dec = [op for (tag, a, b) in p.bwd_segments if tag == "dec" for op in p.bwd[a:b]]
+    kcat = [op for op in dec if op.name == "crd_conv_igemm" and "dgrad-kcat" in op.meta["shape"]]
+    assert len(kcat) >= 15                                              # 5 stages x 3 launches (+ ragged column splits)
+    for op in dec:
+        if op.name == "crd_conv_igemm" and " k3 " in op.meta["shape"] and "dgrad" in op.meta["shape"] and "Cin32" not in op.meta["shape"]:
+            assert "dgrad-kcat" in op.meta["shape"], op.meta["shape"]   # (the heads' 32 -> 128 data gradients still accumulate into d(stage))
+    assert sum(op.name == "crd_gn_bwd_conv" for op in p.bwd) == 4 + 3   # fc1 behind Mlp.norm1 in every Block, the sr scatter at stages 1-3
+    assert sum(op.name == "crd_gn_conv2" for op in p.fwd) == 1          # stage 3
+    assert len(p.kcat_entries) == 5 * 6                                 # per stage: layer 2 -> WA, WB, WC; layer 1 -> WB, WC; layer 0 -> WC
+    # what is left of crd_gn_bwd_apply in a Block: Mlp.norm2 (+ GELU) and Block.norm1; Block.norm2's rides in crd_attn_out_bwd_gn
+    enc = [op.name for (tag, a, b) in p.bwd_segments if tag != "dec" for op in p.bwd[a:b]]
+    assert enc.count("crd_gn_bwd_apply") == 4 * 2 + 4                   # 2 per Block + the four patch embeds' norms

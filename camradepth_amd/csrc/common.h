@@ -180,9 +180,11 @@ __device__ __forceinline__ unsigned pack_fp8x4(float a, float b, float c, float 
 // the fp8 copy of a bf16 tensor: e4m3(bf16(v) * inv_scale) -- rounded to bf16 first, so that it IS the quantised bf16 value
 // whichever kernel (crd_quant_fp8 on the stored tensor, or a producer's fused fp8 output) wrote it
 __device__ __forceinline__ void store8_fp8(void* base, int64_t elem_off, const float (&v)[8], float inv_scale) {
+  // (the bf16 rounding through the hardware converter, two values per instruction: as bf_round per value it was ~5 integer operations each)
+  const uint32_t w0 = pack_bf2(v[0], v[1]), w1 = pack_bf2(v[2], v[3]), w2 = pack_bf2(v[4], v[5]), w3 = pack_bf2(v[6], v[7]);
   uint2 q;
-  q.x = pack_fp8x4(bf_round(v[0]) * inv_scale, bf_round(v[1]) * inv_scale, bf_round(v[2]) * inv_scale, bf_round(v[3]) * inv_scale);
-  q.y = pack_fp8x4(bf_round(v[4]) * inv_scale, bf_round(v[5]) * inv_scale, bf_round(v[6]) * inv_scale, bf_round(v[7]) * inv_scale);
+  q.x = pack_fp8x4(bf_lo(w0) * inv_scale, bf_hi(w0) * inv_scale, bf_lo(w1) * inv_scale, bf_hi(w1) * inv_scale);
+  q.y = pack_fp8x4(bf_lo(w2) * inv_scale, bf_hi(w2) * inv_scale, bf_lo(w3) * inv_scale, bf_hi(w3) * inv_scale);
   *reinterpret_cast<uint2*>(reinterpret_cast<unsigned char*>(base) + elem_off) = q;
 }
 __device__ __forceinline__ void store8_f32(float* base, int64_t elem_off, const float (&v)[8]) {

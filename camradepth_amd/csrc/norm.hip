@@ -410,15 +410,23 @@ __global__ __launch_bounds__(TPB) void k_gn_bwd_apply(const void* x, int x_f32, 
         store8_bf16(dx, off, o);
       }
       if (dx8) {          // e4m3 copy of the stored bf16 gradient + its running amax
-        // (a NaN / infinite gradient would vanish here -- fmaxf drops NaN, the e4m3 conversion clamps to +-448 -- while the bf16 tensor
-        //  next to it carries it on: raise the sticky non-finite flag instead, so that the step reports NaN like the bf16 path)
-        bool bad = false;
+        // The bf16 values come from the hardware converter (v_cvt_pk_bf16_f32, what store8_bf16 above wrote) and are unpacked once for
+        // BOTH the amax and the e4m3 conversion: as software roundings per use (bf_round = ~5 integer operations, twice per element)
+        // they were 80 of this path's ~110 vector operations per 8 elements and made crd_gn_bwd_apply_fp8 459 us where the plain apply takes
+        // 318 (B = 16, 128 channels): three quarters of what the e4m3 data gradients gain (profiles/r06_c5_decoder_backward_chain_*).
+        const uint32_t w0 = pack_bf2(o[0], o[1]), w1 = pack_bf2(o[2], o[3]), w2 = pack_bf2(o[4], o[5]), w3 = pack_bf2(o[6], o[7]);
+        const float r[8] = {bf_lo(w0), bf_hi(w0), bf_lo(w1), bf_hi(w1), bf_lo(w2), bf_hi(w2), bf_lo(w3), bf_hi(w3)};
+        // a NaN / infinite gradient would vanish here -- fmaxf drops NaN, the e4m3 conversion clamps to +-448 -- while the bf16 tensor next
+        // to it carries it on: raise the sticky non-finite flag instead, so that the step reports NaN like the bf16 path.
+        // (one test per 8 values: a sum is non-finite iff a term is, or the finite terms overflow -- 8 values near the bf16 maximum)
+        const float chk = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if (!(fabsf(chk) < 3.0e38f)) crd_tu_nonfinite = 1;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) bad |= !(fabsf(o[j]) < 3.0e38f);
-        if (bad) crd_tu_nonfinite = 1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(bf_round(o[j])));
-        store8_fp8(dx8, ((long long)b * P + pp) * dx8_ld + c0, o, inv8);
+        for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(r[j]));
+        uint2 q8;
+        q8.x = pack_fp8x4(r[0] * inv8, r[1] * inv8, r[2] * inv8, r[3] * inv8);
+        q8.y = pack_fp8x4(r[4] * inv8, r[5] * inv8, r[6] * inv8, r[7] * inv8);
+        *reinterpret_cast<uint2*>(dx8 + ((long long)b * P + pp) * dx8_ld + c0) = q8;
       }
       if (dx2) {          // second copy of the finished gradient: bf16(scale2[b] * dx)
 #pragma unroll

@@ -278,7 +278,7 @@ class TrainStep:
         self.graphs = {}
         if self.late_wgrad:
             self.plan.split_late = True
-            self.late_stream = torch.cuda.Stream()
+            self.late_stream = (getattr(self, "late_stream_factory", None) or torch.cuda.Stream)()
         for zero, opt in self._variants():
             self._zero, self._opt = zero, opt
             self.graphs[(zero, opt)] = self._capture_variant()

@@ -874,3 +874,25 @@ def test_diffgradnorm_refuses_a_switched_active_set_without_touching_state():
     a.grad, b.grad = torch.randn(300, generator=g).cuda(), None     # ... and the run it interrupted can go on
     opt.step()
     assert st["step"] == 4 and opt.state[a]["step"] == 4
+
+
+def test_diffgradnorm_never_reads_the_segment_of_a_tensor_without_gradient():
+    """Round 6: with separately allocated tensors the optimizer uses the gradients in place -- g = the first active gradient's pointer minus
+    its offset -- so a tensor WITHOUT a gradient (`p.grad is None`, diffGradNorm.py:54-55) has no storage behind its segment; k_dgn_norm read
+    it anyway (past the end of another allocation: the full GPU suite took a memory access fault there once).  The norm kernel now skips
+    such tensors like k_dgn_update always did: their workgroups' parts of ||g||^2 are written as zeros, whatever lies behind the segment."""
+    from camradepth_amd.optim import diffGradNorm
+    g = torch.Generator().manual_seed(11)
+    a = torch.nn.Parameter(torch.randn(5000, generator=g).cuda())
+    b = torch.nn.Parameter(torch.randn(9000, generator=g).cuda())
+    opt = diffGradNorm([a, b], lr=1e-2)
+    b0 = b.detach().clone()
+    for _ in range(2):
+        a.grad, b.grad = torch.randn(5000, generator=g).cuda(), None
+        opt.step()
+    torch.cuda.synchronize()
+    st = opt._groups[0]
+    blocks_of_b = (st["b2s"] == 1).nonzero().flatten()
+    assert len(blocks_of_b) >= 2 and float(st["nsq"][blocks_of_b].abs().max()) == 0.0
+    assert float(st["nsq"][(st["b2s"] == 0).nonzero().flatten()].sum()) > 0
+    assert torch.equal(b.detach(), b0) and float(st["fac"][1]) == 1.0

@@ -1166,7 +1166,9 @@ class Plan:
                 with self.side(1):       # q projection: independent of the key path below
                     self.conv(F_, q_spec)
             sr_spec = self.conv_desc(XN, csr, Cs, sr, sr, 0, Hs // sr, Ws // sr, KR, bias=csr.bias, stats=stk)
-            if fused and (QSR_GROUP >> stage_i) & 1 and F_ and F_[-1].name == "crd_gn_conv":
+            small64 = lambda ohw: Cs <= 64 or -(-ohw // 64) * -(-Cs // 128) * B < 256        # crd_gn_conv2's rule: both problems on the 64 x 64 tiles
+            if (fused and (QSR_GROUP >> stage_i) & 1 and F_ and F_[-1].name == "crd_gn_conv" and F_[-1].meta["kernel"].startswith("k_gngemm_reg")
+                    and small64(Hs * Ws) and small64((Hs // sr) * (Ws // sr))):
                 # round 6: q (recorded just above) and sr in one launch
                 q_op = F_.pop()
                 sr_spec["x"] = X

@@ -634,3 +634,20 @@ def test_two_rank_replicas_stay_bit_identical(tmp_path):
     a, b = (torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2))
     assert torch.equal(a["flat"], b["flat"])
     assert (a["rng_rank"], b["rng_rank"]) == (0, 1) and not torch.equal(a["d2_masks"], b["d2_masks"])
+
+
+def test_q_sr_grouping_falls_back_where_the_library_would_refuse_it():
+    """Round 6: crd_gn_conv2 (q + sr of a stage-3 Block in one launch) covers the 64 x 64 tiles only; on a grid where crd_gn_conv takes the
+    128-column tiles for q (here 5 x 512 x 832: 260 column-tile workgroups) the plan must keep the two launches.  The first build of the
+    grouping raised CrdError at 4 x 928 x 1600 (config 4's benchmark size, which no test ran)."""
+    cfg = dataclasses.replace(ModelConfig.variant("base"), depths=(1, 1, 1, 1))
+    m = build(cfg)
+    x = synth.make_batch(5, 512, 832, seed=3)["image"].cuda()
+    out = m(x)["depth"]["final_depth"]
+    out.float().mean().backward()
+    torch.cuda.synchronize()
+    plan = m._plans[m._plan_key(x)]
+    assert sum(op.name == "crd_gn_conv2" for op in plan.fwd) == 0 and bool(torch.isfinite(out).all())
+    xs = synth.make_batch(2, 64, 96, seed=3)["image"].cuda()
+    m(xs)
+    assert sum(op.name == "crd_gn_conv2" for op in m._plans[m._plan_key(xs)].fwd) == 1

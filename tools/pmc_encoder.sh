@@ -27,7 +27,7 @@ run_set() {   # $1 label, $2 env, $3.. program
 import csv, sys, collections
 if len(sys.argv) < 2 or not sys.argv[1]:
     print("   (no output for", sys.argv[2] if len(sys.argv) > 2 else "?", ")"); sys.exit()
-WANT = ("k_igemm<2, 2, 1, 1", "k_gngemm_reg", "k_gn_bwd_apply", "k_gn_bwd_reduce", "k_dwconv", "k_attn_scores_bwd", "k_attn_scores"e",
+WANT = ("k_igemm<2, 2, 1, 1", "k_gngemm_reg", "k_gn_bwd_apply", "k_gn_bwd_reduce", "k_dwconv", "k_attn_scores_bwd", "k_attn_scores", "k_gnbwd_gemm", "k_attn_out_bwd",
         "k_conv3x3p", "k_wgrad3x3", "k_pw_narrow", "k_gn_pw_wide", "k_wgrad_grouped")
 agg = collections.defaultdict(list)
 tot = collections.defaultdict(float)
@@ -47,5 +47,5 @@ PY
     rm -rf $O/p$i
   done
 }
-run_set "eager training iterations x3 (per-launch encoder), base 8x7x256x416" "CRD_ENC_PERSIST=0" tools/run_forward.py 3 train
+run_set "eager training iterations x3 (per-launch encoder), base 8x7x256x416" "CRD_UNUSED=0" tools/run_forward.py 3 train
 cat $O/summary.txt

@@ -164,12 +164,14 @@ def igemm_tile(cout, ohw=1 << 30, batch=1):
 # Round 6: the APPLY phase of a GroupNorm backward inside the pointwise data-gradient GEMM that consumes it (crd_gn_bwd_conv,
 # csrc/xfgemm.hip) instead of a crd_gn_bwd_apply launch: Mlp.norm1 in front of fc1's data gradient (GNB_FC1) and attn.norm in front of
 # the sr patch scatter (GNB_SR).  Bit s of a mask = encoder stage s + 1 (developer switches CRD_GNB_FC1 / CRD_GNB_SR for the A/B).
+# fc1 at stage 4 stays on the two launches: 832 rows x K = 1024 are 52 workgroups walking 32 serial K slabs in the fused kernel, 21.7 us
+# against 4.4 + 10.5 (split-K crd_conv_igemm); masks 15 / 7 / 3 / 1 in one call: 17.39 / 17.33-17.37 / 17.42-17.46 / 17.51 ms per step.
 # Round 6: the data gradients of a decoder stage's three ConvLayers (ShortResBlock, utils.py:127-135) as WRITE-ONCE launches over the
 # K-concatenated gradient buffer [d(raw2) | d(raw1) | d(raw0)]: columns [o1, o1+64) of the concat-buffer gradient from layer 2 alone
 # (K = 128 x 9), [o0, o1) from layers 2 | 1 (K = 192 x 9), [0, o0) from all three (K = 288 x 9) -- no read-modify-write of the 304-channel
 # gradient, no accumulating epilogue.  Developer switch CRD_KCAT=0: the per-layer accumulating launches of rounds 1-5 (the A/B).
 KCAT = _dev_int("CRD_KCAT", 1) != 0
-GNB_FC1 = _dev_int("CRD_GNB_FC1", 15)
+GNB_FC1 = _dev_int("CRD_GNB_FC1", 7)
 GNB_SR = _dev_int("CRD_GNB_SR", 15)
 # attn.q and the attn.sr patch convolution of a Block as ONE launch (crd_gn_conv2: both read Block.norm1(x); sr normalises its own rows
 # instead of waiting for q's stored copy).  Bit s = encoder stage s + 1.  Stage 3 only: measured in one call (profiles/r06_ab_q_sr_grouped.txt)

@@ -96,9 +96,9 @@ def test_round6_plan_structure():
     for op in dec:
         if op.name == "crd_conv_igemm" and " k3 " in op.meta["shape"] and "dgrad" in op.meta["shape"] and "Cin32" not in op.meta["shape"]:
             assert "dgrad-kcat" in op.meta["shape"], op.meta["shape"]   # (the heads' 32 -> 128 data gradients still accumulate into d(stage))
-    assert sum(op.name == "crd_gn_bwd_conv" for op in p.bwd) == 4 + 3   # fc1 behind Mlp.norm1 in every Block, the sr scatter at stages 1-3
+    assert sum(op.name == "crd_gn_bwd_conv" for op in p.bwd) == 3 + 3   # fc1 behind Mlp.norm1 in the Blocks of stages 1-3 (stage 4 keeps the two launches), the sr scatter at stages 1-3
     assert sum(op.name == "crd_gn_conv2" for op in p.fwd) == 1          # stage 3
     assert len(p.kcat_entries) == 5 * 6                                 # per stage: layer 2 -> WA, WB, WC; layer 1 -> WB, WC; layer 0 -> WC
     # what is left of crd_gn_bwd_apply in a Block: Mlp.norm2 (+ GELU) and Block.norm1; Block.norm2's rides in crd_attn_out_bwd_gn
     enc = [op.name for (tag, a, b) in p.bwd_segments if tag != "dec" for op in p.bwd[a:b]]
-    assert enc.count("crd_gn_bwd_apply") == 4 * 2 + 4                   # 2 per Block + the four patch embeds' norms
+    assert enc.count("crd_gn_bwd_apply") == 4 * 2 + 1 + 4               # 2 per Block (+ Mlp.norm1's at stage 4) + the four patch embeds' norms

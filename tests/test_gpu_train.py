@@ -651,3 +651,25 @@ def test_q_sr_grouping_falls_back_where_the_library_would_refuse_it():
     xs = synth.make_batch(2, 64, 96, seed=3)["image"].cuda()
     m(xs)
     assert sum(op.name == "crd_gn_conv2" for op in m._plans[m._plan_key(xs)].fwd) == 1
+
+
+def test_plan_labels_name_the_kernels_that_ran():
+    """the plan labels launches "k_pw_narrow" from the shape query (crd_pw_narrow_supported) while the library decides with
+    crd_pw_narrow_applicable (alignment, leading dimensions, epilogue): the two must agree on a real step, or the floor budget and the
+    per-kernel tables attribute time to a kernel that did not run.  Same for the fused GroupNorm-backward GEMM and the grouped q + sr launch,
+    which are entry points of their own (their launch counts are the ops' counts)."""
+    from camradepth_amd import lib
+    L = lib.load()
+    cfg = dataclasses.replace(ModelConfig.variant("base"), depths=(1, 2, 1, 1))
+    m = build(cfg)
+    x = synth.make_batch(2, 256, 416, seed=5)["image"].cuda()
+    m(x)["depth"]["final_depth"].float().mean().backward()        # builds the plan (and runs it once)
+    torch.cuda.synchronize()
+    plan = m._plans[m._plan_key(x)]
+    labelled = sum(1 for op in plan.fwd + plan.bwd if str((op.meta or {}).get("kernel", "")).startswith("k_pw_narrow"))
+    assert labelled >= 3                                          # at least fc2 (behind Mlp.norm2 + GELU) of the three Blocks at stages 1-2
+    n0 = L.crd_tune_pw_narrow(-1)
+    m.zero_grad(set_to_none=True)
+    m(x)["depth"]["final_depth"].float().mean().backward()
+    torch.cuda.synchronize()
+    assert L.crd_tune_pw_narrow(-1) - n0 == labelled, "plan labels and the library's dispatch disagree on the narrow pointwise kernel"

@@ -3,6 +3,7 @@ cd "$GRAFT_REPO_ROOT"; O=gpurun_out/final6; rm -rf $O; mkdir -p $O
 ( time timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 ) > $O/gpu_tests.log 2>&1; tail -3 $O/gpu_tests.log
 timeout 900 python bench.py > $O/bench_c2.json 2> $O/bench_c2.err; cut -c1-300 $O/bench_c2.json
 timeout 600 bash tools/profile_round.sh > $O/profile_round.log 2>&1; cp gpurun_out/prof_round/kernel_stats.md gpurun_out/prof_round/one_step.txt gpurun_out/prof_round/bench.log $O/
+cp $O/one_step.txt profiles/r06_one_step_kernels.txt     # the second bench's frac_committed_trace reads this table
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 rm -rf $O/fwd_trace; timeout 300 rocprofv3 --kernel-trace --stats -d $O/fwd_trace -o fwd -- python3 bench.py --inference --batch 8 --steps 20 > $O/bench_inf_b8.json 2> $O/bench_inf_b8.err
 python3 tools/rocprof_forward.py $(ls $O/fwd_trace/*.db | head -1) > $O/forward_only_kernels.txt 2>&1; rm -rf $O/fwd_trace; head -3 $O/forward_only_kernels.txt

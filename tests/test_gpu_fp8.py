@@ -245,6 +245,7 @@ def test_fp8_forward_in_training_matches_oracle_ste():
         errs.append((rel(g, go), n))
     dec = [e for e, n in errs if n.startswith("depth_upsample.3") or n.startswith("depth_upsample.4")]
     med, worst_dec = float(np.median([e for e, _ in errs])), max(dec)
+    loss, lo = loss.detach(), lo.detach()
     print(f"fp8 forward in training: loss {float(loss):.6f} vs oracle {float(lo):.6f}, final depth rel-L2 {r_out:.4f}, "
           f"gradient rel-L2 median {med:.4f}, worst of the fp8 stages' parameters {worst_dec:.4f}")
     assert abs(float(loss) - float(lo)) <= 5e-3 * abs(float(lo))

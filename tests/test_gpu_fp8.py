@@ -454,7 +454,7 @@ def _fp8_grad_step_vs_oracle(depths, B, H, W, seed=77, reference_init=False):
         q_errs.append(rel(go, gb))
         ratios.append(float(g.double().norm() / (go.double().norm() + 1e-30)))
     model.calibrate_fp8(None)
-    return float(loss), float(lo), errs, q_errs, np.array(ratios), gsc
+    return float(loss.detach()), float(lo.detach()), errs, q_errs, np.array(ratios), gsc
 
 
 def test_fp8_data_gradients_in_training_match_oracle_fp8_mode_shallow():

@@ -10,6 +10,8 @@
 // split across workgroups (split-K); partial tiles meet in a 64-bit fixed-point accumulator (integer
 // atomics: the sum does not depend on the order of arrival, see crd_sum_t).
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 #include "common.h"
 
 int crd_wgrad3x3_stream(const crd_wgrad_desc* d, hipStream_t st);   // wgrad3x3.hip
@@ -201,6 +203,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgK a) {
 template <int WMc, int WNc, int TMc, int TNc>
 __global__ __launch_bounds__(256) void k_wgrad_grouped(const WgK* __restrict__ probs, const int4* __restrict__ items) {
   const int4 it = items[blockIdx.x];
+  if (it.x < 0) return;                               // padding of the XCD-interleaved item list
   const WgK a = probs[it.x];
   wgrad_tile<WMc, WNc, TMc, TNc>(a, it.y, it.z, it.w);
 }
@@ -264,38 +267,75 @@ const int CFG_BM[4] = {32, 64, 96, 128};
 extern "C" int crd_wgrad_group_build(const crd_wgrad_desc* descs, int32_t n, void* host_table, int64_t capacity,
                                      crd_wgrad_group_info* info) {
   CRD_CHECK_ARG(descs && info && n > 0, "crd_wgrad_group_build: null pointer / empty group");
-  // pass 1: plan every problem, count the work items of each tile configuration
+  // Item order (round 6): workgroups are dealt to the 8 XCDs round-robin by index, and the tiles of one (problem, K split) re-read the same
+  // x and dy rows -- tn x tm of them, e.g. 30 for a stage-3 fc layer.  Dealt in problem order each XCD's L2 fetched its own copy
+  // (457 MB per launch of the stage-3 group for 10 MB of unique operands per Block: profiles/r06_pmc_traffic.json).  So the units
+  // (problem, split) are binned onto the XCDs -- largest first onto the least-loaded bin -- and the item list interleaves the bins:
+  // item 8 j + x is the j-th item of XCD x's bin; bins shorter than the longest end in no-op items (problem index -1).  Where whole
+  // units do not balance over the XCDs the pieces get finer (rows of tiles, then single tiles = the plain order).
+  constexpr int NX = 8;
   const long long head = ((long long)n * sizeof(WgK) + 15) / 16 * 16;
-  long long count[4] = {0, 0, 0, 0};
-  WgK* probs = reinterpret_cast<WgK*>(host_table);
-  for (int pass = 0; pass < 2; ++pass) {
-    long long cursor[4];
-    if (pass == 1) {
-      long long off = 0;
-      for (int c = 0; c < 4; ++c) { info->item_offset[c] = (int32_t)off; info->n_items[c] = (int32_t)count[c]; cursor[c] = off; off += count[c]; }
-      info->n_problems = n;
-      info->bytes = head + off * (long long)sizeof(int4);
-      if (host_table == nullptr) return CRD_OK;                                // size query
-      CRD_CHECK_ARG(capacity >= info->bytes, "crd_wgrad_group_build: the table needs %lld bytes, capacity is %lld", (long long)info->bytes,
-                    (long long)capacity);                                      // (was taken for a size query: rc 0, nothing written)
-    }
-    for (int i = 0; i < n; ++i) {
-      WgK k;
-      int rc = fill(&descs[i], k);
-      if (rc == CRD_OK) rc = check_generic(k);
-      if (rc != CRD_OK) return rc;
-      const int c = cfg_of(k.Cout);
-      const int tn = cdiv(k.Ktot, 128), tm = cdiv(k.Cout, CFG_BM[c]);
-      // the group as a whole fills the chip: long K runs per workgroup (8 steps) keep the atomics per problem low
-      const long long splits = plan_splits(k, tn * tm, 1 << 20, 8);
-      if (pass == 0) { count[c] += (long long)tn * tm * splits; continue; }
-      probs[i] = k;
-      int4* items = reinterpret_cast<int4*>(reinterpret_cast<char*>(host_table) + head);
-      for (long long s = 0; s < splits; ++s)
-        for (int m = 0; m < tm; ++m)
-          for (int t = 0; t < tn; ++t) items[cursor[c]++] = make_int4(i, t, m, (int)s);
-    }
+  struct Unit { int prob, split, tn, tm; };
+  std::vector<WgK> ks((size_t)n);
+  std::vector<Unit> units[4];
+  for (int i = 0; i < n; ++i) {
+    WgK k;
+    int rc = fill(&descs[i], k);
+    if (rc == CRD_OK) rc = check_generic(k);
+    if (rc != CRD_OK) return rc;
+    const int c = cfg_of(k.Cout);
+    const int tn = cdiv(k.Ktot, 128), tm = cdiv(k.Cout, CFG_BM[c]);
+    // the group as a whole fills the chip: long K runs per workgroup (8 steps) keep the atomics per problem low.  (No K split at all for a
+    // launch whose tiles alone are two workgroups per CU -- stage 3: 690 tiles -- measured 218 -> 204 us for that launch and nothing in
+    // the step; not kept: one round of long-K workgroups quantises badly at other sizes.)
+    const long long splits = plan_splits(k, tn * tm, 1 << 20, 8);
+    ks[(size_t)i] = k;
+    for (long long sp = 0; sp < splits; ++sp) units[c].push_back(Unit{i, (int)sp, tn, tm});
   }
+  std::vector<int4> lists[4];
+  long long off = 0;
+  for (int c = 0; c < 4; ++c) {
+    std::vector<Unit>& u = units[c];
+    std::stable_sort(u.begin(), u.end(), [](const Unit& p, const Unit& q) { return p.tn * p.tm > q.tn * q.tm; });
+    // granularity 0: a whole (problem, split) per bin entry; 1: one row of tiles (same dy columns, all of x) when the whole units do not
+    // balance -- a group of a few large problems must not be confined to a few XCDs; 2: single tiles, i.e. the plain round-robin order
+    for (int gran = 0; gran < 3; ++gran) {
+      std::vector<int4> bins[NX];
+      for (const Unit& w : u) {
+        const int pieces = gran == 0 ? 1 : gran == 1 ? w.tm : w.tm * w.tn;
+        for (int pc = 0; pc < pieces; ++pc) {
+          int best = 0;
+          for (int x = 1; x < NX; ++x)
+            if (bins[x].size() < bins[best].size()) best = x;
+          const int m0 = gran == 0 ? 0 : gran == 1 ? pc : pc / w.tn, m1 = gran == 0 ? w.tm : m0 + 1;
+          const int t0 = gran == 2 ? pc % w.tn : 0, t1 = gran == 2 ? t0 + 1 : w.tn;
+          for (int m = m0; m < m1; ++m)
+            for (int t = t0; t < t1; ++t) bins[best].push_back(make_int4(w.prob, t, m, w.split));
+        }
+      }
+      size_t longest = 0, total = 0;
+      for (int x = 0; x < NX; ++x) { longest = bins[x].size() > longest ? bins[x].size() : longest; total += bins[x].size(); }
+      if (gran < 2 && longest * NX > total + total / 8 + NX) continue;          // more than ~12 % of the launch would idle: finer pieces
+      lists[c].clear();
+      for (size_t j = 0; j < longest; ++j)
+        for (int x = 0; x < NX; ++x) lists[c].push_back(j < bins[x].size() ? bins[x][j] : make_int4(-1, 0, 0, 0));
+      while (!lists[c].empty() && lists[c].back().x < 0) lists[c].pop_back();    // (trailing no-ops)
+      break;
+    }
+    info->item_offset[c] = (int32_t)off;
+    info->n_items[c] = (int32_t)lists[c].size();
+    off += (long long)lists[c].size();
+  }
+  info->n_problems = n;
+  info->bytes = head + off * (long long)sizeof(int4);
+  if (host_table == nullptr) return CRD_OK;                                // size query
+  CRD_CHECK_ARG(capacity >= info->bytes, "crd_wgrad_group_build: the table needs %lld bytes, capacity is %lld", (long long)info->bytes,
+                (long long)capacity);                                      // (was taken for a size query: rc 0, nothing written)
+  WgK* probs = reinterpret_cast<WgK*>(host_table);
+  for (int i = 0; i < n; ++i) probs[i] = ks[(size_t)i];
+  int4* items = reinterpret_cast<int4*>(reinterpret_cast<char*>(host_table) + head);
+  for (int c = 0; c < 4; ++c)
+    for (size_t j = 0; j < lists[c].size(); ++j) items[info->item_offset[c] + (long long)j] = lists[c][j];
   return CRD_OK;
 }
 

@@ -272,7 +272,10 @@ int crd_conv_wgrad_splits(const crd_wgrad_desc* d);
  * per backward segment and runs them as ONE dispatch once their inputs exist.  crd_wgrad_group_build plans the group
  * on the host (problem descriptors + one work item per workgroup) into host_table; the caller copies the table to
  * device memory once and replays it with crd_conv_wgrad_grouped.  Calling build with host_table = NULL only fills
- * info->bytes (size query); a non-NULL table smaller than that is an error (CRD_E_INVALID).  The inputs named by the descriptors must stay valid until the grouped call. */
+ * info->bytes (size query); a non-NULL table smaller than that is an error (CRD_E_INVALID).  The inputs named by the descriptors must stay valid until the grouped call.
+ * Round 6: the items of a configuration are ordered for the 8 XCDs (workgroup index mod 8 = XCD): all tiles of one (problem, K split)
+ * -- they re-read the same x and dy rows -- sit at indices of one residue, so the re-reads hit that XCD's L2; the list may contain
+ * no-op items (problem index -1) where the XCDs' shares differ in length, and n_items counts them. */
 typedef struct crd_wgrad_group_info {
   int32_t n_problems;
   int32_t n_items[4];      /* work items (workgroups) per tile configuration */

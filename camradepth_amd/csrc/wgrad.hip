@@ -269,7 +269,7 @@ extern "C" int crd_wgrad_group_build(const crd_wgrad_desc* descs, int32_t n, voi
   CRD_CHECK_ARG(descs && info && n > 0, "crd_wgrad_group_build: null pointer / empty group");
   // Item order (round 6): workgroups are dealt to the 8 XCDs round-robin by index, and the tiles of one (problem, K split) re-read the same
   // x and dy rows -- tn x tm of them, e.g. 30 for a stage-3 fc layer.  Dealt in problem order each XCD's L2 fetched its own copy
-  // (457 MB per launch of the stage-3 group for 10 MB of unique operands per Block: profiles/r06_pmc_traffic.json).  So the units
+  // (the grouped launches fetched 457 MB each on average, the stage-3 group's unique operands are ~280 MB: profiles/r06_pmc_traffic.json).  So the units
   // (problem, split) are binned onto the XCDs -- largest first onto the least-loaded bin -- and the item list interleaves the bins:
   // item 8 j + x is the j-th item of XCD x's bin; bins shorter than the longest end in no-op items (problem index -1).  Where whole
   // units do not balance over the XCDs the pieces get finer (rows of tiles, then single tiles = the plain order).

@@ -25,6 +25,7 @@ struct ConvK {
   crd_sum_t* chan;   // optional per-channel (sum, sumsq) of the stored output [B][Cout][2] (scalar epilogue path only)
   int col0;  // first output column of this launch (the 3x3 halo kernel covers wide layers with two tile widths)
   int dbg;   // developer experiments only (CRD_DBG env): 1 no weight-DMA wait, 2 no DMA at all, 4 no epilogue
+  int ny_tiles;   // column tiles of the launch, for kernels that decode (row tile, column tile) from a 1-D XCD-aware grid (xfgemm.hip)
 };
 
 

@@ -106,7 +106,19 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
   const int t = threadIdx.x, l = t & 63;
   const int wv = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wv / WN, wn = wv % WN;
-  const int b = blockIdx.z, m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // workgroup -> (row tile, column tile): the column tiles of one row tile re-read (and re-transform) the same dy / x rows; workgroups go
+  // to the XCDs round-robin by linear index, so indices i and i + 8 share an XCD and its L2.  With a.ny_tiles != 0 the launch is a
+  // (8 ny ceil(row tiles / 8), 1, B) grid in which the column tiles of a row tile are 8 apart (a multiple of 8 per sample, so every sample
+  // starts on XCD 0).  The plain (row tile, column tile, sample) grid put them on different XCDs and each fetched its rows from HBM:
+  // stage 2's fc1 34.5 -> 30.0 us, stage 3's 17.5 -> 16.7 with this order.  Launches with fewer than 7 row tiles per sample (the sr
+  // scatter: 2 row tiles x 32-64 column tiles) keep the plain grid -- their row tiles alone cannot cover the XCDs (8.5 -> 23 us when forced).
+  // (The same order in k_igemm and k_gngemm_reg, whose operands arrive by LDS-DMA / are read once per launch: no gain, 13.8 -> 14.7 us on
+  // fc2's data gradient at stage 3 -- not kept there.  profiles/r06_ab_xcd_tile_order.txt)
+  const int ny = a.ny_tiles;
+  const int bx = ny ? (int)(blockIdx.x / (8 * ny)) * 8 + (int)(blockIdx.x & 7) : (int)blockIdx.x;
+  const int by = ny ? (int)(blockIdx.x % (8 * ny)) >> 3 : (int)blockIdx.y;
+  if (bx >= a.n_tiles) return;
+  const int b = blockIdx.z, m0 = bx * BM, n0 = by * BN;
   const int r0 = 8 * wv + (l >> 3);                   // this thread's rows: r0 + 32 i; LDS slot l & 7 <- K granule g (k_igemm's swizzle)
   const int g = (l & 7) ^ ((r0 >> 1) & 7);
   const unsigned OOB = 0x80000000u;
@@ -120,7 +132,7 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
       (void*)(xi.dx ? xi.dx + (long long)b * xi.dx_bstride : reinterpret_cast<bf16_t*>(const_cast<void*>(xi.gx))), 0,
       xi.dx ? (int)(xi.dx_bstride * 2) : 0, 0x00020000);
   const int nK = (a.Ktot + BK - 1) / BK;
-  const bool store_dx = xi.dx != nullptr && blockIdx.y == 0;
+  const bool store_dx = xi.dx != nullptr && by == 0;
 
   // Loop-invariant BYTE offsets of this thread's rows in dy / x / dx, with the row's validity folded in (an invalid row starts at the
   // out-of-range offset, and stays out of range whatever is added): every load and store of the K loop is then UNCONDITIONAL.  Written
@@ -204,8 +216,8 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
   load_slab(0, r0s);
   load_slab(1, r1s);                                  // (slabs past the end: every offset out of range -- zeros, no traffic)
   // the GroupNorm's parameter gradients: the workgroups of sample 0 / column tile 0 share the channels (crd_gn_bwd_apply's rule)
-  if (b == 0 && blockIdx.y == 0 && xi.dgamma) {
-    for (int c = blockIdx.x * 256 + t; c < a.Cin; c += gridDim.x * 256) {
+  if (b == 0 && by == 0 && xi.dgamma) {
+    for (int c = bx * 256 + t; c < a.Cin; c += a.n_tiles * 256) {
       const float ob = xi.dbeta[c], og = xi.dgamma[c];
       long long g0, g1;
       sum_samples(xi.r, xi.B, a.Cin, c, g0, g1);
@@ -245,7 +257,7 @@ __global__ __launch_bounds__(256) void k_gnbwd_gemm(ConvK a, XfIn xi) {
     mfma_slab<TN>(sA, sB, acc, wm, wn, l);
     lds_barrier();
   }
-  conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, blockIdx.x, lds,
+  conv_epilogue<TM, TN, WM, WN>(a, acc, b, l, wm, wn, n0, bx, lds,
                                 [&](int i, int rr, bool& valid, int& row) { row = m0 + (wm * TM + i) * 32 + rr; valid = row < a.OHW; },
                                 [&](int rl, bool& valid, int& row) { row = m0 + rl; valid = row < a.OHW; });
 }
@@ -266,7 +278,11 @@ int launch(const ConvK& k0, const XfIn& xi, int B, hipStream_t st) {
     attr_done = true;
   }
   k.lds_bytes = (int)tiles;
-  hipLaunchKernelGGL((k_gnbwd_gemm<TN, ACT, GXF32>), dim3(k.n_tiles, cdiv(k.Cout, BN), B), dim3(256), lds, st, k, xi);
+  const int ny = cdiv(k.Cout, BN);
+  const bool xcd = ny >= 2 && k.n_tiles >= 7;
+  k.ny_tiles = xcd ? ny : 0;
+  if (xcd) hipLaunchKernelGGL((k_gnbwd_gemm<TN, ACT, GXF32>), dim3(8 * ny * cdiv(k.n_tiles, 8), 1, B), dim3(256), lds, st, k, xi);
+  else hipLaunchKernelGGL((k_gnbwd_gemm<TN, ACT, GXF32>), dim3(k.n_tiles, ny, B), dim3(256), lds, st, k, xi);
   CRD_LAUNCH_CHECK("crd_gn_bwd_conv");
   return CRD_OK;
 }
